@@ -1,0 +1,121 @@
+"""TEST INFRASTRUCTURE — deterministic episode traces over a BuchbergerEnv-like checker.
+
+Used by oracle/make_golden.py (on the compiled reference) to produce
+tests/golden/*.npz and by the tests to replay the same action sequences on the
+C restatement and on the HIP path.
+"""
+import numpy as np
+
+from . import ffi
+
+FNV_OFF = 0xcbf29ce484222325
+FNV_PRIME = 0x100000001b3
+M64 = (1 << 64) - 1
+
+
+def fnv64(arr, h=FNV_OFF):
+    """FNV-1a over the int32 little-endian words of arr (word-wise, not byte-wise)."""
+    a = np.ascontiguousarray(arr, dtype=np.int32).ravel().astype(np.uint32)
+    for w in a.tolist():
+        h = ((h ^ w) * FNV_PRIME) & M64
+    return h
+
+
+def fnv64_fast(arr, h=FNV_OFF):
+    """Same value as fnv64, vectorised in chunks via python ints only when small;
+    for big arrays callers should hash per step (arrays are tiny per step)."""
+    return fnv64(arr, h)
+
+
+def degree_action(env):
+    """First pair (in P order) of minimal deg lcm(LM_i, LM_j): buchberger.cpp:171-176
+    given P's (j,i)-ascending invariant; also LeadMonomialsAgent('degree') (buchberger.py:562-565)."""
+    pairs = env.pairs()
+    best, arg = None, 0
+    lms = {}
+    for r, (i, j) in enumerate(pairs):
+        for g in (i, j):
+            if g not in lms:
+                lms[g] = env.poly(int(g))[1][0]
+        d = int(np.maximum(lms[i], lms[j]).sum())
+        if best is None or d < best:
+            best, arg = d, r
+    return arg
+
+
+def poly_words(coef, exps):
+    """Canonical int32 word stream of a polynomial: [nterms, c0, e0[8], c1, e1[8], ...]."""
+    n = len(coef)
+    out = np.zeros(1 + n * 9, dtype=np.int32)
+    out[0] = n
+    if n:
+        body = np.concatenate([np.asarray(coef, dtype=np.int32)[:, None], np.asarray(exps, dtype=np.int32)], axis=1)
+        out[1:] = body.ravel()
+    return out
+
+
+def run_trace(env, k, nsteps, policy, agent_seed=0, nobs=None, until_done=False, max_steps=100000):
+    """Drive `env` (already seeded) and record a per-step trace.
+
+    policy: 'hash' (action = agent_hash(agent_seed, t) mod |P|), 'degree', 'first'.
+    Auto-resets on done unless until_done.  Returns dict of numpy arrays.
+    """
+    n = env.nvars() if nobs is None else nobs
+    env.reset()
+    rec = {key: [] for key in ("action", "reward", "nP", "nG", "obs_hash", "pairs_hash", "newpoly_hash", "done")}
+    init = {"nG": env.nG, "nP": env.nP, "obs_hash": fnv64(env.obs(k, n)), "pairs_hash": fnv64(env.pairs())}
+    t = 0
+    while True:
+        if until_done:
+            if t >= max_steps:
+                break
+        elif t >= nsteps:
+            break
+        nP = env.nP
+        if policy == "hash":
+            a = ffi.agent_hash(agent_seed, t) % nP
+        elif policy == "degree":
+            a = degree_action(env)
+        elif policy == "first":
+            a = 0
+        else:
+            raise ValueError(policy)
+        nG0 = env.nG
+        r = env.step(a)
+        done = env.nP == 0
+        rec["action"].append(a); rec["reward"].append(r); rec["nP"].append(env.nP); rec["nG"].append(env.nG)
+        rec["obs_hash"].append(fnv64(env.obs(k, n))); rec["pairs_hash"].append(fnv64(env.pairs()))
+        rec["newpoly_hash"].append(fnv64(poly_words(*env.poly(env.nG - 1))) if env.nG > nG0 else 0)
+        rec["done"].append(int(done))
+        t += 1
+        if done:
+            if until_done:
+                break
+            env.reset()
+    out = {
+        "action": np.array(rec["action"], dtype=np.int32),
+        "reward": np.array(rec["reward"], dtype=np.float64),
+        "nP": np.array(rec["nP"], dtype=np.int32),
+        "nG": np.array(rec["nG"], dtype=np.int32),
+        "done": np.array(rec["done"], dtype=np.int8),
+        "obs_hash": np.array(rec["obs_hash"], dtype=np.uint64),
+        "pairs_hash": np.array(rec["pairs_hash"], dtype=np.uint64),
+        "newpoly_hash": np.array(rec["newpoly_hash"], dtype=np.uint64),
+        "init": np.array([init["nG"], init["nP"]], dtype=np.int32),
+        "init_hash": np.array([init["obs_hash"], init["pairs_hash"]], dtype=np.uint64),
+    }
+    # full dump of the final state
+    out["final_pairs"] = env.pairs().astype(np.int32)
+    out["final_order"] = env.reducer_order().astype(np.int32)
+    words = [poly_words(*env.poly(i)) for i in range(env.nG)]
+    out["final_basis"] = np.concatenate(words) if words else np.zeros(0, dtype=np.int32)
+    out["final_obs"] = env.obs(k, n)
+    return out
+
+
+def flat_ideal(polys):
+    """[[(c,(e..)),..],..] -> int32 word stream (poly_words per polynomial, prefixed by count)."""
+    w = [np.array([len(polys)], dtype=np.int32)]
+    for p in polys:
+        w.append(poly_words([t[0] for t in p], ffi.pad_exps([t[1] for t in p]) if p else np.zeros((0, 8))))
+    return np.concatenate(w)
