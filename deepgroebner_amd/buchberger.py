@@ -1,0 +1,201 @@
+"""Gym-style Buchberger environments with the surface of the reference's
+deepgroebner.wrapped.CLeadMonomialsEnv (wrapped.pyx:11-38) and
+deepgroebner.buchberger.LeadMonomialsEnv (buchberger.py:448-542), running on libbbx (HIP, gfx950).
+
+reset() -> int32 [rows, 2*n*k]; step(a) -> (state, reward, done, {}); seed(); value(); copy().
+VecLeadMonomialsEnv steps a whole batch of independent environments per call.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+from .ideals import FixedIdealGenerator
+
+NV = 8
+
+
+def _caps(caps):
+    if caps is None:
+        return None
+    c = _ffi.Caps()
+    for key, val in caps.items():
+        setattr(c, key, int(val))
+    return C.byref(c)
+
+
+class VecLeadMonomialsEnv:
+    """`batch` independent LeadMonomialsEnv instances stepped together on one GPU.
+
+    ideal_dist : distribution string (reference grammar) or FixedIdealGenerator
+    mimic : 'cpp'  -> observation width follows the C++ class (FixedIdealGenerator's
+                      largest-variable-index quirk, ideals.cpp:146-154)
+            'python' -> width follows ring.ngens like buchberger.py:537
+    """
+
+    def __init__(self, ideal_dist="3-20-10-weighted", batch=1, elimination="gebauermoeller", rewards="additions",
+                 sort_input=False, sort_reducers=True, k=1, device=0, caps=None, mimic="cpp"):
+        L = _ffi.lib()
+        self._h = C.c_void_p()
+        self.batch, self.k = int(batch), int(k)
+        el, rw = _ffi.ELIMINATION[elimination], _ffi.REWARDS[rewards]
+        if isinstance(ideal_dist, FixedIdealGenerator):
+            F = ideal_dist.F
+            nterms = np.array([len(f) for f in F], dtype=np.int32)
+            coefs = np.array([c for f in F for c, _ in f], dtype=np.int32)
+            exps = np.zeros((len(coefs), NV), dtype=np.int32)
+            r = 0
+            for f in F:
+                for _, e in f:
+                    exps[r, :len(e)] = e
+                    r += 1
+            nv = ideal_dist.nvars if mimic == "python" else 0
+            _ffi.check(L.bbx_create_fixed(len(F), _ffi.ptr(nterms), _ffi.ptr(coefs), _ffi.ptr(exps), nv, el, rw,
+                                          int(sort_input), int(sort_reducers), self.k, self.batch, int(device),
+                                          _caps(caps), C.byref(self._h)))
+        else:
+            _ffi.check(L.bbx_create(str(ideal_dist).encode(), el, rw, int(sort_input), int(sort_reducers), self.k,
+                                    self.batch, int(device), _caps(caps), C.byref(self._h)))
+        self.cols = L.bbx_cols(self._h)
+        self.nvars = L.bbx_nvars(self._h)
+        self.rows = np.zeros(self.batch, dtype=np.int32)
+        self._rewards = np.zeros(self.batch, dtype=np.float64)
+        self._dones = np.zeros(self.batch, dtype=np.uint8)
+
+    @classmethod
+    def _from_handle(cls, h, src):
+        self = cls.__new__(cls)
+        self._h = h
+        self.batch, self.k, self.cols, self.nvars = src.batch, src.k, src.cols, src.nvars
+        self.rows = src.rows.copy()
+        self._rewards = np.zeros(self.batch, dtype=np.float64)
+        self._dones = np.zeros(self.batch, dtype=np.uint8)
+        return self
+
+    def __del__(self):
+        try:
+            if self._h:
+                _ffi.lib().bbx_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # ---- reference surface, batched
+    def seed(self, seeds=None):
+        if seeds is None:
+            return
+        s = np.ascontiguousarray(np.broadcast_to(np.asarray(seeds, dtype=np.int64), (self.batch,)))
+        _ffi.check(_ffi.lib().bbx_seed(self._h, _ffi.ptr(s)))
+
+    def seed_agent(self, seeds):
+        s = np.ascontiguousarray(np.broadcast_to(np.asarray(seeds, dtype=np.uint32), (self.batch,)))
+        _ffi.check(_ffi.lib().bbx_seed_agent(self._h, _ffi.ptr(s)))
+
+    def reset(self, mask=None):
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        _ffi.check(_ffi.lib().bbx_reset(self._h, _ffi.ptr(m), _ffi.ptr(self.rows)))
+        return self.observations()
+
+    def step(self, actions):
+        a = np.ascontiguousarray(np.broadcast_to(np.asarray(actions, dtype=np.int32), (self.batch,)))
+        _ffi.check(_ffi.lib().bbx_step(self._h, _ffi.ptr(a), _ffi.ptr(self._rewards), _ffi.ptr(self._dones), _ffi.ptr(self.rows)))
+        return self.observations(), self._rewards.copy(), self._dones.astype(bool), [{} for _ in range(self.batch)]
+
+    def rollout(self, agent="random", nsteps=1, auto_reset=True):
+        _ffi.check(_ffi.lib().bbx_rollout(self._h, _ffi.AGENTS[agent], int(nsteps), int(auto_reset),
+                                          _ffi.ptr(self._rewards), _ffi.ptr(self._dones), _ffi.ptr(self.rows)))
+        return self._rewards.copy(), self._dones.astype(bool), self.rows.copy()
+
+    def observations(self, max_rows=None, fill=True):
+        """List of per-environment int32 [rows_e, cols] matrices (max_rows=None) or the padded
+        int32 [batch, max_rows, cols] block with -1 fill."""
+        mr = int(max(1, self.rows.max())) if max_rows is None else int(max_rows)
+        out = np.empty((self.batch, mr, self.cols), dtype=np.int32)
+        _ffi.check(_ffi.lib().bbx_obs(self._h, _ffi.ptr(out), mr, int(fill)))
+        if max_rows is None:
+            return [out[e, :self.rows[e]].copy() for e in range(self.batch)]
+        return out
+
+    def value(self, idx=0, strategy="degree", gamma=0.99):
+        v = C.c_double()
+        _ffi.check(_ffi.lib().bbx_value(self._h, int(idx), strategy.encode(), float(gamma), C.byref(v)))
+        return v.value
+
+    def copy(self):
+        h = C.c_void_p()
+        _ffi.check(_ffi.lib().bbx_copy(self._h, C.byref(h)))
+        return VecLeadMonomialsEnv._from_handle(h, self)
+
+    # ---- introspection
+    def stats(self):
+        out = np.zeros((self.batch, 6), dtype=np.int64)
+        _ffi.check(_ffi.lib().bbx_stats(self._h, _ffi.ptr(out)))
+        return out
+
+    def state(self, idx=0):
+        """(basis, pairs, reducer_order): basis = list of (coefs[int32 n], exps[int32 n,8])."""
+        nG, nP, nT = C.c_int32(), C.c_int32(), C.c_int32()
+        _ffi.check(_ffi.lib().bbx_state_sizes(self._h, int(idx), C.byref(nG), C.byref(nP), C.byref(nT)))
+        nterms = np.zeros(max(nG.value, 1), dtype=np.int32)
+        coefs = np.zeros(max(nT.value, 1), dtype=np.int32)
+        exps = np.zeros((max(nT.value, 1), NV), dtype=np.int32)
+        pairs = np.zeros((max(nP.value, 1), 2), dtype=np.int32)
+        order = np.zeros(max(nG.value, 1), dtype=np.int32)
+        _ffi.check(_ffi.lib().bbx_state_get(self._h, int(idx), _ffi.ptr(nterms), _ffi.ptr(coefs), _ffi.ptr(exps), _ffi.ptr(pairs), _ffi.ptr(order)))
+        basis, at = [], 0
+        for g in range(nG.value):
+            basis.append((coefs[at:at + nterms[g]].copy(), exps[at:at + nterms[g]].copy()))
+            at += nterms[g]
+        return basis, pairs[:nP.value].copy(), order[:nG.value].copy()
+
+    def trace_enable(self, capacity):
+        _ffi.check(_ffi.lib().bbx_trace_enable(self._h, int(capacity)))
+
+    def trace_read(self, env, first, count):
+        out = np.zeros(count, dtype=_ffi.TRACE_DTYPE)
+        _ffi.check(_ffi.lib().bbx_trace_read(self._h, int(env), int(first), int(count), _ffi.ptr(out)))
+        return out
+
+
+class CLeadMonomialsEnv:
+    """Drop-in for deepgroebner.wrapped.CLeadMonomialsEnv (wrapped.pyx:11-38): one environment,
+    always Gebauer-Moeller / additions like the C++ class (the Cython class ignores those two
+    arguments, wrapped.pyx:16 -> buchberger.cpp:377)."""
+
+    _mimic = "cpp"
+
+    def __init__(self, ideal_dist="3-20-10-weighted", elimination="gebauermoeller", rewards="additions",
+                 sort_input=False, sort_reducers=True, k=1, device=0, caps=None, _vec=None):
+        if _vec is not None:
+            self._vec = _vec
+            return
+        if self._mimic == "cpp":
+            elimination, rewards = "gebauermoeller", "additions"
+        self._vec = VecLeadMonomialsEnv(ideal_dist, 1, elimination, rewards, sort_input, sort_reducers, k, device, caps, self._mimic)
+
+    def reset(self):
+        return self._vec.reset()[0]
+
+    def step(self, action):
+        obs, r, d, _ = self._vec.step(int(action))   # accepts numpy / python scalars like action.numpy()
+        return obs[0], float(r[0]), bool(d[0]), {}
+
+    def seed(self, seed=None):
+        if seed is not None:
+            self._vec.seed([seed])
+
+    def value(self, strategy="degree", gamma=0.99):
+        return self._vec.value(0, strategy, gamma)
+
+    def copy(self):
+        return type(self)(_vec=self._vec.copy())
+
+
+class LeadMonomialsEnv(CLeadMonomialsEnv):
+    """Drop-in for the pure-Python deepgroebner.buchberger.LeadMonomialsEnv (buchberger.py:448-542):
+    honours elimination/rewards, accepts a FixedIdealGenerator, observation width = ring variables."""
+
+    _mimic = "python"
+
+    def value(self, gamma=0.99):
+        return self._vec.value(0, "degree", gamma)

@@ -1,0 +1,642 @@
+// libbbx.so — host side of the C ABI declared in include/bbx.h.
+// Owns the device memory (environment records, ideal queues, output buffers), drives the HIP
+// kernels in bbx_kernels.hip and keeps the per-environment ideal generators (bbx_ideals.cpp).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/bbx.h"
+#include "bbx_common.h"
+#include "bbx_ideals.h"
+
+extern "C" int bbx_launch_step(const BbxParams* p, int staged, int envs_per_block, hipStream_t stream);
+extern "C" int bbx_launch_init(char* recs, uint32_t rec_bytes, int B, const uint32_t* agent_seeds, hipStream_t stream);
+extern "C" int bbx_launch_mark_reset(char* recs, uint32_t rec_bytes, int B, const uint8_t* mask, hipStream_t stream);
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+  g_err = buf;
+  return code;
+}
+#define HIPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(BBX_E_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); } while (0)
+
+uint32_t align16(uint32_t x) { return (x + 15u) & ~15u; }
+
+BbxLayout make_layout(int W, int maxG, int maxP, int arena, int maxT) {
+  BbxLayout L{};
+  L.W = W; L.maxG = maxG; L.maxP = maxP; L.arena = arena; L.maxT = maxT;
+  const uint32_t MW = 4u * W;
+  uint32_t o = sizeof(BbxHdr);
+  auto take = [&o](uint32_t bytes) { uint32_t at = o; o = align16(o + bytes); return at; };
+  L.off_lm = take(MW * maxG); L.off_slm = take(MW * maxG); L.off_lcm = take(MW * maxG);
+  L.off_am = take(MW * arena); L.off_hm = take(MW * 5u * maxT);
+  L.off_poff = take(4u * maxG); L.off_pairs = take(4u * maxP);
+  L.off_sidx = take(2u * maxG); L.off_plen = take(2u * maxG); L.off_psug = take(2u * maxG); L.off_pinv = take(2u * maxG);
+  L.off_ac = take(2u * arena); L.off_hc = take(2u * 5u * maxT); L.off_cp = take(maxG);
+  L.rec_bytes = (o + 255u) & ~255u;
+  return L;
+}
+
+struct OutBuf {            // one contiguous device block so a step needs a single D2H copy
+  double* rewards; int32_t* rows; uint8_t* dones;
+  size_t bytes;
+};
+
+}  // namespace
+
+struct bbx_gen {
+  std::unique_ptr<bbx::IdealGen> g;
+  bbx::HIdeal last;
+};
+
+struct bbx_batch {
+  int B = 0, device = 0, k = 1, nvars = 0, W = 2;
+  int elim = 0, rewards = 0, sort_input = 0, sort_reducers = 1;
+  bool fixed = false;
+  BbxLayout L{};
+  std::vector<std::unique_ptr<bbx::IdealGen>> gens;   // one per environment (one shared when fixed)
+  uint32_t slot_words = 0, nslots = 0;
+  std::vector<uint32_t> h_q;          // host mirror of the ideal queue
+  std::vector<int32_t> h_tail, h_head;
+  std::vector<BbxHdr> h_hdr;
+  bool q_dirty = true;
+  // device
+  char* d_recs = nullptr;
+  uint32_t* d_q = nullptr;
+  int32_t* d_tail = nullptr;
+  char* d_out = nullptr; double* d_rewards = nullptr; int32_t* d_rows = nullptr; uint8_t* d_dones = nullptr;
+  int32_t* d_actions = nullptr; uint8_t* d_mask = nullptr; uint32_t* d_seeds = nullptr;
+  int32_t* d_obs = nullptr; size_t obs_rows_cap = 0;
+  BbxTraceRec* d_trace = nullptr; int trace_cap = 0;
+  std::vector<char> h_out;
+  // the rollout in flight (so bbx_sync can finish environments that waited for ideals)
+  BbxParams last{};
+  bool in_flight = false;
+  int staged = 0, envs_per_block = 4;
+};
+
+namespace {
+
+int pack_mono(const bbx_batch* b, const bbx::HTerm& t, uint32_t* w) {
+  const int W = b->W, slots = 2 * W;
+  uint32_t s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int v = 0; v < bbx::kN; v++) {
+    if (t.e[v] == 0) continue;
+    if (v >= slots - 1) return fail(BBX_E_UNSUPPORTED, "variable index %d does not fit the %d-slot monomial", v, slots);
+    if (t.e[v] < 0 || t.e[v] > 65535) return fail(BBX_E_UNSUPPORTED, "exponent %d out of range", t.e[v]);
+    s[v] = (uint32_t)t.e[v];
+  }
+  if (t.deg > 65535) return fail(BBX_E_UNSUPPORTED, "degree %d out of range", t.deg);
+  s[slots - 1] = (uint32_t)t.deg;
+  for (int i = 0; i < W; i++) w[i] = s[2 * i] | (s[2 * i + 1] << 16);
+  return BBX_OK;
+}
+
+// serialise one ideal into a queue slot: [npolys, {nterms, sugar, {coef, mono[W]}...}...]
+int pack_ideal(const bbx_batch* b, bbx::HIdeal F, uint32_t* slot) {
+  if (b->sort_input)   // BuchbergerEnv::reset, buchberger.cpp:301-302 (std::sort, like the reference)
+    std::sort(F.begin(), F.end(), [](const bbx::HPoly& f, const bbx::HPoly& g) { return bbx::mono_gt(g.t[0], f.t[0]); });
+  size_t need = 1;
+  for (auto& f : F) need += 2 + f.t.size() * (1 + b->W);
+  if (need > b->slot_words) return fail(BBX_E_CAPACITY, "ideal needs %zu queue words, slot has %u", need, b->slot_words);
+  uint32_t* w = slot;
+  *w++ = (uint32_t)F.size();
+  for (auto& f : F) {
+    if (f.t.empty()) return fail(BBX_E_ARG, "zero polynomial among the generators");
+    if ((int)f.t.size() > (int)b->L.maxT) return fail(BBX_E_CAPACITY, "generator with %zu terms exceeds max_poly_terms %u", f.t.size(), b->L.maxT);
+    *w++ = (uint32_t)f.t.size();
+    *w++ = (uint32_t)f.sugar;
+    for (auto& t : f.t) {
+      *w++ = (uint32_t)t.c;
+      int rc = pack_mono(b, t, w);
+      if (rc) return rc;
+      w += b->W;
+    }
+  }
+  return BBX_OK;
+}
+
+int upload_queue(bbx_batch* b) {
+  if (!b->q_dirty) return BBX_OK;
+  HIPCHK(hipMemcpy(b->d_q, b->h_q.data(), b->h_q.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(b->d_tail, b->h_tail.data(), b->h_tail.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  b->q_dirty = false;
+  return BBX_OK;
+}
+
+// top every environment's ring up to nslots pre-generated ideals
+int fill_queues(bbx_batch* b) {
+  if (b->fixed) return upload_queue(b);
+  std::string err;
+  bbx::HIdeal F;
+  for (int e = 0; e < b->B; e++) {
+    while (b->h_tail[e] - b->h_head[e] < (int)b->nslots) {
+      if (!b->gens[e]->next(F, &err)) return fail(BBX_E_GENERATOR, "%s", err.c_str());
+      uint32_t* slot = b->h_q.data() + (size_t)e * b->nslots * b->slot_words + (size_t)(b->h_tail[e] % (int)b->nslots) * b->slot_words;
+      int rc = pack_ideal(b, F, slot);
+      if (rc) return rc;
+      b->h_tail[e]++;
+      b->q_dirty = true;
+    }
+  }
+  return upload_queue(b);
+}
+
+int read_headers(bbx_batch* b) {
+  b->h_hdr.resize(b->B);
+  HIPCHK(hipMemcpy2D(b->h_hdr.data(), sizeof(BbxHdr), b->d_recs, b->L.rec_bytes, sizeof(BbxHdr), b->B, hipMemcpyDeviceToHost));
+  for (int e = 0; e < b->B; e++) b->h_head[e] = b->h_hdr[e].q_head;
+  return BBX_OK;
+}
+
+const char* status_name(int s) {
+  switch (s) {
+    case BBX_ST_G_FULL: return "basis capacity (max_basis) exceeded";
+    case BBX_ST_P_FULL: return "pair capacity (max_pairs) exceeded";
+    case BBX_ST_ARENA_FULL: return "term arena (arena_terms) exhausted";
+    case BBX_ST_POLY_TOO_LONG: return "intermediate polynomial longer than max_poly_terms";
+    case BBX_ST_DEG_OVERFLOW: return "degree above 65535";
+    case BBX_ST_BAD_ACTION: return "action index outside [0, rows)";
+    default: return "unknown";
+  }
+}
+
+void fill_params(bbx_batch* b, BbxParams* p) {
+  memset(p, 0, sizeof *p);
+  p->recs = b->d_recs; p->L = b->L; p->B = b->B;
+  p->q.words = b->d_q; p->q.env_stride = b->fixed ? 0 : b->nslots * b->slot_words; p->q.slot_words = b->slot_words;
+  p->q.nslots = b->nslots; p->q.fixed = b->fixed ? 1 : 0; p->q.tail = b->d_tail;
+  p->elim = b->elim; p->rewards_mode = b->rewards; p->sort_reducers = b->sort_reducers; p->k = b->k; p->nvars = b->nvars;
+  p->trace = b->d_trace; p->trace_stride = b->trace_cap;
+}
+
+// wait for the launch in flight; serve environments that ran out of queued ideals; surface errors
+int finish(bbx_batch* b, hipStream_t stream) {
+  for (int round = 0;; round++) {
+    HIPCHK(hipStreamSynchronize(stream));
+    int rc = read_headers(b);
+    if (rc) return rc;
+    bool starved = false;
+    for (int e = 0; e < b->B; e++) {
+      int st = b->h_hdr[e].status;
+      if (st == BBX_ST_STARVED) starved = true;
+      else if (st == BBX_ST_BAD_ACTION) return fail(BBX_E_ACTION, "environment %d: %s", e, status_name(st));
+      else if (st != BBX_ST_OK) return fail(BBX_E_CAPACITY, "environment %d: %s (|G|=%d |P|=%d terms=%d)", e, status_name(st),
+                                            b->h_hdr[e].nG, b->h_hdr[e].nP, b->h_hdr[e].arena_used);
+    }
+    if (!starved) break;
+    if (round > 100000) return fail(BBX_E_GENERATOR, "ideal queue starvation did not resolve");
+    rc = fill_queues(b);
+    if (rc) return rc;
+    BbxParams p = b->last;
+    p.set_budget = 0;          // continue the rollout where each environment stopped
+    int lrc = bbx_launch_step(&p, b->staged, b->envs_per_block, stream);
+    if (lrc) return fail(BBX_E_DEVICE, "kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
+  }
+  b->in_flight = false;
+  return BBX_OK;
+}
+
+int launch(bbx_batch* b, BbxParams& p, hipStream_t stream) {
+  int rc = fill_queues(b);
+  if (rc) return rc;
+  b->last = p;
+  b->in_flight = true;
+  int lrc = bbx_launch_step(&p, b->staged, b->envs_per_block, stream);
+  if (lrc) return fail(BBX_E_DEVICE, "kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
+  return BBX_OK;
+}
+
+int copy_out(bbx_batch* b, double* rewards, uint8_t* dones, int32_t* rows) {
+  b->h_out.resize((size_t)b->B * 13);
+  HIPCHK(hipMemcpy(b->h_out.data(), b->d_out, (size_t)b->B * 13, hipMemcpyDeviceToHost));
+  if (rewards) memcpy(rewards, b->h_out.data(), (size_t)b->B * 8);
+  if (rows) memcpy(rows, b->h_out.data() + (size_t)b->B * 8, (size_t)b->B * 4);
+  if (dones) memcpy(dones, b->h_out.data() + (size_t)b->B * 12, (size_t)b->B);
+  return BBX_OK;
+}
+
+int create_common(std::unique_ptr<bbx::IdealGen> proto, int nvars_obs, int elimination, int rewards, int sort_input,
+                  int sort_reducers, int k, int batch, int device, const bbx_caps* caps, bbx_batch** out) {
+  if (!out) return fail(BBX_E_ARG, "out is null");
+  *out = nullptr;
+  if (batch < 1 || k < 1) return fail(BBX_E_ARG, "batch and k must be positive");
+  if (elimination < 0 || elimination > 2 || rewards < 0 || rewards > 1) return fail(BBX_E_ARG, "bad elimination/rewards selector");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(BBX_E_DEVICE, "no HIP device available (libbbx has no CPU fallback)");
+  if (device < 0 || device >= ndev) return fail(BBX_E_DEVICE, "device %d out of range (have %d)", device, ndev);
+  HIPCHK(hipSetDevice(device));
+
+  auto b = std::make_unique<bbx_batch>();
+  b->B = batch; b->device = device; b->k = k;
+  b->elim = elimination; b->rewards = rewards; b->sort_input = sort_input ? 1 : 0; b->sort_reducers = sort_reducers ? 1 : 0;
+  b->fixed = proto->fixed();
+  b->nvars = nvars_obs > 0 ? nvars_obs : proto->nvars();
+  // ring variables actually used: probe one ideal from a clone (does not disturb the prototype's stream)
+  int maxvar = 0;
+  {
+    auto probe = proto->clone();
+    bbx::HIdeal F; std::string err;
+    if (!probe->next(F, &err)) return fail(BBX_E_GENERATOR, "%s", err.c_str());
+    for (auto& f : F) for (auto& t : f.t) for (int v = 0; v < bbx::kN; v++) if (t.e[v]) maxvar = std::max(maxvar, v + 1);
+    if (!b->fixed) maxvar = std::max(maxvar, proto->nvars());
+  }
+  if (maxvar > 7) return fail(BBX_E_UNSUPPORTED, "8-variable rings are not supported by the device monomial format (7 exponents + degree)");
+  if (b->nvars > 7) return fail(BBX_E_UNSUPPORTED, "observation width of %d variables is not supported", b->nvars);
+  b->W = maxvar <= 3 ? 2 : 4;
+  const bool binomial = !b->fixed && proto->max_terms_hint() == 2;
+  bbx_caps c{};
+  if (caps) c = *caps;
+  if (b->fixed) {
+    if (!c.max_basis) c.max_basis = 4096; if (!c.max_pairs) c.max_pairs = 16384;
+    if (!c.arena_terms) c.arena_terms = 1 << 20; if (!c.max_poly_terms) c.max_poly_terms = 8192;
+  } else if (binomial) {
+    if (!c.max_basis) c.max_basis = b->W == 2 ? 512 : 4096; if (!c.max_pairs) c.max_pairs = b->W == 2 ? 2048 : 16384;
+    if (!c.arena_terms) c.arena_terms = 2 * c.max_basis; if (!c.max_poly_terms) c.max_poly_terms = 8;
+  } else {
+    if (!c.max_basis) c.max_basis = 2048; if (!c.max_pairs) c.max_pairs = 8192;
+    if (!c.arena_terms) c.arena_terms = 1 << 18; if (!c.max_poly_terms) c.max_poly_terms = 4096;
+  }
+  if (!c.queue_slots) c.queue_slots = 8;
+  if (c.max_basis > 65535 || c.max_poly_terms > 65535 || c.max_basis < 2 || c.max_pairs < 2 || c.max_poly_terms < 4 || c.queue_slots < 1)
+    return fail(BBX_E_ARG, "capacities out of range");
+  b->L = make_layout(b->W, c.max_basis, c.max_pairs, c.arena_terms, c.max_poly_terms);
+  b->nslots = b->fixed ? 1 : (uint32_t)c.queue_slots;
+  b->slot_words = 1 + (uint32_t)proto->npolys() * (2 + (uint32_t)std::min(proto->max_terms_hint(), c.max_poly_terms) * (1 + b->W));
+  b->slot_words = (b->slot_words + 3u) & ~3u;
+
+  if (b->fixed) b->gens.push_back(std::move(proto));
+  else {
+    for (int e = 0; e < batch; e++) { b->gens.push_back(proto->clone()); b->gens.back()->seed(5489 + e); }
+  }
+  const size_t qwords = b->fixed ? b->slot_words : (size_t)batch * b->nslots * b->slot_words;
+  b->h_q.assign(qwords, 0u);
+  b->h_tail.assign(batch, 0); b->h_head.assign(batch, 0);
+  if (b->fixed) {
+    bbx::HIdeal F; std::string err;
+    b->gens[0]->next(F, &err);
+    int rc = pack_ideal(b.get(), F, b->h_q.data());
+    if (rc) return rc;
+  }
+
+  HIPCHK(hipMalloc((void**)&b->d_recs, (size_t)batch * b->L.rec_bytes));
+  HIPCHK(hipMalloc((void**)&b->d_q, qwords * sizeof(uint32_t)));
+  HIPCHK(hipMalloc((void**)&b->d_tail, (size_t)batch * sizeof(int32_t)));
+  HIPCHK(hipMalloc((void**)&b->d_out, (size_t)batch * 13));
+  b->d_rewards = (double*)b->d_out; b->d_rows = (int32_t*)(b->d_out + (size_t)batch * 8); b->d_dones = (uint8_t*)(b->d_out + (size_t)batch * 12);
+  HIPCHK(hipMalloc((void**)&b->d_actions, (size_t)batch * sizeof(int32_t)));
+  HIPCHK(hipMalloc((void**)&b->d_mask, (size_t)batch));
+  HIPCHK(hipMalloc((void**)&b->d_seeds, (size_t)batch * sizeof(uint32_t)));
+  int lrc = bbx_launch_init(b->d_recs, b->L.rec_bytes, batch, nullptr, 0);
+  if (lrc) return fail(BBX_E_DEVICE, "init launch failed: %s", hipGetErrorString((hipError_t)lrc));
+  lrc = bbx_launch_mark_reset(b->d_recs, b->L.rec_bytes, batch, nullptr, 0);
+  if (lrc) return fail(BBX_E_DEVICE, "init launch failed: %s", hipGetErrorString((hipError_t)lrc));
+  HIPCHK(hipDeviceSynchronize());
+  *out = b.release();
+  return BBX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* bbx_last_error(void) { return g_err.c_str(); }
+const char* bbx_version(void) { return "bbx 0.1 (gfx950)"; }
+uint32_t bbx_agent_hash(uint32_t seed, uint32_t t) { return bbx_agent_hash32(seed, t); }
+
+int bbx_create(const char* ideal_dist, int elimination, int rewards, int sort_input, int sort_reducers,
+               int k, int batch, int device, const bbx_caps* caps, bbx_batch** out) {
+  if (!ideal_dist) return fail(BBX_E_ARG, "ideal_dist is null");
+  std::string err;
+  auto g = bbx::parse_ideal_dist(ideal_dist, &err);
+  if (!g) return fail(BBX_E_ARG, "%s", err.c_str());
+  return create_common(std::move(g), 0, elimination, rewards, sort_input, sort_reducers, k, batch, device, caps, out);
+}
+
+int bbx_create_fixed(int npolys, const int32_t* nterms, const int32_t* coefs, const int32_t* exps, int nvars_obs,
+                     int elimination, int rewards, int sort_input, int sort_reducers,
+                     int k, int batch, int device, const bbx_caps* caps, bbx_batch** out) {
+  if (npolys < 1 || !nterms || !coefs || !exps) return fail(BBX_E_ARG, "bad fixed ideal");
+  bbx::HIdeal F;
+  size_t at = 0;
+  for (int p = 0; p < npolys; p++) {
+    std::vector<bbx::HTerm> ts;
+    for (int t = 0; t < nterms[p]; t++, at++) {
+      bbx::HTerm h; h.c = bbx::coef_norm(coefs[at]); h.deg = 0;
+      for (int v = 0; v < bbx::kN; v++) { h.e[v] = exps[at * bbx::kN + v]; h.deg += h.e[v]; }
+      ts.push_back(h);
+    }
+    if (ts.empty()) return fail(BBX_E_ARG, "zero polynomial among the generators");
+    F.push_back(bbx::poly_from_terms(ts));
+  }
+  return create_common(bbx::make_fixed(F), nvars_obs, elimination, rewards, sort_input, sort_reducers, k, batch, device, caps, out);
+}
+
+void bbx_destroy(bbx_batch* b) {
+  if (!b) return;
+  (void)hipSetDevice(b->device);
+  (void)hipDeviceSynchronize();
+  void* bufs[] = {b->d_recs, b->d_q, b->d_tail, b->d_out, b->d_actions, b->d_mask, b->d_seeds, b->d_obs, b->d_trace};
+  for (void* p : bufs) (void)hipFree(p);
+  delete b;
+}
+
+int bbx_copy(const bbx_batch* s, bbx_batch** out) {
+  if (!s || !out) return fail(BBX_E_ARG, "null argument");
+  HIPCHK(hipSetDevice(s->device));
+  HIPCHK(hipDeviceSynchronize());
+  auto b = std::make_unique<bbx_batch>();
+  b->B = s->B; b->device = s->device; b->k = s->k; b->nvars = s->nvars; b->W = s->W;
+  b->elim = s->elim; b->rewards = s->rewards; b->sort_input = s->sort_input; b->sort_reducers = s->sort_reducers;
+  b->fixed = s->fixed; b->L = s->L; b->slot_words = s->slot_words; b->nslots = s->nslots;
+  b->h_q = s->h_q; b->h_tail = s->h_tail; b->h_head = s->h_head; b->q_dirty = true;
+  b->staged = s->staged; b->envs_per_block = s->envs_per_block;
+  for (auto& g : s->gens) b->gens.push_back(g->clone());
+  const int batch = s->B;
+  HIPCHK(hipMalloc((void**)&b->d_recs, (size_t)batch * b->L.rec_bytes));
+  HIPCHK(hipMemcpy(b->d_recs, s->d_recs, (size_t)batch * b->L.rec_bytes, hipMemcpyDeviceToDevice));
+  HIPCHK(hipMalloc((void**)&b->d_q, b->h_q.size() * sizeof(uint32_t)));
+  HIPCHK(hipMalloc((void**)&b->d_tail, (size_t)batch * sizeof(int32_t)));
+  HIPCHK(hipMalloc((void**)&b->d_out, (size_t)batch * 13));
+  b->d_rewards = (double*)b->d_out; b->d_rows = (int32_t*)(b->d_out + (size_t)batch * 8); b->d_dones = (uint8_t*)(b->d_out + (size_t)batch * 12);
+  HIPCHK(hipMalloc((void**)&b->d_actions, (size_t)batch * sizeof(int32_t)));
+  HIPCHK(hipMalloc((void**)&b->d_mask, (size_t)batch));
+  HIPCHK(hipMalloc((void**)&b->d_seeds, (size_t)batch * sizeof(uint32_t)));
+  int rc = upload_queue(b.get());
+  if (rc) return rc;
+  *out = b.release();
+  return BBX_OK;
+}
+
+int bbx_seed(bbx_batch* b, const int64_t* seeds) {
+  if (!b || !seeds) return fail(BBX_E_ARG, "null argument");
+  if (b->fixed) return BBX_OK;                 // FixedIdealGenerator::seed is a no-op (ideals.h:94)
+  HIPCHK(hipSetDevice(b->device));
+  int rc = read_headers(b);                    // ideals generated ahead from the old stream are dropped
+  if (rc) return rc;
+  for (int e = 0; e < b->B; e++) { b->gens[e]->seed(seeds[e]); b->h_tail[e] = b->h_head[e]; }
+  b->q_dirty = true;
+  return BBX_OK;
+}
+
+int bbx_seed_agent(bbx_batch* b, const uint32_t* seeds) {
+  if (!b || !seeds) return fail(BBX_E_ARG, "null argument");
+  HIPCHK(hipSetDevice(b->device));
+  // written straight into the headers (field agent_seed), strided copy
+  HIPCHK(hipMemcpy2D(b->d_recs + offsetof(BbxHdr, agent_seed), b->L.rec_bytes, seeds, sizeof(uint32_t), sizeof(uint32_t), b->B, hipMemcpyHostToDevice));
+  // the agent's step counter restarts with a new seed
+  std::vector<int32_t> zero(b->B, 0);
+  HIPCHK(hipMemcpy2D(b->d_recs + offsetof(BbxHdr, t), b->L.rec_bytes, zero.data(), sizeof(int32_t), sizeof(int32_t), b->B, hipMemcpyHostToDevice));
+  return BBX_OK;
+}
+
+int bbx_reset(bbx_batch* b, const uint8_t* mask, int32_t* rows) {
+  if (!b) return fail(BBX_E_ARG, "null argument");
+  HIPCHK(hipSetDevice(b->device));
+  if (mask) HIPCHK(hipMemcpy(b->d_mask, mask, (size_t)b->B, hipMemcpyHostToDevice));
+  int lrc = bbx_launch_mark_reset(b->d_recs, b->L.rec_bytes, b->B, mask ? b->d_mask : nullptr, 0);
+  if (lrc) return fail(BBX_E_DEVICE, "launch failed: %s", hipGetErrorString((hipError_t)lrc));
+  BbxParams p; fill_params(b, &p);
+  p.nsteps = 0; p.set_budget = 1; p.agent = BBX_AGENT_EXTERNAL; p.auto_reset = 0;
+  p.rewards = b->d_rewards; p.dones = b->d_dones; p.rows = b->d_rows;
+  int rc = launch(b, p, 0);
+  if (rc) return rc;
+  rc = finish(b, 0);
+  if (rc) return rc;
+  if (rows) for (int e = 0; e < b->B; e++) rows[e] = b->h_hdr[e].nP;
+  return BBX_OK;
+}
+
+int bbx_step(bbx_batch* b, const int32_t* actions, double* rewards, uint8_t* dones, int32_t* rows) {
+  if (!b || !actions) return fail(BBX_E_ARG, "null argument");
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipMemcpy(b->d_actions, actions, (size_t)b->B * sizeof(int32_t), hipMemcpyHostToDevice));
+  BbxParams p; fill_params(b, &p);
+  p.nsteps = 1; p.set_budget = 1; p.agent = BBX_AGENT_EXTERNAL; p.auto_reset = 0; p.actions = b->d_actions;
+  p.rewards = b->d_rewards; p.dones = b->d_dones; p.rows = b->d_rows;
+  int rc = launch(b, p, 0);
+  if (rc) return rc;
+  rc = finish(b, 0);
+  if (rc) return rc;
+  return copy_out(b, rewards, dones, rows);
+}
+
+int bbx_rollout(bbx_batch* b, int agent, int nsteps, int auto_reset, double* rewards, uint8_t* dones, int32_t* rows) {
+  if (!b || nsteps < 0 || agent < BBX_RANDOM_HASH || agent > BBX_FIRST) return fail(BBX_E_ARG, "bad rollout arguments");
+  HIPCHK(hipSetDevice(b->device));
+  if (b->d_trace && nsteps > b->trace_cap) return fail(BBX_E_ARG, "rollout of %d steps exceeds the trace capacity %d", nsteps, b->trace_cap);
+  BbxParams p; fill_params(b, &p);
+  p.nsteps = nsteps; p.set_budget = 1; p.agent = agent; p.auto_reset = auto_reset ? 1 : 0;
+  p.rewards = b->d_rewards; p.dones = b->d_dones; p.rows = b->d_rows;
+  int rc = launch(b, p, 0);
+  if (rc) return rc;
+  rc = finish(b, 0);
+  if (rc) return rc;
+  return copy_out(b, rewards, dones, rows);
+}
+
+int bbx_step_device(bbx_batch* b, const int32_t* d_actions, double* d_rewards, uint8_t* d_dones, int32_t* d_rows,
+                    int32_t* d_obs, int obs_rows, int obs_fill, void* stream) {
+  if (!b || !d_actions) return fail(BBX_E_ARG, "null argument");
+  HIPCHK(hipSetDevice(b->device));
+  BbxParams p; fill_params(b, &p);
+  p.nsteps = 1; p.set_budget = 1; p.agent = BBX_AGENT_EXTERNAL; p.auto_reset = 0; p.actions = d_actions;
+  p.rewards = d_rewards; p.dones = d_dones; p.rows = d_rows; p.obs = d_obs; p.obs_rows = obs_rows; p.obs_fill = obs_fill;
+  return launch(b, p, (hipStream_t)stream);
+}
+
+int bbx_rollout_device(bbx_batch* b, int agent, int nsteps, int auto_reset, double* d_rewards, uint8_t* d_dones,
+                       int32_t* d_rows, int32_t* d_obs, int obs_rows, int obs_fill, void* stream) {
+  if (!b || nsteps < 0 || agent < BBX_RANDOM_HASH || agent > BBX_FIRST) return fail(BBX_E_ARG, "bad rollout arguments");
+  HIPCHK(hipSetDevice(b->device));
+  BbxParams p; fill_params(b, &p);
+  p.nsteps = nsteps; p.set_budget = 1; p.agent = agent; p.auto_reset = auto_reset ? 1 : 0;
+  p.rewards = d_rewards; p.dones = d_dones; p.rows = d_rows; p.obs = d_obs; p.obs_rows = obs_rows; p.obs_fill = obs_fill;
+  return launch(b, p, (hipStream_t)stream);
+}
+
+int bbx_sync(bbx_batch* b) {
+  if (!b) return fail(BBX_E_ARG, "null argument");
+  HIPCHK(hipSetDevice(b->device));
+  if (!b->in_flight) { HIPCHK(hipDeviceSynchronize()); return BBX_OK; }
+  return finish(b, 0);
+}
+
+int bbx_obs(bbx_batch* b, int32_t* out, int max_rows, int fill) {
+  if (!b || !out || max_rows < 1) return fail(BBX_E_ARG, "bad arguments");
+  HIPCHK(hipSetDevice(b->device));
+  const size_t cols = (size_t)2 * b->nvars * b->k;
+  const size_t need = (size_t)b->B * max_rows * cols;
+  if (b->obs_rows_cap < (size_t)max_rows) {
+    if (b->d_obs) HIPCHK(hipFree(b->d_obs));
+    b->d_obs = nullptr;
+    HIPCHK(hipMalloc((void**)&b->d_obs, need * sizeof(int32_t)));
+    b->obs_rows_cap = max_rows;
+  }
+  BbxParams p; fill_params(b, &p);
+  p.nsteps = 0; p.set_budget = 1; p.agent = BBX_AGENT_EXTERNAL; p.auto_reset = 0;
+  p.obs = b->d_obs; p.obs_rows = max_rows; p.obs_fill = fill; p.trace = nullptr;
+  int rc = launch(b, p, 0);
+  if (rc) return rc;
+  rc = finish(b, 0);
+  if (rc) return rc;
+  HIPCHK(hipMemcpy(out, b->d_obs, need * sizeof(int32_t), hipMemcpyDeviceToHost));
+  return BBX_OK;
+}
+
+int bbx_cols(const bbx_batch* b) { return b ? 2 * b->nvars * b->k : 0; }
+int bbx_nvars(const bbx_batch* b) { return b ? b->nvars : 0; }
+int bbx_batch_size(const bbx_batch* b) { return b ? b->B : 0; }
+
+int bbx_value(bbx_batch* b, int idx, const char* strategy, double gamma, double* out) {
+  (void)b; (void)idx; (void)strategy; (void)gamma; (void)out;
+  return fail(BBX_E_UNSUPPORTED, "bbx_value: device-side value rollouts are not built yet");
+}
+
+int bbx_stats(bbx_batch* b, int64_t* out6) {
+  if (!b || !out6) return fail(BBX_E_ARG, "null argument");
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipDeviceSynchronize());
+  int rc = read_headers(b);
+  if (rc) return rc;
+  for (int e = 0; e < b->B; e++) {
+    const BbxHdr& h = b->h_hdr[e];
+    int64_t* o = out6 + (size_t)e * 6;
+    o[0] = h.total_steps; o[1] = h.total_additions; o[2] = h.episodes; o[3] = h.zero_reductions; o[4] = h.status; o[5] = h.q_head;
+  }
+  return BBX_OK;
+}
+
+int bbx_env_status(bbx_batch* b, int32_t* status) {
+  if (!b || !status) return fail(BBX_E_ARG, "null argument");
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipDeviceSynchronize());
+  int rc = read_headers(b);
+  if (rc) return rc;
+  for (int e = 0; e < b->B; e++) status[e] = b->h_hdr[e].status;
+  return BBX_OK;
+}
+
+int bbx_state_sizes(bbx_batch* b, int idx, int32_t* basis_size, int32_t* npairs, int32_t* nterms_total) {
+  if (!b || idx < 0 || idx >= b->B) return fail(BBX_E_ARG, "bad environment index");
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipDeviceSynchronize());
+  BbxHdr h;
+  HIPCHK(hipMemcpy(&h, b->d_recs + (size_t)idx * b->L.rec_bytes, sizeof h, hipMemcpyDeviceToHost));
+  if (basis_size) *basis_size = h.nG;
+  if (npairs) *npairs = h.nP;
+  if (nterms_total) *nterms_total = h.arena_used;
+  return BBX_OK;
+}
+
+int bbx_state_get(bbx_batch* b, int idx, int32_t* nterms, int32_t* coefs, int32_t* exps, int32_t* pairs, int32_t* order) {
+  if (!b || idx < 0 || idx >= b->B) return fail(BBX_E_ARG, "bad environment index");
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipDeviceSynchronize());
+  const char* rec = b->d_recs + (size_t)idx * b->L.rec_bytes;
+  BbxHdr h;
+  HIPCHK(hipMemcpy(&h, rec, sizeof h, hipMemcpyDeviceToHost));
+  const int W = b->W, nG = h.nG, nP = h.nP, nt = h.arena_used;
+  std::vector<uint32_t> am((size_t)std::max(nt, 1) * W), poff(std::max(nG, 1)), pr(std::max(nP, 1));
+  std::vector<uint16_t> ac(std::max(nt, 1)), plen(std::max(nG, 1)), sidx(std::max(nG, 1));
+  if (nt) {
+    HIPCHK(hipMemcpy(am.data(), rec + b->L.off_am, (size_t)nt * W * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(ac.data(), rec + b->L.off_ac, (size_t)nt * 2, hipMemcpyDeviceToHost));
+  }
+  if (nG) {
+    HIPCHK(hipMemcpy(poff.data(), rec + b->L.off_poff, (size_t)nG * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(plen.data(), rec + b->L.off_plen, (size_t)nG * 2, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(sidx.data(), rec + b->L.off_sidx, (size_t)nG * 2, hipMemcpyDeviceToHost));
+  }
+  if (nP) HIPCHK(hipMemcpy(pr.data(), rec + b->L.off_pairs, (size_t)nP * 4, hipMemcpyDeviceToHost));
+  size_t at = 0;
+  for (int g = 0; g < nG; g++) {
+    if (nterms) nterms[g] = plen[g];
+    for (int t = 0; t < plen[g]; t++, at++) {
+      const uint32_t* w = am.data() + ((size_t)poff[g] + t) * W;
+      if (coefs) coefs[at] = ac[poff[g] + t];
+      if (exps) {
+        for (int v = 0; v < bbx::kN; v++) {
+          int x = 0;
+          if (v < 2 * W - 1) x = (v & 1) ? (int)(w[v >> 1] >> 16) : (int)(w[v >> 1] & 0xffffu);
+          exps[at * bbx::kN + v] = x;
+        }
+      }
+    }
+    if (order) order[g] = sidx[g];
+  }
+  if (pairs) for (int r = 0; r < nP; r++) { pairs[2 * r] = (int)(pr[r] & 0xffffu); pairs[2 * r + 1] = (int)(pr[r] >> 16); }
+  return BBX_OK;
+}
+
+int bbx_trace_enable(bbx_batch* b, int capacity_steps) {
+  if (!b || capacity_steps < 0) return fail(BBX_E_ARG, "bad arguments");
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipDeviceSynchronize());
+  if (b->d_trace) { HIPCHK(hipFree(b->d_trace)); b->d_trace = nullptr; }
+  b->trace_cap = capacity_steps;
+  if (capacity_steps) {
+    HIPCHK(hipMalloc((void**)&b->d_trace, (size_t)b->B * capacity_steps * sizeof(BbxTraceRec)));
+    HIPCHK(hipMemset(b->d_trace, 0, (size_t)b->B * capacity_steps * sizeof(BbxTraceRec)));
+  }
+  return BBX_OK;
+}
+
+int bbx_trace_read(bbx_batch* b, int env, int first, int count, bbx_trace_rec* out) {
+  if (!b || !out || !b->d_trace || env < 0 || env >= b->B || first < 0 || count < 0 || first + count > b->trace_cap)
+    return fail(BBX_E_ARG, "bad trace range");
+  static_assert(sizeof(bbx_trace_rec) == sizeof(BbxTraceRec), "trace record layouts must match");
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipMemcpy(out, b->d_trace + (size_t)env * b->trace_cap + first, (size_t)count * sizeof(BbxTraceRec), hipMemcpyDeviceToHost));
+  return BBX_OK;
+}
+
+// ---- generators on their own -------------------------------------------------------------------
+int bbx_gen_create(const char* ideal_dist, bbx_gen** out) {
+  if (!ideal_dist || !out) return fail(BBX_E_ARG, "null argument");
+  std::string err;
+  auto g = bbx::parse_ideal_dist(ideal_dist, &err);
+  if (!g) return fail(BBX_E_ARG, "%s", err.c_str());
+  *out = new bbx_gen{std::move(g), {}};
+  return BBX_OK;
+}
+void bbx_gen_destroy(bbx_gen* g) { delete g; }
+int bbx_gen_seed(bbx_gen* g, int64_t seed) { if (!g) return fail(BBX_E_ARG, "null"); g->g->seed(seed); return BBX_OK; }
+int bbx_gen_nvars(const bbx_gen* g) { return g ? g->g->nvars() : 0; }
+int bbx_gen_next(bbx_gen* g, int32_t* npolys, int32_t* nterms_total) {
+  if (!g) return fail(BBX_E_ARG, "null");
+  std::string err;
+  if (!g->g->next(g->last, &err)) return fail(BBX_E_GENERATOR, "%s", err.c_str());
+  int tot = 0;
+  for (auto& f : g->last) tot += (int)f.t.size();
+  if (npolys) *npolys = (int)g->last.size();
+  if (nterms_total) *nterms_total = tot;
+  return BBX_OK;
+}
+int bbx_gen_get(const bbx_gen* g, int32_t* nterms, int32_t* coefs, int32_t* exps, int32_t* sugars) {
+  if (!g) return fail(BBX_E_ARG, "null");
+  size_t at = 0;
+  for (size_t p = 0; p < g->last.size(); p++) {
+    const auto& f = g->last[p];
+    if (nterms) nterms[p] = (int)f.t.size();
+    if (sugars) sugars[p] = f.sugar;
+    for (auto& t : f.t) {
+      if (coefs) coefs[at] = t.c;
+      if (exps) for (int v = 0; v < bbx::kN; v++) exps[at * bbx::kN + v] = t.e[v];
+      at++;
+    }
+  }
+  return BBX_OK;
+}
+
+}  // extern "C"

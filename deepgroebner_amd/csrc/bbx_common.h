@@ -1,0 +1,127 @@
+// Shared between the host side of libbbx (bbx_api.cpp) and the HIP kernels (bbx_kernels.hip).
+//
+// HBM layout
+// ----------
+// A batch is B independent Buchberger environments.  Each environment owns one
+// contiguous *record* in HBM (rec_bytes, 256-B aligned) holding everything the
+// step path touches; records never reference each other, so a batch shards
+// across wavefronts / GPUs with no exchange.  Inside a record every array is
+// 16-B aligned so monomials can be moved with 8-/16-byte loads:
+//
+//   hdr     BbxHdr                      counters, sizes, status
+//   lm      Mono[maxG]                  lead monomial of G[i]      (G order; pair criteria, lcm)
+//   slm     Mono[maxG]                  lead monomials in REDUCER order (ascending grevlex; the
+//                                       first-divisor scan reads this coalesced, lane k <- slm[k])
+//   lcm     Mono[maxG]                  scratch: lcm(LM G[i], LM f) during the Gebauer-Moeller update
+//   am      Mono[arena]                 term arena: monomials of all basis polynomials, append-only
+//   hm      Mono[5*maxT]                scratch polynomials: h ping/pong, r, merge staging (2*maxT)
+//   poff    u32[maxG]                   arena offset of G[i]
+//   pairs   u32[maxP]                   pair set P in reference order, i | j<<16
+//   sidx    u16[maxG]                   reducer r -> index into G
+//   plen    u16[maxG]                   #terms of G[i]       psug u16[maxG] sugar   pinv u16[maxG] 1/LC
+//   ac      u16[arena]                  arena coefficients   hc u16[5*maxT] scratch coefficients
+//   cp      u8[maxG]                    scratch: G[i] coprime to f
+//
+// Mono is W 32-bit words of packed u16 pairs (v_pk_max_u16 / v_pk_add_u16 / v_pk_sub_u16 clamp
+// operate on it directly): slot s (= variable s) lives in word s/2, half s%2; the LAST slot holds
+// the total degree.  W=2 serves n<=3 variables (8 B / monomial), W=4 serves n<=7 (16 B).
+#pragma once
+#include <stdint.h>
+
+#define BBX_P 32003u
+#define BBX_MAXVARS 8
+
+// per-environment status (sticky except STARVED)
+enum {
+  BBX_ST_OK = 0,
+  BBX_ST_G_FULL = 1,        // basis capacity exceeded
+  BBX_ST_P_FULL = 2,        // pair capacity exceeded
+  BBX_ST_ARENA_FULL = 3,    // term arena exhausted
+  BBX_ST_POLY_TOO_LONG = 4, // an intermediate polynomial exceeded maxT terms
+  BBX_ST_DEG_OVERFLOW = 5,  // total degree above 65535
+  BBX_ST_STARVED = 6,       // ideal queue empty: the environment waits for the host to refill
+  BBX_ST_BAD_ACTION = 7,    // action index outside [0, |P|)
+};
+
+struct BbxHdr {             // 128 bytes
+  int32_t nG, nP, arena_used, status;
+  int32_t need_reset, q_head, t, episode_steps;
+  int64_t total_steps, total_additions;
+  int32_t episodes, zero_reductions;
+  uint32_t agent_seed;
+  int32_t steps_done;       // steps completed in the last launch
+  int32_t budget;           // steps still owed in the current rollout (survives queue starvation)
+  int32_t rollout_pos;      // steps completed in the current rollout (trace slot)
+  int32_t done_last;        // the last executed step ended an episode
+  int32_t reserved[13];
+};
+
+struct BbxLayout {
+  uint32_t W;               // words per monomial (2 or 4)
+  uint32_t maxG, maxP, arena, maxT;
+  uint32_t off_lm, off_slm, off_lcm, off_am, off_hm, off_poff, off_pairs;
+  uint32_t off_sidx, off_plen, off_psug, off_pinv, off_ac, off_hc, off_cp;
+  uint32_t rec_bytes;
+};
+
+// Ideal queue: per environment a ring of `nslots` ideals (or ONE shared slot when fixed != 0).
+// Slot words: [npolys, then per polynomial: nterms, sugar, then nterms x (coef, mono W words)].
+struct BbxQueue {
+  const uint32_t* words;
+  uint32_t env_stride;      // words per environment (0 when fixed)
+  uint32_t slot_words;
+  uint32_t nslots;
+  uint32_t fixed;
+  const int32_t* tail;      // [B] ideals produced so far per environment (host-written)
+};
+
+struct BbxTraceRec {        // one per environment per step when tracing (tests / parity)
+  int32_t action, nP, nG, done;
+  double reward;
+  uint64_t obs_hash, pairs_hash, newpoly_hash;
+};
+
+enum { BBX_AGENT_EXTERNAL = 0, BBX_AGENT_HASH = 1, BBX_AGENT_DEGREE = 2, BBX_AGENT_FIRST = 3 };
+enum { BBX_ELIM_GM = 0, BBX_ELIM_LCM = 1, BBX_ELIM_NONE = 2 };
+enum { BBX_REW_ADDITIONS = 0, BBX_REW_REDUCTIONS = 1 };
+
+struct BbxParams {
+  char* recs;
+  BbxLayout L;
+  BbxQueue q;
+  int32_t B;
+  int32_t nsteps;
+  int32_t set_budget;       // 1: start a rollout of nsteps steps; 0: continue the one in progress
+  int32_t agent;
+  int32_t auto_reset;
+  int32_t elim, rewards_mode, sort_reducers, k, nvars;
+  const int32_t* actions;   // [B], agent == EXTERNAL
+  double* rewards;          // [B] reward of the last executed step
+  uint8_t* dones;           // [B]
+  int32_t* rows;            // [B] |P| after the step
+  int32_t* obs;             // [B, obs_rows, 2*n*k] int32 or null
+  int32_t obs_rows;         // row capacity per environment in obs
+  int32_t obs_fill;         // 1: pad rows [nP, obs_rows) with -1
+  BbxTraceRec* trace;       // [B, trace_stride] or null
+  int32_t trace_stride;
+};
+
+// position-keyed commutative hash used for parity traces (same definition in oracle/trace.py)
+static inline
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+uint64_t bbx_mix64(uint64_t idx, uint32_t word) {
+  uint64_t z = ((idx << 32) | (uint64_t)word) + 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+// counter-based action hash of the built-in random agent (same in oracle/ffi.py, oracle/*.c*)
+static inline
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+uint32_t bbx_agent_hash32(uint32_t seed, uint32_t t) {
+  return (uint32_t)(bbx_mix64((uint64_t)seed, t) >> 32);
+}

@@ -1,0 +1,321 @@
+#include "bbx_ideals.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <sstream>
+
+namespace bbx {
+
+// ---------------------------------------------------------------- GF(32003), polynomials.h:14, cpp:11-23
+int coef_norm(long long i) { return (int)((i < 0) ? (i % kP) + kP : i % kP); }
+int coef_inv(int a) {
+  long long r = 1, b = a;
+  for (int e = kP - 2; e; e >>= 1) { if (e & 1) r = r * b % kP; b = b * b % kP; }
+  return (int)r;
+}
+
+bool mono_gt(const HTerm& a, const HTerm& b) {
+  if (a.deg != b.deg) return a.deg > b.deg;
+  for (int i = kN - 1; i >= 0; i--) {
+    if (b.e[i] > a.e[i]) return true;
+    if (a.e[i] > b.e[i]) return false;
+  }
+  return false;
+}
+static bool mono_eq(const HTerm& a, const HTerm& b) { return a.e == b.e; }
+
+static HTerm make_term(int c, const std::array<int, kN>& e) {
+  HTerm t; t.c = coef_norm(c); t.e = e; t.deg = 0;
+  for (int x : e) t.deg += x;
+  return t;
+}
+
+HPoly poly_from_terms(std::vector<HTerm> ts) {
+  HPoly f;
+  // the reference constructor calls std::sort with this comparator (polynomials.cpp:134-135, 142-143)
+  std::sort(ts.begin(), ts.end(), [](const HTerm& a, const HTerm& b) { return mono_gt(a, b); });
+  f.t = std::move(ts);
+  f.sugar = f.t.empty() ? 0 : f.t[0].deg;
+  return f;
+}
+
+HPoly poly_add(const HPoly& a, const HPoly& b) {
+  HPoly g;
+  g.sugar = std::max(a.sugar, b.sugar);
+  size_t i = 0, j = 0;
+  while (i < a.t.size() && j < b.t.size()) {
+    if (mono_gt(a.t[i], b.t[j])) g.t.push_back(a.t[i++]);
+    else if (mono_gt(b.t[j], a.t[i])) g.t.push_back(b.t[j++]);
+    else {
+      int c = coef_norm((long long)a.t[i].c + b.t[j].c);
+      if (c != 0) { HTerm t = a.t[i]; t.c = c; g.t.push_back(t); }
+      i++; j++;
+    }
+  }
+  for (; i < a.t.size(); i++) g.t.push_back(a.t[i]);
+  for (; j < b.t.size(); j++) g.t.push_back(b.t[j]);
+  return g;
+}
+
+// ---------------------------------------------------------------- libstdc++ 11 <random>, restated
+void MinStd0::seed(long long s) {   // linear_congruential_engine<uint_fast32_t,16807,0,2147483647>::seed
+  x = (uint64_t)s % 2147483647ull;
+  if (x == 0) x = 1;
+}
+uint64_t MinStd0::next() { x = x * 16807ull % 2147483647ull; return x; }
+
+static const uint64_t kRngMin = 1, kRngMax = 2147483646ull;
+
+// uniform_int_distribution<int>{a,b}(rng): downscaling branch with two divisions (uniform_int_dist.h)
+static int uniform_int(MinStd0& r, int a, int b) {
+  const uint64_t urngrange = kRngMax - kRngMin;
+  const uint64_t urange = (uint64_t)((long long)b - (long long)a);
+  uint64_t ret;
+  if (urngrange > urange) {
+    const uint64_t uerange = urange + 1;
+    const uint64_t scaling = urngrange / uerange;
+    const uint64_t past = uerange * scaling;
+    do ret = r.next() - kRngMin; while (ret >= past);
+    ret /= scaling;
+  } else {
+    ret = r.next() - kRngMin;
+  }
+  return (int)(ret + (uint64_t)(long long)a);
+}
+// generate_canonical<double,53>: two engine draws for minstd_rand0 (random.tcc)
+static double canonical(MinStd0& r) {
+  const long double R = (long double)kRngMax - (long double)kRngMin + 1.0L;
+  double sum = 0.0, tmp = 1.0;
+  for (int k = 2; k != 0; --k) {
+    sum += (double)(r.next() - kRngMin) * tmp;
+    tmp = (double)((long double)tmp * R);
+  }
+  double ret = sum / tmp;
+  if (ret >= 1.0) ret = std::nextafter(1.0, 0.0);
+  return ret;
+}
+struct Discrete {               // discrete_distribution<int>::param_type::_M_initialize + operator()
+  std::vector<double> prob, cp;
+  void init(const std::vector<int>& w) {
+    prob.clear(); cp.clear();
+    if (w.size() < 2) return;
+    double sum = 0.0;
+    for (int x : w) sum += (double)x;
+    for (int x : w) prob.push_back((double)x / sum);
+    double acc = 0.0;
+    for (double p : prob) { acc += p; cp.push_back(acc); }
+    cp.back() = 1.0;
+  }
+  int draw(MinStd0& r) const {
+    if (cp.empty()) return 0;
+    double p = canonical(r);
+    return (int)(std::lower_bound(cp.begin(), cp.end(), p) - cp.begin());
+  }
+};
+// poisson_distribution<int>{mean}(rng), mean < 12 (random.tcc)
+static int poisson_small(MinStd0& r, double lm_thr) {
+  int x = 0;
+  double prod = 1.0;
+  do { prod *= canonical(r); x += 1; } while (prod > lm_thr);
+  return x - 1;
+}
+
+// ---------------------------------------------------------------- ideals.cpp
+std::vector<HPoly> cyclic(int n) {
+  std::vector<HPoly> F;
+  for (int d = 1; d < n; d++) {
+    std::vector<HTerm> p;
+    for (int i = 0; i < n; i++) {
+      std::array<int, kN> e{};
+      for (int k = 0; k < d; k++) e[(i + k) % n] = 1;
+      p.push_back(make_term(1, e));
+    }
+    F.push_back(poly_from_terms(p));
+  }
+  std::array<int, kN> e{};
+  for (int i = 0; i < n; i++) e[i] = 1;
+  F.push_back(poly_from_terms({make_term(1, e), make_term(-1, std::array<int, kN>{})}));
+  return F;
+}
+
+std::vector<std::array<int, kN>> basis(int n, int d) {
+  std::vector<int> a;
+  for (int i = 0; i < d; i++) a.push_back(0);
+  for (int i = 0; i < n - 1; i++) a.push_back(1);
+  std::vector<std::array<int, kN>> B;
+  do {                                   // stars (0) and bars (1); std::next_permutation order matters
+    std::array<int, kN> e{};
+    int index = 0;
+    for (int v : a) { if (v == 0) e[index]++; else index++; }
+    B.push_back(e);
+  } while (std::next_permutation(a.begin(), a.end()));
+  return B;
+}
+
+static int binomial(int n, int k) { return (k == 0 || k == n) ? 1 : binomial(n - 1, k - 1) + binomial(n - 1, k); }
+
+static std::vector<int> degree_weights(int n, int d, DistType dist, bool constants) {  // ideals.cpp:75-100
+  std::vector<int> count;
+  count.push_back(constants ? 1 : 0);
+  switch (dist) {
+    case DistType::Uniform: for (int i = 1; i < d + 1; i++) count.push_back(binomial(n + i - 1, n - 1)); break;
+    case DistType::Weighted: for (int i = 0; i < d; i++) count.push_back(1); break;
+    case DistType::Maximum: for (int i = 0; i < d - 1; i++) count.push_back(0); count.push_back(1); break;
+  }
+  return count;
+}
+std::vector<double> degree_probabilities(int n, int d, DistType dist, bool constants) {
+  Discrete dd; dd.init(degree_weights(n, d, dist, constants));
+  return dd.prob;
+}
+
+namespace {
+
+using Bases = std::vector<std::vector<std::array<int, kN>>>;
+
+class FixedGen : public IdealGen {
+ public:
+  explicit FixedGen(const HIdeal& F) : F_(F) {
+    n_ = 0;                               // ideals.cpp:146-154: the max variable INDEX (sic)
+    for (auto& f : F_) for (auto& t : f.t) for (int i = 0; i < kN; i++) if (t.e[i] != 0) n_ = std::max(n_, i);
+  }
+  bool next(HIdeal& out, std::string*) override { out = F_; return true; }
+  int nvars() const override { return n_; }
+  std::unique_ptr<IdealGen> clone() const override { return std::make_unique<FixedGen>(*this); }
+  bool fixed() const override { return true; }
+  int max_terms_hint() const override { size_t m = 1; for (auto& f : F_) m = std::max(m, f.t.size()); return (int)m; }
+  int npolys() const override { return (int)F_.size(); }
+ private:
+  HIdeal F_;
+  int n_;
+};
+
+class RandomBase : public IdealGen {
+ public:
+  RandomBase(int n, int d, int s, DistType dist, bool constants, bool homogeneous)
+      : n_(n), s_(s), homogeneous_(homogeneous) {
+    auto b = std::make_shared<Bases>();
+    for (int i = 0; i < d + 1; i++) b->push_back(basis(n, i));
+    bases_ = b;
+    degree_.init(degree_weights(n, d, dist, constants));
+    rng_.seed(5489);                      // the reference seeds from std::random_device; callers seed explicitly
+  }
+  void seed(long long s) override { rng_.seed(s); }
+  int nvars() const override { return n_; }
+  int npolys() const override { return s_; }
+ protected:
+  HTerm choice(int d, int c) {            // choice(): fresh uniform_int_distribution(0, len-1), ideals.h:68-73
+    const auto& B = (*bases_)[d];
+    return make_term(c, B[uniform_int(rng_, 0, (int)B.size() - 1)]);
+  }
+  int n_, s_;
+  bool homogeneous_;
+  std::shared_ptr<const Bases> bases_;
+  Discrete degree_;
+  MinStd0 rng_;
+};
+
+class BinomialGen : public RandomBase {   // ideals.cpp:156-201
+ public:
+  BinomialGen(int n, int d, int s, DistType dist, bool constants, bool homogeneous, bool pure)
+      : RandomBase(n, d, s, dist, constants, homogeneous), pure_(pure) {}
+  bool next(HIdeal& F, std::string* err) override {
+    F.clear();
+    for (int i = 0; i < s_; i++) {
+      int c = pure_ ? coef_norm(-1) : uniform_int(rng_, 1, kP - 1);
+      int d1, d2;
+      if (homogeneous_) d1 = d2 = degree_.draw(rng_);
+      else { d1 = degree_.draw(rng_); d2 = degree_.draw(rng_); }
+      bool success = false;
+      for (int trials = 0; trials < 1000; trials++) {
+        HTerm m1 = choice(d1, 1), m2 = choice(d2, 1);
+        HPoly f;
+        if (mono_gt(m2, m1)) { m1.c = c; f.t = {m2, m1}; }
+        else if (mono_gt(m1, m2)) { m2.c = c; f.t = {m1, m2}; }
+        else continue;
+        f.sugar = f.t[0].deg;
+        F.push_back(f);
+        success = true;
+        break;
+      }
+      if (!success) { if (err) *err = "failed to generate two distinct random monomials after 1000 trials"; return false; }
+    }
+    return true;
+  }
+  std::unique_ptr<IdealGen> clone() const override { return std::make_unique<BinomialGen>(*this); }
+  int max_terms_hint() const override { return 2; }
+ private:
+  bool pure_;
+};
+
+class RandomGen : public RandomBase {     // ideals.cpp:203-231
+ public:
+  RandomGen(int n, int d, int s, double lam, DistType dist, bool constants, bool homogeneous)
+      : RandomBase(n, d, s, dist, constants, homogeneous), lam_(lam), lm_thr_(std::exp(-lam)) {}
+  bool next(HIdeal& F, std::string* err) override {
+    F.clear();
+    if (lam_ >= 12.0) { if (err) *err = "poisson means >= 12 are not supported"; return false; }
+    for (int i = 0; i < s_; i++) {
+      HPoly f;
+      int terms = 2 + poisson_small(rng_, lm_thr_);
+      int d = degree_.draw(rng_);
+      for (int j = 0; j < terms; j++) {
+        int c = uniform_int(rng_, 1, kP - 1);
+        HTerm t = choice(d, c);
+        HPoly single; single.t = {t}; single.sugar = t.deg;
+        f = poly_add(f, single);
+        if (!homogeneous_) d = degree_.draw(rng_);
+      }
+      if (f.t.empty()) { if (err) *err = "random polynomial cancelled to zero (undefined in the reference)"; return false; }
+      int inv = coef_inv(f.t[0].c);       // Term{1 / f.LC(), {}} * f
+      for (auto& t : f.t) t.c = coef_norm((long long)t.c * inv);
+      F.push_back(f);
+    }
+    return true;
+  }
+  std::unique_ptr<IdealGen> clone() const override { return std::make_unique<RandomGen>(*this); }
+  int max_terms_hint() const override { return 64; }
+ private:
+  double lam_, lm_thr_;
+};
+
+}  // namespace
+
+std::unique_ptr<IdealGen> make_fixed(const HIdeal& F) { return std::make_unique<FixedGen>(F); }
+
+std::unique_ptr<IdealGen> parse_ideal_dist(const std::string& ideal_dist, std::string* err) {
+  std::vector<std::string> a;
+  std::string arg;
+  std::istringstream iss(ideal_dist);
+  while (std::getline(iss, arg, '-')) a.push_back(arg);
+  auto dist_of = [](const std::string& s, DistType* out) {
+    if (s == "uniform") { *out = DistType::Uniform; return true; }
+    if (s == "weighted") { *out = DistType::Weighted; return true; }
+    if (s == "maximum") { *out = DistType::Maximum; return true; }
+    return false;
+  };
+  auto has = [&a](const char* s) { return std::find(a.begin(), a.end(), s) != a.end(); };
+  auto fail = [&](const char* m) { if (err) *err = std::string(m) + ": '" + ideal_dist + "'"; return std::unique_ptr<IdealGen>(); };
+  try {
+    if (a.size() >= 2 && a[0] == "cyclic") {
+      int n = std::stoi(a[1]);
+      if (n < 2 || n > kN) return fail("cyclic-n needs 2 <= n <= 8");
+      return make_fixed(cyclic(n));
+    }
+    if (a.size() < 4) return fail("unrecognised ideal distribution");
+    int n = std::stoi(a[0]), d = std::stoi(a[1]), s = std::stoi(a[2]);
+    if (n < 1 || n > kN || d < 1 || s < 1) return fail("bad n-d-s in ideal distribution");
+    DistType dt;
+    if (dist_of(a[3], &dt)) return std::make_unique<BinomialGen>(n, d, s, dt, has("consts"), has("homog"), has("pure"));
+    if (a.size() < 5) return fail("unrecognised ideal distribution");
+    double lam = std::stod(a[3]);
+    if (!dist_of(a[4], &dt)) dt = DistType::Uniform;   // dist_types[unknown] default-inserts Uniform
+    return std::make_unique<RandomGen>(n, d, s, lam, dt, has("consts"), has("homog"));
+  } catch (const std::exception&) {
+    return fail("unparsable ideal distribution");
+  }
+}
+
+}  // namespace bbx

@@ -1,0 +1,659 @@
+// Hand-written HIP for gfx950 (MI355X): the BuchbergerEnv step path.
+//
+// One 64-lane wavefront owns one environment for the whole launch and runs
+// `nsteps` environment steps back to back:
+//
+//   select pair -> S-polynomial -> full reduction -> Gebauer-Moeller update -> reducer insert -> observation
+//
+// replacing, bit for bit, the reference's
+//   LeadMonomialsEnv::step / BuchbergerEnv::step   deepgroebner/buchberger.cpp:318-329, 398-408
+//   spoly / reduce / update                        deepgroebner/buchberger.cpp:18-99
+//   Polynomial +,-,Term*  and Monomial ops         deepgroebner/polynomials.cpp:41-202
+//   BuchbergerEnv::reset (from a host-generated ideal) deepgroebner/buchberger.cpp:299-315
+//
+// Design notes (MI355X):
+//  * integer/indexing work, no MFMA.  Exponent vectors are packed u16 pairs so that lcm / product /
+//    quotient / divisibility are v_pk_max_u16 / v_pk_add_u16 / v_pk_sub_u16 [clamp] on whole words.
+//  * the first-divisor scan reads the reducers' lead monomials in reducer order, lane k <- slm[k]
+//    (coalesced 8/16-B loads), tests divisibility per lane, and takes the first set bit of the
+//    64-bit ballot — identical to the reference's linear scan with `break`.
+//  * kernel template STAGED keeps the whole environment record in LDS for the launch (small
+//    classes: 3-variable binomial ideals need ~6 KB); otherwise the record is worked on in HBM/L2.
+//  * no inter-workgroup communication at all: environments are independent.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "bbx_common.h"
+
+#define WAVE 64
+
+// ------------------------------------------------------------------ wave helpers
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
+__device__ __forceinline__ void wave_sync() {
+  // lanes of one wave exchange data through LDS / their own HBM record; memory operations of a
+  // wave complete in order, so a wavefront-scope fence (a compiler barrier, no cache action) is all
+  // that is needed between a write by one lane and a read by another.
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ uint64_t ballot64(bool p) { return __ballot(p); }
+__device__ __forceinline__ int prefix_of(uint64_t mask, int lane) { return __popcll(mask & ((1ull << lane) - 1ull)); }
+__device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ uint64_t wave_sum64(uint64_t v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+  return v;
+}
+__device__ __forceinline__ uint64_t wave_min64(uint64_t v) {
+  for (int o = 32; o > 0; o >>= 1) { uint64_t w = __shfl_xor(v, o, WAVE); v = w < v ? w : v; }
+  return v;
+}
+
+// ------------------------------------------------------------------ GF(32003)   polynomials.h:10-26
+__device__ __forceinline__ uint32_t mulmod(uint32_t a, uint32_t b) { return (a * b) % BBX_P; }
+__device__ __forceinline__ uint32_t addmod(uint32_t a, uint32_t b) { uint32_t s = a + b; return s >= BBX_P ? s - BBX_P : s; }
+__device__ __forceinline__ uint32_t negmod(uint32_t a) { return a ? BBX_P - a : 0u; }
+// inverse (polynomials.cpp:11-23 computes the same unique field element by extended Euclid):
+// a^(P-2), P-2 = 32001 = 0b111110100000001
+__device__ inline uint32_t invmod(uint32_t a) {
+  uint32_t r = 1, b = a;
+  uint32_t e = BBX_P - 2;
+#pragma unroll 1
+  while (e) { if (e & 1) r = mulmod(r, b); b = mulmod(b, b); e >>= 1; }
+  return r;
+}
+
+// ------------------------------------------------------------------ packed monomials   polynomials.h:29-55
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b))); }
+__device__ __forceinline__ uint32_t pk_min(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b))); }
+__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_bit_cast(us2, a) + __builtin_bit_cast(us2, b)); }
+__device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_bit_cast(us2, a) - __builtin_bit_cast(us2, b)); }
+__device__ __forceinline__ uint32_t pk_subsat(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b))); }
+
+template <int W> struct __attribute__((aligned(W * 4))) Mono { uint32_t w[W]; };
+
+template <int W> __device__ __forceinline__ uint32_t m_deg(const Mono<W>& a) { return a.w[W - 1] >> 16; }
+template <int W> __device__ __forceinline__ Mono<W> m_zero() { Mono<W> r; for (int i = 0; i < W; i++) r.w[i] = 0; return r; }
+template <int W> __device__ __forceinline__ Mono<W> m_mul(const Mono<W>& a, const Mono<W>& b) {  // cpp:41-47 (degree slot adds too)
+  Mono<W> r;
+#pragma unroll
+  for (int i = 0; i < W; i++) r.w[i] = pk_add(a.w[i], b.w[i]);
+  return r;
+}
+template <int W> __device__ __forceinline__ Mono<W> m_div(const Mono<W>& a, const Mono<W>& b) {  // cpp:50-57
+  Mono<W> r;
+#pragma unroll
+  for (int i = 0; i < W; i++) r.w[i] = pk_sub(a.w[i], b.w[i]);
+  return r;
+}
+template <int W> __device__ __forceinline__ Mono<W> m_lcm(const Mono<W>& a, const Mono<W>& b) {  // cpp:111-118
+  Mono<W> r;
+#pragma unroll
+  for (int i = 0; i < W; i++) r.w[i] = pk_max(a.w[i], b.w[i]);
+  // recompute the degree slot = sum of the exponent slots
+  uint32_t t = 0;
+#pragma unroll
+  for (int i = 0; i < W - 1; i++) t += r.w[i];            // halves add independently (sums < 65536)
+  uint32_t d = (t & 0xffffu) + (t >> 16) + (r.w[W - 1] & 0xffffu);
+  r.w[W - 1] = (r.w[W - 1] & 0xffffu) | (d << 16);
+  return r;
+}
+template <int W> __device__ __forceinline__ bool m_eq(const Mono<W>& a, const Mono<W>& b) {  // cpp:77-81
+  uint32_t x = 0;
+#pragma unroll
+  for (int i = 0; i < W; i++) x |= a.w[i] ^ b.w[i];
+  return x == 0;
+}
+// a | b  (is_divisible(b, a), cpp:93-98): every exponent of a <= that of b
+template <int W> __device__ __forceinline__ bool m_divides(const Mono<W>& a, const Mono<W>& b) {
+  uint32_t x = 0;
+#pragma unroll
+  for (int i = 0; i < W; i++) x |= pk_subsat(a.w[i], b.w[i]);
+  return x == 0;
+}
+// gcd == 1  <=>  lcm(a,b) == a*b, the test at buchberger.cpp:65 and :88
+template <int W> __device__ __forceinline__ bool m_coprime(const Mono<W>& a, const Mono<W>& b) {
+  uint32_t x = 0;
+#pragma unroll
+  for (int i = 0; i < W - 1; i++) x |= pk_min(a.w[i], b.w[i]);
+  x |= pk_min(a.w[W - 1], b.w[W - 1]) & 0xffffu;
+  return x == 0;
+}
+// grevlex a > b (cpp:60-74): degree first, then from the last variable down the SMALLER exponent wins.
+// With the degree in the most significant slot and the exponent slots complemented this is one
+// unsigned compare of the whole monomial.
+__device__ __forceinline__ bool m_gt(const Mono<2>& a, const Mono<2>& b) {
+  uint64_t ka = (((uint64_t)a.w[1] << 32) | a.w[0]) ^ 0x0000FFFFFFFFFFFFull;
+  uint64_t kb = (((uint64_t)b.w[1] << 32) | b.w[0]) ^ 0x0000FFFFFFFFFFFFull;
+  return ka > kb;
+}
+__device__ __forceinline__ bool m_gt(const Mono<4>& a, const Mono<4>& b) {
+  uint64_t ha = (((uint64_t)a.w[3] << 32) | a.w[2]) ^ 0x0000FFFFFFFFFFFFull;
+  uint64_t hb = (((uint64_t)b.w[3] << 32) | b.w[2]) ^ 0x0000FFFFFFFFFFFFull;
+  uint64_t la = ~(((uint64_t)a.w[1] << 32) | a.w[0]);
+  uint64_t lb = ~(((uint64_t)b.w[1] << 32) | b.w[0]);
+  return ha > hb || (ha == hb && la > lb);
+}
+template <int W> __device__ __forceinline__ uint32_t m_exp(const Mono<W>& a, int v) {
+  uint32_t w = a.w[0];                          // select chain, not a runtime index (keeps Mono in VGPRs)
+#pragma unroll
+  for (int i = 1; i < W; i++) w = ((v >> 1) == i) ? a.w[i] : w;
+  return (v & 1) ? (w >> 16) : (w & 0xffffu);
+}
+
+// ------------------------------------------------------------------ environment view
+template <int W> struct Env {
+  BbxHdr* hdr;
+  Mono<W>*lm, *slm, *lcm, *am, *hm;
+  uint32_t *poff, *pairs;
+  uint16_t *sidx, *plen, *psug, *pinv, *ac, *hc;
+  uint8_t* cp;
+};
+template <int W> __device__ __forceinline__ Env<W> env_view(char* rec, const BbxLayout& L) {
+  Env<W> e;
+  e.hdr = (BbxHdr*)rec;
+  e.lm = (Mono<W>*)(rec + L.off_lm); e.slm = (Mono<W>*)(rec + L.off_slm); e.lcm = (Mono<W>*)(rec + L.off_lcm);
+  e.am = (Mono<W>*)(rec + L.off_am); e.hm = (Mono<W>*)(rec + L.off_hm);
+  e.poff = (uint32_t*)(rec + L.off_poff); e.pairs = (uint32_t*)(rec + L.off_pairs);
+  e.sidx = (uint16_t*)(rec + L.off_sidx); e.plen = (uint16_t*)(rec + L.off_plen); e.psug = (uint16_t*)(rec + L.off_psug);
+  e.pinv = (uint16_t*)(rec + L.off_pinv); e.ac = (uint16_t*)(rec + L.off_ac); e.hc = (uint16_t*)(rec + L.off_hc);
+  e.cp = (uint8_t*)(rec + L.off_cp);
+  return e;
+}
+
+// a polynomial seen through a term multiplier:  element t = (c[t]*scale mod p) * x^(m[t]+shift)
+template <int W> struct PView {
+  const Mono<W>* m; const uint16_t* c; int n; Mono<W> shift; uint32_t scale;
+  __device__ __forceinline__ Mono<W> mono(int t) const { return m_mul(m[t], shift); }
+  __device__ __forceinline__ uint32_t coef(int t) const { return mulmod(c[t], scale); }
+};
+
+// out = A + B (both descending grevlex), equal monomials summed, zero sums dropped:
+// Polynomial operator+ (polynomials.cpp:148-177) as a rank-and-compact wave merge.
+// tm/tc: staging of at least A.n + B.n terms.  Returns the number of output terms, or -1 if it
+// would exceed ocap.
+template <int W>
+__device__ int wave_merge(const PView<W>& A, const PView<W>& B, Mono<W>* tm, uint16_t* tc,
+                          Mono<W>* om, uint16_t* oc, int ocap) {
+  const int lane = lane_id();
+  const int na = A.n, nb = B.n, total = na + nb;
+  // pass 1: every term finds its slot in the virtual merged sequence
+  for (int x = lane; x < na; x += WAVE) {
+    Mono<W> a = A.mono(x);
+    int lo = 0, hi = nb;                       // #B terms strictly greater than a
+    while (lo < hi) { int mid = (lo + hi) >> 1; if (m_gt(B.mono(mid), a)) lo = mid + 1; else hi = mid; }
+    uint32_t c = A.coef(x);
+    if (lo < nb && m_eq(B.mono(lo), a)) c = addmod(c, B.coef(lo));
+    tm[x + lo] = a; tc[x + lo] = (uint16_t)c;  // c == 0 marks a hole
+  }
+  for (int y = lane; y < nb; y += WAVE) {
+    Mono<W> b = B.mono(y);
+    int lo = 0, hi = na;                       // #A terms >= b
+    while (lo < hi) { int mid = (lo + hi) >> 1; if (m_gt(b, A.mono(mid))) hi = mid; else lo = mid + 1; }
+    bool dup = lo > 0 && m_eq(A.mono(lo - 1), b);
+    tm[y + lo] = b; tc[y + lo] = dup ? (uint16_t)0 : (uint16_t)B.coef(y);
+  }
+  wave_sync();
+  // pass 2: squeeze the holes out
+  int nout = 0;
+  for (int base = 0; base < total; base += WAVE) {
+    int idx = base + lane;
+    uint32_t c = idx < total ? tc[idx] : 0u;
+    uint64_t mask = ballot64(c != 0);
+    if (c != 0) {
+      int o = nout + prefix_of(mask, lane);
+      if (o < ocap) { om[o] = tm[idx]; oc[o] = (uint16_t)c; }
+    }
+    nout += __popcll(mask);
+  }
+  wave_sync();
+  return nout > ocap ? -1 : nout;
+}
+
+// ------------------------------------------------------------------ update()   buchberger.cpp:52-99
+// Adds the polynomial whose lead monomial is lmf as G[m] (the caller has already stored its terms and
+// metadata) and updates the pair set.  Returns false on capacity overflow.
+template <int W>
+__device__ bool wave_update(Env<W>& e, const BbxLayout& L, int& nG, int& nP, const Mono<W> lmf, int elim, int* status) {
+  const int lane = lane_id();
+  const int m = nG;
+  if (elim == BBX_ELIM_GM) {
+    // (70-76) drop old pairs (i,j) with LM f | lcm_ij, lcm_ij != lcm_if, lcm_ij != lcm_jf  — stable
+    int w = 0;
+    for (int base = 0; base < nP; base += WAVE) {
+      int k = base + lane;
+      bool keep = false; uint32_t pr = 0;
+      if (k < nP) {
+        pr = e.pairs[k];
+        Mono<W> li = e.lm[pr & 0xffffu], lj = e.lm[pr >> 16];
+        Mono<W> l = m_lcm(li, lj);
+        bool drop = m_divides(lmf, l) && !m_eq(l, m_lcm(li, lmf)) && !m_eq(l, m_lcm(lj, lmf));
+        keep = !drop;
+      }
+      uint64_t mask = ballot64(keep);
+      wave_sync();
+      if (keep) e.pairs[w + prefix_of(mask, lane)] = pr;
+      w += __popcll(mask);
+      wave_sync();
+    }
+    nP = w;
+    // (78-81) lcm_i = lcm(LM G[i], LM f), and whether G[i] is coprime to f
+    for (int i = lane; i < m; i += WAVE) {
+      Mono<W> li = e.lm[i];
+      e.lcm[i] = m_lcm(li, lmf);
+      e.cp[i] = m_coprime(li, lmf) ? 1 : 0;
+    }
+    wave_sync();
+    // (82-91) The std::map walk keeps exactly the lcms that are minimal under divisibility among the
+    // distinct values (a proper divisor has smaller degree, hence comes earlier in grevlex), and emits
+    // (min index of the bucket, m) unless some index of the bucket is coprime to f.
+    for (int base = 0; base < m; base += WAVE) {
+      int i = base + lane;
+      bool emit = false;
+      if (i < m) {
+        Mono<W> Li = e.lcm[i];
+        bool bad = false;
+        for (int k = 0; k < m; k++) {
+          Mono<W> Lk = e.lcm[k];              // same address in every lane: broadcast read
+          bool eq = m_eq(Lk, Li);
+          bad |= (!eq && m_divides(Lk, Li)) || (eq && (k < i || e.cp[k]));
+        }
+        emit = !bad;
+      }
+      uint64_t mask = ballot64(emit);
+      int cnt = __popcll(mask);
+      if (nP + cnt > (int)L.maxP) { *status = BBX_ST_P_FULL; return false; }
+      if (emit) e.pairs[nP + prefix_of(mask, lane)] = (uint32_t)i | ((uint32_t)m << 16);  // (92) ascending i
+      nP += cnt;
+    }
+  } else {
+    for (int base = 0; base < m; base += WAVE) {
+      int i = base + lane;
+      bool emit = false;
+      if (i < m) emit = (elim == BBX_ELIM_NONE) ? true : !m_coprime(e.lm[i], lmf);  // 58-68
+      uint64_t mask = ballot64(emit);
+      int cnt = __popcll(mask);
+      if (nP + cnt > (int)L.maxP) { *status = BBX_ST_P_FULL; return false; }
+      if (emit) e.pairs[nP + prefix_of(mask, lane)] = (uint32_t)i | ((uint32_t)m << 16);
+      nP += cnt;
+    }
+  }
+  wave_sync();
+  return true;
+}
+
+// insert G[g] into the reducer order: std::upper_bound by lead monomial, buchberger.cpp:309-311, 323-326
+template <int W>
+__device__ void wave_insert_reducer(Env<W>& e, int nR, int g, const Mono<W> lmf, int sort_reducers) {
+  const int lane = lane_id();
+  int pos = nR;
+  if (sort_reducers) {
+    pos = 0;                                   // #reducers with LM <= lmf
+    for (int base = 0; base < nR; base += WAVE) {
+      int k = base + lane;
+      bool le = k < nR && !m_gt(e.slm[k], lmf);
+      pos += __popcll(ballot64(le));
+    }
+    for (int hi = nR; hi > pos; hi -= WAVE) { // shift [pos, nR) up by one, top chunk first
+      int k = hi - 1 - lane;
+      Mono<W> v; uint16_t s = 0;
+      if (k >= pos) { v = e.slm[k]; s = e.sidx[k]; }
+      wave_sync();
+      if (k >= pos) { e.slm[k + 1] = v; e.sidx[k + 1] = s; }
+      wave_sync();
+    }
+  }
+  if (lane == 0) { e.slm[pos] = lmf; e.sidx[pos] = (uint16_t)g; }
+  wave_sync();
+}
+
+// append a polynomial (terms at sm/sc) to the basis: arena copy, metadata, update(), reducer insert
+template <int W>
+__device__ bool wave_add_poly(Env<W>& e, const BbxLayout& L, int& nG, int& nP, int& arena_used,
+                              const Mono<W>* sm, const uint16_t* sc, int n, int sugar,
+                              int elim, int sort_reducers, int* status) {
+  const int lane = lane_id();
+  if (nG >= (int)L.maxG) { *status = BBX_ST_G_FULL; return false; }
+  if (arena_used + n > (int)L.arena) { *status = BBX_ST_ARENA_FULL; return false; }
+  const int g = nG, off = arena_used;
+  for (int t = lane; t < n; t += WAVE) { e.am[off + t] = sm[t]; e.ac[off + t] = sc[t]; }
+  const Mono<W> lmf = sm[0];
+  const uint32_t lc = sc[0];
+  if (lane == 0) {
+    e.lm[g] = lmf; e.poff[g] = (uint32_t)off; e.plen[g] = (uint16_t)n; e.psug[g] = (uint16_t)sugar;
+    e.pinv[g] = (uint16_t)invmod(lc);
+  }
+  wave_sync();
+  if (!wave_update<W>(e, L, nG, nP, lmf, elim, status)) return false;
+  wave_insert_reducer<W>(e, g, g, lmf, sort_reducers);
+  nG = g + 1;
+  arena_used = off + n;
+  return true;
+}
+
+// BuchbergerEnv::reset (buchberger.cpp:299-315) from the next host-generated ideal(s) of the queue.
+// Returns false if the queue ran dry (status STARVED) or on overflow.
+template <int W>
+__device__ bool wave_reset(Env<W>& e, const BbxParams& p, int env, int& nG, int& nP, int& arena_used, int& q_head, int* status) {
+  const int lane = lane_id();
+  for (;;) {
+    const uint32_t* slot;
+    if (p.q.fixed) slot = p.q.words;
+    else {
+      int tail = p.q.tail[env];
+      if (q_head >= tail) { *status = BBX_ST_STARVED; return false; }
+      slot = p.q.words + (size_t)env * p.q.env_stride + (size_t)(q_head % (int)p.q.nslots) * p.q.slot_words;
+    }
+    nG = 0; nP = 0; arena_used = 0;
+    const int npoly = (int)slot[0];
+    const uint32_t* w = slot + 1;
+    Mono<W>* sm = e.hm; uint16_t* sc = e.hc;   // stage each generator's terms in scratch
+    for (int f = 0; f < npoly; f++) {
+      const int n = (int)w[0], sugar = (int)w[1];
+      w += 2;
+      if (n > (int)p.L.maxT) { *status = BBX_ST_POLY_TOO_LONG; return false; }
+      for (int t = lane; t < n; t += WAVE) {
+        const uint32_t* tw = w + (size_t)t * (1 + W);
+        Mono<W> mm;
+#pragma unroll
+        for (int i = 0; i < W; i++) mm.w[i] = tw[1 + i];
+        sm[t] = mm; sc[t] = (uint16_t)tw[0];
+      }
+      wave_sync();
+      if (!wave_add_poly<W>(e, p.L, nG, nP, arena_used, sm, sc, n, sugar, p.elim, p.sort_reducers, status)) return false;
+      w += (size_t)n * (1 + W);
+    }
+    if (!p.q.fixed) q_head++;
+    if (nP != 0) return true;                  // 313-314: redraw while the pair set is empty
+    if (p.q.fixed) return true;                // a fixed ideal with no pairs can never change
+  }
+}
+
+// lead-monomial observation, buchberger.cpp:354-370 + 391-394 / 403-406: row r = first k monomials of
+// G[i] || first k of G[j] for the r-th pair, n exponents each, zero padded
+template <int W>
+__device__ uint64_t wave_obs(const Env<W>& e, const BbxParams& p, int env, int nP, bool write, bool want_hash) {
+  const int lane = lane_id();
+  const int n = p.nvars, k = p.k;
+  const int cols = 2 * n * k;
+  int32_t* out = (write && p.obs) ? p.obs + (size_t)env * p.obs_rows * cols : nullptr;
+  const int rows = out ? (nP < p.obs_rows ? nP : p.obs_rows) : nP;
+  const int items = rows * 2 * k;               // one item = one monomial slot of the matrix
+  uint64_t h = 0;
+  for (int it = lane; it < items; it += WAVE) {
+    int r = it / (2 * k), rem = it - r * 2 * k;
+    int half = rem / k, t = rem - half * k;
+    uint32_t pr = e.pairs[r];
+    int g = half ? (int)(pr >> 16) : (int)(pr & 0xffffu);
+    bool have = t < (int)e.plen[g];
+    Mono<W> mm = have ? e.am[e.poff[g] + t] : m_zero<W>();
+    int base = it * n;
+    for (int v = 0; v < n; v++) {
+      uint32_t x = m_exp(mm, v);
+      if (out) out[base + v] = (int32_t)x;
+      if (want_hash) h += bbx_mix64((uint64_t)(base + v), x);
+    }
+  }
+  if (out && p.obs_fill) {
+    for (int idx = rows * cols + lane; idx < p.obs_rows * cols; idx += WAVE) out[idx] = -1;
+  }
+  return want_hash ? wave_sum64(h) : 0;
+}
+
+template <int W>
+__device__ uint64_t wave_pairs_hash(const Env<W>& e, int nP) {
+  uint64_t h = 0;
+  for (int r = lane_id(); r < nP; r += WAVE) {
+    uint32_t pr = e.pairs[r];
+    h += bbx_mix64((uint64_t)(2 * r), pr & 0xffffu) + bbx_mix64((uint64_t)(2 * r + 1), pr >> 16);
+  }
+  return wave_sum64(h);
+}
+// words: [nterms, c0, e0[8], c1, e1[8], ...]  (oracle/trace.py poly_words)
+template <int W>
+__device__ uint64_t wave_poly_hash(const Env<W>& e, int g) {
+  const int n = e.plen[g], off = e.poff[g];
+  uint64_t h = lane_id() == 0 ? bbx_mix64(0, (uint32_t)n) : 0;
+  for (int t = lane_id(); t < n; t += WAVE) {
+    Mono<W> mm = e.am[off + t];
+    uint64_t b = 1 + (uint64_t)t * 9;
+    h += bbx_mix64(b, e.ac[off + t]);
+    for (int v = 0; v < BBX_MAXVARS; v++) h += bbx_mix64(b + 1 + v, v < 2 * W - 1 ? m_exp(mm, v) : 0u);
+  }
+  return wave_sum64(h);
+}
+
+// ------------------------------------------------------------------ the step kernel
+template <int W, bool STAGED>
+__global__ __launch_bounds__(256) void bbx_step_kernel(BbxParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = lane_id();
+  const int wave_in_block = threadIdx.x / WAVE;
+  const int env = blockIdx.x * (blockDim.x / WAVE) + wave_in_block;
+  if (env >= p.B) return;                       // whole wave exits together
+  char* grec = p.recs + (size_t)env * p.L.rec_bytes;
+  char* rec = grec;
+  if (STAGED) {
+    rec = smem + (size_t)wave_in_block * p.L.rec_bytes;
+    // whole-record copy, 16 B per lane per trip (records are tiny in the staged class)
+    const uint4* src = (const uint4*)grec; uint4* dst = (uint4*)rec;
+    for (uint32_t i = lane; i < p.L.rec_bytes / 16; i += WAVE) dst[i] = src[i];
+    wave_sync();
+  }
+  Env<W> e = env_view<W>(rec, p.L);
+  const BbxLayout& L = p.L;
+
+  int nG = uni(e.hdr->nG), nP = uni(e.hdr->nP), arena_used = uni(e.hdr->arena_used);
+  int status = uni(e.hdr->status), need_reset = uni(e.hdr->need_reset), q_head = uni(e.hdr->q_head);
+  int t_agent = uni(e.hdr->t), episode_steps = uni(e.hdr->episode_steps);
+  int episodes = uni(e.hdr->episodes), zero_red = uni(e.hdr->zero_reductions);
+  long long total_steps = e.hdr->total_steps, total_adds = e.hdr->total_additions;
+  const uint32_t agent_seed = e.hdr->agent_seed;
+  if (status == BBX_ST_STARVED) status = BBX_ST_OK;   // the host has refilled the queue
+  int budget = uni(e.hdr->budget), rollout_pos = uni(e.hdr->rollout_pos);
+  if (p.set_budget) { budget = p.nsteps; rollout_pos = 0; }
+  int steps_done = 0, done_last = 0;
+  double last_reward = 0.0;
+  const bool tracing = p.trace != nullptr;
+
+  // scratch polynomials
+  const int maxT = (int)L.maxT;
+  Mono<W>* hm0 = e.hm;            uint16_t* hc0 = e.hc;
+  Mono<W>* hm1 = e.hm + maxT;     uint16_t* hc1 = e.hc + maxT;
+  Mono<W>* rm = e.hm + 2 * maxT;  uint16_t* rc = e.hc + 2 * maxT;
+  Mono<W>* tm = e.hm + 3 * maxT;  uint16_t* tc = e.hc + 3 * maxT;   // 2*maxT staging
+
+  for (;;) {
+    if (status != BBX_ST_OK) break;
+    if (need_reset) {                           // also serves a reset left pending by the last step
+      if (!wave_reset<W>(e, p, env, nG, nP, arena_used, q_head, &status)) break;
+      need_reset = 0; episode_steps = 0;
+    }
+    if (budget <= 0) break;
+    if (nP == 0) break;                         // finished episode and no auto-reset: nothing to do
+
+    // ---- choose the pair ------------------------------------------------------------------
+    int action;
+    if (p.agent == BBX_AGENT_EXTERNAL) action = p.actions[env];
+    else if (p.agent == BBX_AGENT_HASH) action = (int)(bbx_agent_hash32(agent_seed, (uint32_t)t_agent) % (uint32_t)nP);
+    else if (p.agent == BBX_AGENT_FIRST) action = 0;
+    else {                                      // degree: first row of minimal deg lcm (buchberger.cpp:171-176)
+      uint64_t best = ~0ull;
+      for (int r = lane; r < nP; r += WAVE) {
+        uint32_t pr = e.pairs[r];
+        uint64_t key = ((uint64_t)m_deg(m_lcm(e.lm[pr & 0xffffu], e.lm[pr >> 16])) << 32) | (uint32_t)r;
+        best = key < best ? key : best;
+      }
+      action = (int)(uint32_t)wave_min64(best);
+    }
+    action = uni(action);
+    if (action < 0 || action >= nP) { status = BBX_ST_BAD_ACTION; break; }
+    const uint32_t pr = e.pairs[action];
+    const int gi = pr & 0xffffu, gj = pr >> 16;
+    // P.erase(remove(action))  buchberger.cpp:319 — stable
+    for (int base = action; base < nP - 1; base += WAVE) {
+      int k = base + lane;
+      uint32_t v = 0;
+      if (k < nP - 1) v = e.pairs[k + 1];
+      wave_sync();
+      if (k < nP - 1) e.pairs[k] = v;
+      wave_sync();
+    }
+    nP -= 1;
+
+    // ---- S-polynomial  buchberger.cpp:18-21 -----------------------------------------------------
+    int hn, hoff = 0, hsug;
+    Mono<W>* hm = hm0; uint16_t* hc = hc0;
+    {
+      const Mono<W> lmi = e.lm[gi], lmj = e.lm[gj];
+      const Mono<W> gamma = m_lcm(lmi, lmj);
+      PView<W> A, Bv;
+      A.m = e.am + e.poff[gi] + 1; A.c = e.ac + e.poff[gi] + 1; A.n = (int)e.plen[gi] - 1;
+      A.shift = m_div(gamma, lmi); A.scale = e.pinv[gi];
+      Bv.m = e.am + e.poff[gj] + 1; Bv.c = e.ac + e.poff[gj] + 1; Bv.n = (int)e.plen[gj] - 1;
+      Bv.shift = m_div(gamma, lmj); Bv.scale = negmod(e.pinv[gj]);
+      int si = (int)e.psug[gi] + (int)m_deg(A.shift), sj = (int)e.psug[gj] + (int)m_deg(Bv.shift);
+      hsug = si > sj ? si : sj;
+      if (hsug > 65535) { status = BBX_ST_DEG_OVERFLOW; break; }
+      if (A.n + Bv.n > 2 * maxT) { status = BBX_ST_POLY_TOO_LONG; break; }
+      hn = wave_merge<W>(A, Bv, tm, tc, hm, hc, maxT);
+      if (hn < 0) { status = BBX_ST_POLY_TOO_LONG; break; }
+    }
+
+    // ---- reduce  buchberger.cpp:24-49 -----------------------------------------------------------
+    int nsteps_red = 0, rn = 0, rsug = 0;
+    bool overflow = false;
+    while (hn - hoff > 0) {
+      const Mono<W> lmh = hm[hoff];
+      int found = -1;
+      for (int base = 0; base < nG; base += WAVE) {   // first reducer (in G_ order) whose LM divides LM(h)
+        int k = base + lane;
+        bool d = k < nG && m_divides(e.slm[k], lmh);
+        uint64_t mask = ballot64(d);
+        if (mask) { found = base + __builtin_ctzll(mask); break; }
+      }
+      if (found >= 0) {                         // h <- h - (LT h / LT f) f     (34-36)
+        const int g = e.sidx[found];
+        const uint32_t c = mulmod(hc[hoff], e.pinv[g]);
+        PView<W> A, Bv;
+        A.m = hm + hoff + 1; A.c = hc + hoff + 1; A.n = hn - hoff - 1; A.shift = m_zero<W>(); A.scale = 1;
+        Bv.m = e.am + e.poff[g] + 1; Bv.c = e.ac + e.poff[g] + 1; Bv.n = (int)e.plen[g] - 1;
+        Bv.shift = m_div(lmh, e.lm[g]); Bv.scale = negmod(c);
+        int fs = (int)e.psug[g] + (int)m_deg(Bv.shift);
+        hsug = fs > hsug ? fs : hsug;
+        if (hsug > 65535) { status = BBX_ST_DEG_OVERFLOW; overflow = true; break; }
+        if (A.n + Bv.n > 2 * maxT) { status = BBX_ST_POLY_TOO_LONG; overflow = true; break; }
+        Mono<W>* nm = (hm == hm0) ? hm1 : hm0; uint16_t* nc = (hc == hc0) ? hc1 : hc0;
+        int nn = wave_merge<W>(A, Bv, tm, tc, nm, nc, maxT);
+        if (nn < 0) { status = BBX_ST_POLY_TOO_LONG; overflow = true; break; }
+        hm = nm; hc = nc; hn = nn; hoff = 0;
+        nsteps_red++;
+      } else {                                  // r <- r + LT h ; h <- h - LT h   (41-44)
+        if (rn >= maxT) { status = BBX_ST_POLY_TOO_LONG; overflow = true; break; }
+        if (lane == 0) { rm[rn] = lmh; rc[rn] = hc[hoff]; }
+        int d = (int)m_deg(lmh);
+        rsug = d > rsug ? d : rsug;
+        rn++; hoff++;
+      }
+    }
+    if (overflow) break;
+    wave_sync();
+    rsug = rsug > hsug ? rsug : hsug;            // sugar of r + h (48), h's sugar survives its terms
+
+    // ---- basis / pair-set update  buchberger.cpp:321-327 ---------------------------------------
+    const int nG_before = nG;
+    if (rn != 0) {
+      if (!wave_add_poly<W>(e, L, nG, nP, arena_used, rm, rc, rn, rsug, p.elim, p.sort_reducers, &status)) break;
+    } else zero_red++;
+    const double reward = (p.rewards_mode == BBX_REW_ADDITIONS) ? (-1.0 - (double)nsteps_red) : -1.0;  // 328
+    last_reward = reward;
+    total_steps++; total_adds += 1 + nsteps_red; t_agent++; episode_steps++; steps_done++;
+    const bool done = nP == 0;
+
+    // ---- parity trace (tests): hashes of the post-step observation / pair set / new element ---
+    if (tracing) {
+      uint64_t oh = wave_obs<W>(e, p, env, nP, false, true);
+      uint64_t ph = wave_pairs_hash<W>(e, nP);
+      uint64_t nh = nG > nG_before ? wave_poly_hash<W>(e, nG - 1) : 0;
+      if (lane == 0) {
+        BbxTraceRec& tr = p.trace[(size_t)env * p.trace_stride + rollout_pos];
+        tr.action = action; tr.nP = nP; tr.nG = nG; tr.done = done ? 1 : 0; tr.reward = reward;
+        tr.obs_hash = oh; tr.pairs_hash = ph; tr.newpoly_hash = nh;
+      }
+    }
+    budget--; rollout_pos++;
+    done_last = done ? 1 : 0;
+    if (done) {
+      episodes++;
+      if (p.auto_reset) need_reset = 1;
+    }
+  }
+
+  // ---- observation of the state the caller sees next ------------------------------------------
+  if (p.obs && status == BBX_ST_OK) wave_obs<W>(e, p, env, nP, true, false);
+
+  if (lane == 0) {
+    BbxHdr* h = e.hdr;
+    h->nG = nG; h->nP = nP; h->arena_used = arena_used; h->status = status; h->need_reset = need_reset;
+    h->q_head = q_head; h->t = t_agent; h->episode_steps = episode_steps; h->total_steps = total_steps;
+    h->total_additions = total_adds; h->episodes = episodes; h->zero_reductions = zero_red; h->steps_done = steps_done;
+    h->budget = budget; h->rollout_pos = rollout_pos; h->done_last = done_last;
+    if (p.rewards) p.rewards[env] = last_reward;
+    if (p.dones) p.dones[env] = (uint8_t)((done_last || (nP == 0 && !need_reset)) ? 1 : 0);
+    if (p.rows) p.rows[env] = nP;
+  }
+  if (STAGED) {
+    wave_sync();
+    const uint4* src = (const uint4*)rec; uint4* dst = (uint4*)grec;
+    for (uint32_t i = lane; i < p.L.rec_bytes / 16; i += WAVE) dst[i] = src[i];
+  }
+}
+
+// ------------------------------------------------------------------ housekeeping kernels
+// zero the headers and set the per-environment agent seeds
+__global__ void bbx_init_kernel(char* recs, uint32_t rec_bytes, int B, const uint32_t* agent_seeds) {
+  int env = blockIdx.x * blockDim.x + threadIdx.x;
+  if (env >= B) return;
+  BbxHdr* h = (BbxHdr*)(recs + (size_t)env * rec_bytes);
+  BbxHdr z = {};
+  z.agent_seed = agent_seeds ? agent_seeds[env] : (uint32_t)env;
+  *h = z;
+}
+// request a reset (mask == null: every environment); clears a sticky error so the slot can be reused
+__global__ void bbx_mark_reset_kernel(char* recs, uint32_t rec_bytes, int B, const uint8_t* mask) {
+  int env = blockIdx.x * blockDim.x + threadIdx.x;
+  if (env >= B) return;
+  if (mask && !mask[env]) return;
+  BbxHdr* h = (BbxHdr*)(recs + (size_t)env * rec_bytes);
+  h->need_reset = 1; h->status = BBX_ST_OK; h->nP = 0; h->nG = 0; h->arena_used = 0; h->done_last = 0;
+}
+extern "C" int bbx_launch_init(char* recs, uint32_t rec_bytes, int B, const uint32_t* agent_seeds, hipStream_t stream) {
+  hipLaunchKernelGGL(bbx_init_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, recs, rec_bytes, B, agent_seeds);
+  return (int)hipGetLastError();
+}
+extern "C" int bbx_launch_mark_reset(char* recs, uint32_t rec_bytes, int B, const uint8_t* mask, hipStream_t stream) {
+  hipLaunchKernelGGL(bbx_mark_reset_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, recs, rec_bytes, B, mask);
+  return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------ host-callable launcher
+extern "C" int bbx_launch_step(const BbxParams* p, int staged, int envs_per_block, hipStream_t stream) {
+  const int threads = envs_per_block * WAVE;
+  const int blocks = (p->B + envs_per_block - 1) / envs_per_block;
+  const size_t lds = staged ? (size_t)envs_per_block * p->L.rec_bytes : 0;
+  hipError_t err = hipSuccess;
+  if (p->L.W == 2) {
+    if (staged) {
+      err = hipFuncSetAttribute((const void*)bbx_step_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (err != hipSuccess) return (int)err;
+      hipLaunchKernelGGL((bbx_step_kernel<2, true>), dim3(blocks), dim3(threads), lds, stream, *p);
+    } else hipLaunchKernelGGL((bbx_step_kernel<2, false>), dim3(blocks), dim3(threads), 0, stream, *p);
+  } else {
+    if (staged) {
+      err = hipFuncSetAttribute((const void*)bbx_step_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (err != hipSuccess) return (int)err;
+      hipLaunchKernelGGL((bbx_step_kernel<4, true>), dim3(blocks), dim3(threads), lds, stream, *p);
+    } else hipLaunchKernelGGL((bbx_step_kernel<4, false>), dim3(blocks), dim3(threads), 0, stream, *p);
+  }
+  return (int)hipGetLastError();
+}

@@ -1,0 +1,136 @@
+"""Ideal generators with the surface of the reference's deepgroebner/ideals.py, producing the
+seeded streams of the reference's C++ generators (deepgroebner/ideals.cpp) through libbbx.
+
+A polynomial is a list of (coefficient, exponent-tuple) terms in descending grevlex order,
+coefficients in GF(32003); an ideal is a list of polynomials.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+
+NV = 8
+
+
+def _terms(nterms, coefs, exps, n):
+    out, at = [], 0
+    for m in nterms:
+        out.append([(int(coefs[at + t]), tuple(int(x) for x in exps[at + t, :n])) for t in range(m)])
+        at += m
+    return out
+
+
+class IdealGenerator:
+    """Iterator over ideals (reference ideals.py:142-170 / ideals.h:86-104)."""
+
+    def __init__(self, dist):
+        self.dist = dist
+        self._h = C.c_void_p()
+        _ffi.check(_ffi.lib().bbx_gen_create(dist.encode(), C.byref(self._h)))
+        self.nvars = _ffi.lib().bbx_gen_nvars(self._h)
+
+    def __del__(self):
+        try:
+            if self._h:
+                _ffi.lib().bbx_gen_destroy(self._h)
+        except Exception:
+            pass
+
+    def __iter__(self):
+        return self
+
+    def seed(self, seed=None):
+        if seed is not None:
+            _ffi.check(_ffi.lib().bbx_gen_seed(self._h, int(seed)))
+
+    def __next__(self):
+        np_, nt = C.c_int32(), C.c_int32()
+        _ffi.check(_ffi.lib().bbx_gen_next(self._h, C.byref(np_), C.byref(nt)))
+        nterms = np.zeros(max(np_.value, 1), dtype=np.int32)
+        coefs = np.zeros(max(nt.value, 1), dtype=np.int32)
+        exps = np.zeros((max(nt.value, 1), NV), dtype=np.int32)
+        _ffi.check(_ffi.lib().bbx_gen_get(self._h, _ffi.ptr(nterms), _ffi.ptr(coefs), _ffi.ptr(exps), None))
+        return _terms(nterms[:np_.value], coefs, exps, NV)
+
+
+class FixedIdealGenerator:
+    """Repeats one ideal (reference ideals.py:173-189).  F: list of term lists."""
+
+    def __init__(self, F):
+        self.F = [[(int(c), tuple(int(x) for x in e)) for c, e in f] for f in F]
+        self.nvars = max(len(e) for f in self.F for _, e in f)
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        return self.F
+
+    def seed(self, seed=None):
+        pass
+
+
+def _dist_name(n, d, s, dist, constants, homogeneous, pure=False, lam=None):
+    parts = [str(n), str(d), str(s)] + ([repr(float(lam))] if lam is not None else []) + [dist]
+    if constants:
+        parts.append("consts")
+    if homogeneous:
+        parts.append("homog")
+    if pure:
+        parts.append("pure")
+    return "-".join(parts)
+
+
+class RandomBinomialIdealGenerator(IdealGenerator):
+    """Reference ideals.py:192-250 / ideals.cpp:156-201."""
+
+    def __init__(self, n=3, d=20, s=10, degrees="uniform", constants=False, homogeneous=False, pure=False):
+        super().__init__(_dist_name(n, d, s, degrees, constants, homogeneous, pure))
+
+
+class RandomIdealGenerator(IdealGenerator):
+    """Reference ideals.py:253-323 / ideals.cpp:203-231."""
+
+    def __init__(self, n=3, d=20, s=10, lam=0.5, degrees="uniform", constants=False, homogeneous=False):
+        super().__init__(_dist_name(n, d, s, degrees, constants, homogeneous, lam=lam))
+
+
+def parse_ideal_dist(ideal_dist):
+    """String -> generator, same grammar as the reference (ideals.py:112-139, ideals.cpp:103-143)."""
+    return IdealGenerator(ideal_dist)
+
+
+def cyclic(n):
+    g = IdealGenerator("cyclic-%d" % n)
+    return [[(c, e[:n]) for c, e in f] for f in next(g)]
+
+
+def basis(n, d):
+    """Monomials of degree d in n variables in the reference's enumeration order (ideals.cpp:39-64)."""
+    out = []
+
+    def rec(prefix, left, slots):
+        if slots == 1:
+            out.append(tuple(prefix + [left]))
+            return
+        for first in range(left, -1, -1):
+            rec(prefix + [first], left - first, slots - 1)
+    rec([], d, n)
+    return out
+
+
+def degree_distribution(n, d, dist="uniform", constants=False):
+    """Probabilities over degrees 0..d (ideals.cpp:75-100)."""
+    from math import comb
+    w = [1 if constants else 0]
+    if dist == "uniform":
+        w += [comb(n + i - 1, n - 1) for i in range(1, d + 1)]
+    elif dist == "weighted":
+        w += [1] * d
+    elif dist == "maximum":
+        w += [0] * (d - 1) + [1]
+    else:
+        raise ValueError("unrecognized distribution type")
+    tot = float(sum(w))
+    return [x / tot for x in w]

@@ -1,0 +1,147 @@
+/* bbx — MI355X-native BuchbergerEnv step path: the C ABI of libbbx.so
+ *
+ * This is the drop-in boundary for the one hot path of dylanpeifer/deepgroebner that this
+ * project replaces: everything the reference's Cython binding (deepgroebner/wrapped.pyx:11-38,
+ * declared in deepgroebner/buchberger.pxd:8-18) calls on the C++ class LeadMonomialsEnv
+ * (deepgroebner/buchberger.h:224-257, buchberger.cpp:373-408) — generalised from one
+ * environment per object to a batch of independent environments per handle, because the device
+ * wants thousands of them per launch.  batch == 1 is exactly the reference's single env.
+ *
+ * Conventions: plain C, caller-allocated outputs, every entry point returns 0 or a negative
+ * bbx_status; nothing throws across the ABI; bbx_last_error() (thread-local) explains the last
+ * failure.  One host thread per handle.  The library owns all device memory.  It fails loudly
+ * (BBX_E_DEVICE) when no HIP device is usable: there is no CPU fallback in the product.
+ */
+#ifndef BBX_H
+#define BBX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bbx_batch bbx_batch;
+
+enum bbx_status {
+  BBX_OK = 0,
+  BBX_E_ARG = -1,         /* bad argument / unparsable distribution string */
+  BBX_E_DEVICE = -2,      /* HIP error or no device */
+  BBX_E_CAPACITY = -3,    /* an environment exceeded its configured capacity (see bbx_env_status) */
+  BBX_E_GENERATOR = -4,   /* the ideal generator failed (the reference would have thrown) */
+  BBX_E_UNSUPPORTED = -5, /* e.g. 8 variables, poisson mean >= 12 */
+  BBX_E_ACTION = -6       /* an action index was outside [0, rows) */
+};
+
+/* elimination / reward selectors (reference enums buchberger.h:58 and :93) */
+enum { BBX_GEBAUERMOELLER = 0, BBX_LCM = 1, BBX_NONE = 2 };
+enum { BBX_ADDITIONS = 0, BBX_REDUCTIONS = 1 };
+/* built-in device-side agents for bbx_rollout (0 = actions supplied by the caller) */
+enum { BBX_EXTERNAL = 0, BBX_RANDOM_HASH = 1, BBX_DEGREE = 2, BBX_FIRST = 3 };
+
+/* Per-environment capacities; 0 picks a default suited to the distribution. */
+typedef struct bbx_caps {
+  int32_t max_basis;      /* |G|  (<= 65535) */
+  int32_t max_pairs;      /* |P| */
+  int32_t arena_terms;    /* total terms of all basis polynomials */
+  int32_t max_poly_terms; /* longest intermediate polynomial during spoly/reduce (<= 65535) */
+  int32_t queue_slots;    /* pre-generated ideals buffered per environment for device-side resets */
+} bbx_caps;
+
+/* One record per environment per step of a traced rollout (parity tests). */
+typedef struct bbx_trace_rec {
+  int32_t action, rows, basis_size, done;
+  double reward;
+  uint64_t obs_hash, pairs_hash, newpoly_hash;
+} bbx_trace_rec;
+
+/* ---- construction ------------------------------------------------------------------------------
+ * Replaces LeadMonomialsEnv::LeadMonomialsEnv(ideal_dist, sort_input, sort_reducers, k)
+ * (buchberger.cpp:373-381; reached from wrapped.pyx:14-16) and, for the options the Cython class
+ * ignores but the Python class honours, BuchbergerEnv's constructor (buchberger.cpp:269-276;
+ * buchberger.py:320-326).  ideal_dist uses the reference grammar (ideals.cpp:103-143). */
+int bbx_create(const char* ideal_dist, int elimination, int rewards, int sort_input, int sort_reducers,
+               int k, int batch, int device, const bbx_caps* caps, bbx_batch** out);
+/* Same over a fixed ideal (FixedIdealGenerator, ideals.h:116-138): polynomial p has nterms[p] terms,
+ * coefs/exps (8 ints per term) are concatenated.  nvars_obs <= 0 reproduces the reference's
+ * "largest variable index" quirk (ideals.cpp:146-154). */
+int bbx_create_fixed(int npolys, const int32_t* nterms, const int32_t* coefs, const int32_t* exps, int nvars_obs,
+                     int elimination, int rewards, int sort_input, int sort_reducers,
+                     int k, int batch, int device, const bbx_caps* caps, bbx_batch** out);
+void bbx_destroy(bbx_batch* b);
+/* LeadMonomialsEnv copy constructor (buchberger.pxd:11, wrapped.pyx:35-38): deep clone incl. the
+ * generators' RNG state. */
+int bbx_copy(const bbx_batch* b, bbx_batch** out);
+
+/* ---- LeadMonomialsEnv::seed (buchberger.h:243, wrapped.pyx:28-30): one seed per environment ---- */
+int bbx_seed(bbx_batch* b, const int64_t* seeds);
+/* seeds of the built-in BBX_RANDOM_HASH agent: action = bbx_agent_hash(seed, t) mod rows */
+int bbx_seed_agent(bbx_batch* b, const uint32_t* seeds);
+
+/* ---- LeadMonomialsEnv::reset (buchberger.cpp:384-395, wrapped.pyx:18-21) ----------------------
+ * mask == NULL resets every environment, else those with mask[e] != 0.  rows[e] = |P|. */
+int bbx_reset(bbx_batch* b, const uint8_t* mask, int32_t* rows);
+
+/* ---- LeadMonomialsEnv::step (buchberger.cpp:398-408, wrapped.pyx:23-26) -----------------------
+ * actions[e] indexes the rows of environment e's observation.  Environments that are done are
+ * left untouched (reward 0).  rewards/dones/rows may be NULL. */
+int bbx_step(bbx_batch* b, const int32_t* actions, double* rewards, uint8_t* dones, int32_t* rows);
+
+/* nsteps steps per environment in one go with a device-side agent, optionally re-drawing a new
+ * ideal whenever an episode ends (what the reference's scripts/random_episodes.cpp:13-29 loop does
+ * on the host).  rewards/dones/rows describe the LAST step. */
+int bbx_rollout(bbx_batch* b, int agent, int nsteps, int auto_reset, double* rewards, uint8_t* dones, int32_t* rows);
+
+/* ---- the observation: `state` of LeadMonomialsEnv (buchberger.h:247-248; wrapped.pyx:20,25) ---
+ * out is int32 [batch, max_rows, cols], cols = 2*nvars*k; rows beyond |P| are filled with -1 when
+ * fill != 0 (the padding the reference's agents apply, pg.py:217-226). */
+int bbx_obs(bbx_batch* b, int32_t* out, int max_rows, int fill);
+int bbx_cols(const bbx_batch* b);
+int bbx_nvars(const bbx_batch* b);
+int bbx_batch_size(const bbx_batch* b);
+
+/* ---- LeadMonomialsEnv::value (buchberger.h:245, buchberger.cpp:332-351, wrapped.pyx:32-33) ----
+ * discounted return of a full Buchberger rollout from environment idx's current state.
+ * Unknown strategies select First, as the reference's std::map lookup does. */
+int bbx_value(bbx_batch* b, int idx, const char* strategy, double gamma, double* out);
+
+/* ---- same calls on caller-owned DEVICE buffers (e.g. torch tensors), asynchronous on `stream` ----
+ * (hipStream_t passed as void*; NULL = the default stream).  obs may be NULL. */
+int bbx_step_device(bbx_batch* b, const int32_t* d_actions, double* d_rewards, uint8_t* d_dones, int32_t* d_rows,
+                    int32_t* d_obs, int obs_rows, int obs_fill, void* stream);
+int bbx_rollout_device(bbx_batch* b, int agent, int nsteps, int auto_reset, double* d_rewards, uint8_t* d_dones,
+                       int32_t* d_rows, int32_t* d_obs, int obs_rows, int obs_fill, void* stream);
+/* after asynchronous rollouts: waits, refills the ideal queues, finishes environments that had to
+ * wait for ideals; returns BBX_E_CAPACITY etc. if any environment failed */
+int bbx_sync(bbx_batch* b);
+
+/* ---- introspection (tests, checkpoints) -------------------------------------------------------- */
+/* per environment: [total_steps, total_additions, episodes, zero_reductions, status, ideals_consumed] */
+int bbx_stats(bbx_batch* b, int64_t* out6);
+int bbx_env_status(bbx_batch* b, int32_t* status);
+int bbx_state_sizes(bbx_batch* b, int idx, int32_t* basis_size, int32_t* npairs, int32_t* nterms_total);
+/* G[0..basis_size): nterms[i], then concatenated coefs and exps (8 ints per term); pairs as (i,j);
+ * order[r] = index into G of the r-th reducer */
+int bbx_state_get(bbx_batch* b, int idx, int32_t* nterms, int32_t* coefs, int32_t* exps, int32_t* pairs, int32_t* order);
+int bbx_trace_enable(bbx_batch* b, int capacity_steps);  /* 0 disables */
+int bbx_trace_read(bbx_batch* b, int env, int first, int count, bbx_trace_rec* out);
+
+/* ---- ideal generators on their own (reference deepgroebner/ideals.{h,cpp}; host only) ---------- */
+typedef struct bbx_gen bbx_gen;
+int bbx_gen_create(const char* ideal_dist, bbx_gen** out);
+void bbx_gen_destroy(bbx_gen* g);
+int bbx_gen_seed(bbx_gen* g, int64_t seed);
+int bbx_gen_nvars(const bbx_gen* g);
+/* bbx_gen_next draws the next ideal (IdealGenerator::next) and reports its size; bbx_gen_get copies
+ * the ideal drawn last: nterms[npolys], coefs[nterms_total], exps[nterms_total*8]; sugars may be NULL */
+int bbx_gen_next(bbx_gen* g, int32_t* npolys, int32_t* nterms_total);
+int bbx_gen_get(const bbx_gen* g, int32_t* nterms, int32_t* coefs, int32_t* exps, int32_t* sugars);
+
+uint32_t bbx_agent_hash(uint32_t seed, uint32_t t);
+const char* bbx_last_error(void);
+const char* bbx_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -8,23 +8,25 @@ import numpy as np
 
 from . import ffi
 
-FNV_OFF = 0xcbf29ce484222325
-FNV_PRIME = 0x100000001b3
 M64 = (1 << 64) - 1
+_C0 = np.uint64(0x9E3779B97F4A7C15)
+_C1 = np.uint64(0xBF58476D1CE4E5B9)
+_C2 = np.uint64(0x94D049BB133111EB)
 
 
-def fnv64(arr, h=FNV_OFF):
-    """FNV-1a over the int32 little-endian words of arr (word-wise, not byte-wise)."""
-    a = np.ascontiguousarray(arr, dtype=np.int32).ravel().astype(np.uint32)
-    for w in a.tolist():
-        h = ((h ^ w) * FNV_PRIME) & M64
-    return h
-
-
-def fnv64_fast(arr, h=FNV_OFF):
-    """Same value as fnv64, vectorised in chunks via python ints only when small;
-    for big arrays callers should hash per step (arrays are tiny per step)."""
-    return fnv64(arr, h)
+def fnv64(arr):
+    """Position-keyed commutative hash of an int32 word stream: sum_i mix64(i, word_i) mod 2^64
+    (bbx_mix64 in deepgroebner_amd/csrc/bbx_common.h; a sum so that a wavefront can compute it in
+    parallel).  The name is historical."""
+    a = np.ascontiguousarray(arr, dtype=np.int32).ravel().astype(np.uint32).astype(np.uint64)
+    if a.size == 0:
+        return 0
+    with np.errstate(over="ignore"):
+        z = ((np.arange(a.size, dtype=np.uint64) << np.uint64(32)) | a) + _C0
+        z = (z ^ (z >> np.uint64(30))) * _C1
+        z = (z ^ (z >> np.uint64(27))) * _C2
+        z = z ^ (z >> np.uint64(31))
+        return int(np.add.reduce(z, dtype=np.uint64))
 
 
 def degree_action(env):

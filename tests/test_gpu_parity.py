@@ -1,0 +1,153 @@
+"""Parity of the HIP path (through the C ABI) against the golden vectors recorded from the
+compiled reference and against the CPU oracle.  Bit-exact: every action, reward, |P|, |G|,
+observation matrix, pair list and new basis element of every step, plus the full final state."""
+import numpy as np
+import pytest
+
+from oracle import ffi
+from oracle.trace import fnv64, poly_words, run_trace
+from tests.golden_util import load_trace, meta, trace_names
+
+pytestmark = pytest.mark.gpu
+
+POLICY = {"hash": "random", "degree": "degree", "first": "first"}
+
+
+def make_env(m, batch, **extra):
+    from deepgroebner_amd import VecLeadMonomialsEnv
+    return VecLeadMonomialsEnv(m["dist"], batch=batch, k=m["k"], **m["kwargs"], **extra)
+
+
+def compare_with_trace(env, e, want, T, label):
+    got = env.trace_read(e, 0, T)
+    for field, key in (("action", "action"), ("reward", "reward"), ("rows", "nP"), ("basis_size", "nG"), ("done", "done"),
+                       ("obs_hash", "obs_hash"), ("pairs_hash", "pairs_hash"), ("newpoly_hash", "newpoly_hash")):
+        w = np.asarray(want[key])
+        g = got[field].astype(w.dtype)
+        if not np.array_equal(g, w):
+            bad = int(np.flatnonzero(g != w)[0])
+            raise AssertionError("%s env %d: %s differs first at step %d: %r != %r" % (label, e, field, bad, g[bad], w[bad]))
+    basis, pairs, order = env.state(e)
+    assert np.array_equal(pairs, want["final_pairs"]), label
+    assert np.array_equal(order, want["final_order"]), label
+    words = [poly_words(c, x) for c, x in basis]
+    assert np.array_equal(np.concatenate(words) if words else np.zeros(0, np.int32), want["final_basis"]), label
+
+
+@pytest.mark.parametrize("name", trace_names())
+def test_golden_trace(name):
+    m = meta()["traces"][name]
+    gold = load_trace(name)
+    B = m["nenvs"]
+    T = len(gold["e0_action"])
+    env = make_env(m, B)
+    env.seed(np.arange(B) + m["seed0"])
+    env.seed_agent(np.arange(B) + m["agent_seed0"])
+    env.trace_enable(max(T, 1))
+    obs0 = env.reset()
+    for e in range(B):
+        assert (len(env.state(e)[0]), int(env.rows[e])) == tuple(gold["e%d_init" % e]), name
+        assert fnv64(obs0[e]) == int(gold["e%d_init_hash" % e][0]), name
+    env.rollout(POLICY[m["policy"]], T, auto_reset=not m["until_done"])
+    final_obs = env.observations()
+    for e in range(B):
+        want = {k[len("e%d_" % e):]: gold[k] for k in gold.files if k.startswith("e%d_" % e)}
+        assert len(want["action"]) == T
+        compare_with_trace(env, e, want, T, name)
+        assert np.array_equal(final_obs[e], want["final_obs"]), name
+
+
+def test_gym_surface_single_env_vs_oracle():
+    """CLeadMonomialsEnv.reset/step with host-chosen actions, observation compared matrix by matrix."""
+    from deepgroebner_amd import CLeadMonomialsEnv
+    bo = ffi.load("bo")
+    env = CLeadMonomialsEnv("3-20-10-weighted", k=2)
+    env.seed(123)
+    o = bo.env("3-20-10-weighted")
+    o.seed(123)
+    for episode in range(3):
+        state = env.reset()
+        o.reset()
+        assert state.dtype == np.int32 and np.array_equal(state, o.obs(2))
+        if episode == 0:
+            assert state.shape == (19, 12) and state[0].tolist() == [11, 6, 3, 9, 7, 2, 7, 0, 5, 2, 0, 2]
+        t = 0
+        done = False
+        while not done:
+            a = ffi.agent_hash(7, t) % len(state)
+            state, r, done, info = env.step(np.int64(a))
+            assert r == o.step(a) and info == {}
+            assert np.array_equal(state, o.obs(2))
+            assert done == (o.nP == 0) and (len(state) == 0) == done
+            t += 1
+
+
+def test_vec_step_matches_oracle_and_masked_reset():
+    from deepgroebner_amd import VecLeadMonomialsEnv
+    bo = ffi.load("bo")
+    B, k = 5, 1
+    env = VecLeadMonomialsEnv("3-20-10-uniform", batch=B, k=k)
+    env.seed(np.arange(B) + 77)
+    oracles = []
+    for e in range(B):
+        o = bo.env("3-20-10-uniform"); o.seed(77 + e); o.reset(); oracles.append(o)
+    obs = env.reset()
+    for t in range(150):
+        for e in range(B):
+            assert np.array_equal(obs[e], oracles[e].obs(k)), (t, e)
+        acts = np.array([ffi.agent_hash(e, t) % max(1, oracles[e].nP) for e in range(B)], dtype=np.int32)
+        obs, r, d, _ = env.step(acts)
+        mask = np.zeros(B, dtype=np.uint8)
+        for e in range(B):
+            if oracles[e].nP == 0:       # finished earlier and not reset: untouched
+                continue
+            assert r[e] == oracles[e].step(int(acts[e])), (t, e)
+            assert bool(d[e]) == (oracles[e].nP == 0)
+            if oracles[e].nP == 0 and (t + e) % 2 == 0:
+                mask[e] = 1
+        if mask.any():
+            obs = env.reset(mask)
+            for e in np.flatnonzero(mask):
+                oracles[e].reset()
+
+
+def test_fixed_ideal_python_flavour_and_eliminations():
+    """tests/test_buchberger.py:328-362 of the reference (LeadMonomialsEnv over a FixedIdealGenerator)."""
+    from deepgroebner_amd import FixedIdealGenerator, LeadMonomialsEnv
+    F = [[(1, (0, 1, 0)), (-1, (2, 0, 0))], [(1, (0, 0, 1)), (-1, (3, 0, 0))]]     # y - x^2, z - x^3
+    env = LeadMonomialsEnv(FixedIdealGenerator(F))
+    state = env.reset()
+    assert np.array_equal(state, [[2, 0, 0, 3, 0, 0]])
+    state, _, done, _ = env.step(0)
+    assert np.array_equal(state, [[2, 0, 0, 1, 1, 0]]) and not done
+    state, _, done, _ = env.step(0)
+    assert np.array_equal(state, [[1, 1, 0, 0, 2, 0]]) and not done
+    state, _, done, _ = env.step(0)
+    assert done
+    env = LeadMonomialsEnv(FixedIdealGenerator(F), elimination="none")
+    state = env.reset()
+    state, _, done, _ = env.step(0)
+    assert np.array_equal(state, [[2, 0, 0, 1, 1, 0], [3, 0, 0, 1, 1, 0]])
+
+
+def test_copy_is_deep():
+    from deepgroebner_amd import CLeadMonomialsEnv
+    env = CLeadMonomialsEnv("3-20-10-weighted", k=2)
+    env.seed(5)
+    s0 = env.reset()
+    cp = env.copy()
+    s1, r1, _, _ = env.step(0)
+    s1c, r1c, _, _ = cp.step(0)
+    assert np.array_equal(s1, s1c) and r1 == r1c
+    env.step(0)
+    assert np.array_equal(cp.reset(), env.reset())    # generator state travelled with the copy
+
+
+def test_capacity_overflow_is_reported_not_wrapped():
+    from deepgroebner_amd import VecLeadMonomialsEnv, _ffi
+    env = VecLeadMonomialsEnv("3-20-10-weighted", batch=4, k=1, caps={"max_basis": 12, "max_pairs": 16})
+    env.seed(np.arange(4))
+    env.reset()
+    with pytest.raises(_ffi.BbxError) as ei:
+        env.rollout("random", 200, auto_reset=True)
+    assert ei.value.code == -3
