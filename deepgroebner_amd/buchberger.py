@@ -128,7 +128,7 @@ class VecLeadMonomialsEnv:
 
     # ---- introspection
     def stats(self):
-        out = np.zeros((self.batch, 6), dtype=np.int64)
+        out = np.zeros((self.batch, 8), dtype=np.int64)
         _ffi.check(_ffi.lib().bbx_stats(self._h, _ffi.ptr(out)))
         return out
 
@@ -147,6 +147,18 @@ class VecLeadMonomialsEnv:
             basis.append((coefs[at:at + nterms[g]].copy(), exps[at:at + nterms[g]].copy()))
             at += nterms[g]
         return basis, pairs[:nP.value].copy(), order[:nG.value].copy()
+
+    def rollout_device(self, agent, nsteps, auto_reset=True, stream=0, rewards=None, dones=None, rows=None,
+                       obs=None, obs_rows=0, obs_fill=False):
+        """Asynchronous rollout on caller-owned device buffers (raw device pointers or objects with
+        .data_ptr(), e.g. torch tensors); call sync() before reading results."""
+        def dp(x):
+            return None if x is None else C.c_void_p(x.data_ptr() if hasattr(x, "data_ptr") else int(x))
+        _ffi.check(_ffi.lib().bbx_rollout_device(self._h, _ffi.AGENTS[agent], int(nsteps), int(auto_reset), dp(rewards), dp(dones),
+                                                 dp(rows), dp(obs), int(obs_rows), int(obs_fill), C.c_void_p(int(stream))))
+
+    def sync(self):
+        _ffi.check(_ffi.lib().bbx_sync(self._h))
 
     def trace_enable(self, capacity):
         _ffi.check(_ffi.lib().bbx_trace_enable(self._h, int(capacity)))

@@ -81,6 +81,7 @@ struct bbx_batch {
   std::vector<char> h_out;
   // the rollout in flight (so bbx_sync can finish environments that waited for ideals)
   BbxParams last{};
+  hipStream_t last_stream = 0;
   bool in_flight = false;
   int staged = 0, envs_per_block = 4;
 };
@@ -211,6 +212,7 @@ int launch(bbx_batch* b, BbxParams& p, hipStream_t stream) {
   int rc = fill_queues(b);
   if (rc) return rc;
   b->last = p;
+  b->last_stream = stream;
   b->in_flight = true;
   int lrc = bbx_launch_step(&p, b->staged, b->envs_per_block, stream);
   if (lrc) return fail(BBX_E_DEVICE, "kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
@@ -469,7 +471,7 @@ int bbx_sync(bbx_batch* b) {
   if (!b) return fail(BBX_E_ARG, "null argument");
   HIPCHK(hipSetDevice(b->device));
   if (!b->in_flight) { HIPCHK(hipDeviceSynchronize()); return BBX_OK; }
-  return finish(b, 0);
+  return finish(b, b->last_stream);
 }
 
 int bbx_obs(bbx_batch* b, int32_t* out, int max_rows, int fill) {
@@ -503,7 +505,8 @@ int bbx_value(bbx_batch* b, int idx, const char* strategy, double gamma, double*
   return fail(BBX_E_UNSUPPORTED, "bbx_value: device-side value rollouts are not built yet");
 }
 
-int bbx_stats(bbx_batch* b, int64_t* out6) {
+int bbx_stats(bbx_batch* b, int64_t* out8) {
+  int64_t* out6 = out8;
   if (!b || !out6) return fail(BBX_E_ARG, "null argument");
   HIPCHK(hipSetDevice(b->device));
   HIPCHK(hipDeviceSynchronize());
@@ -511,8 +514,9 @@ int bbx_stats(bbx_batch* b, int64_t* out6) {
   if (rc) return rc;
   for (int e = 0; e < b->B; e++) {
     const BbxHdr& h = b->h_hdr[e];
-    int64_t* o = out6 + (size_t)e * 6;
+    int64_t* o = out6 + (size_t)e * 8;
     o[0] = h.total_steps; o[1] = h.total_additions; o[2] = h.episodes; o[3] = h.zero_reductions; o[4] = h.status; o[5] = h.q_head;
+    o[6] = h.alg_bytes; o[7] = h.nG;
   }
   return BBX_OK;
 }

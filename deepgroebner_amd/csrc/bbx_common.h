@@ -53,7 +53,9 @@ struct BbxHdr {             // 128 bytes
   int32_t budget;           // steps still owed in the current rollout (survives queue starvation)
   int32_t rollout_pos;      // steps completed in the current rollout (trace slot)
   int32_t done_last;        // the last executed step ended an episode
-  int32_t reserved[13];
+  int32_t reserved0;
+  int64_t alg_bytes;        // algorithmic bytes moved so far (SURVEY.md 8d formula), for the roofline figure
+  int32_t reserved[10];
 };
 
 struct BbxLayout {

@@ -447,7 +447,7 @@ __global__ __launch_bounds__(256) void bbx_step_kernel(BbxParams p) {
   int status = uni(e.hdr->status), need_reset = uni(e.hdr->need_reset), q_head = uni(e.hdr->q_head);
   int t_agent = uni(e.hdr->t), episode_steps = uni(e.hdr->episode_steps);
   int episodes = uni(e.hdr->episodes), zero_red = uni(e.hdr->zero_reductions);
-  long long total_steps = e.hdr->total_steps, total_adds = e.hdr->total_additions;
+  long long total_steps = e.hdr->total_steps, total_adds = e.hdr->total_additions, alg_bytes = e.hdr->alg_bytes;
   const uint32_t agent_seed = e.hdr->agent_seed;
   if (status == BBX_ST_STARVED) status = BBX_ST_OK;   // the host has refilled the queue
   int budget = uni(e.hdr->budget), rollout_pos = uni(e.hdr->rollout_pos);
@@ -518,6 +518,7 @@ __global__ __launch_bounds__(256) void bbx_step_kernel(BbxParams p) {
       if (A.n + Bv.n > 2 * maxT) { status = BBX_ST_POLY_TOO_LONG; break; }
       hn = wave_merge<W>(A, Bv, tm, tc, hm, hc, maxT);
       if (hn < 0) { status = BBX_ST_POLY_TOO_LONG; break; }
+      alg_bytes += 12LL * (A.n + Bv.n + 2 + hn);   // both inputs read, S-polynomial written
     }
 
     // ---- reduce  buchberger.cpp:24-49 -----------------------------------------------------------
@@ -546,10 +547,12 @@ __global__ __launch_bounds__(256) void bbx_step_kernel(BbxParams p) {
         Mono<W>* nm = (hm == hm0) ? hm1 : hm0; uint16_t* nc = (hc == hc0) ? hc1 : hc0;
         int nn = wave_merge<W>(A, Bv, tm, tc, nm, nc, maxT);
         if (nn < 0) { status = BBX_ST_POLY_TOO_LONG; overflow = true; break; }
+        alg_bytes += 8LL * (found + 1) + 12LL * (Bv.n + 1) + 12LL * (A.n + 1 + nn);
         hm = nm; hc = nc; hn = nn; hoff = 0;
         nsteps_red++;
       } else {                                  // r <- r + LT h ; h <- h - LT h   (41-44)
         if (rn >= maxT) { status = BBX_ST_POLY_TOO_LONG; overflow = true; break; }
+        alg_bytes += 8LL * nG + 12LL * (2 * (hn - hoff) - 1);
         if (lane == 0) { rm[rn] = lmh; rc[rn] = hc[hoff]; }
         int d = (int)m_deg(lmh);
         rsug = d > rsug ? d : rsug;
@@ -561,10 +564,12 @@ __global__ __launch_bounds__(256) void bbx_step_kernel(BbxParams p) {
     rsug = rsug > hsug ? rsug : hsug;            // sugar of r + h (48), h's sugar survives its terms
 
     // ---- basis / pair-set update  buchberger.cpp:321-327 ---------------------------------------
-    const int nG_before = nG;
+    const int nG_before = nG, nP_before = nP;
     if (rn != 0) {
       if (!wave_add_poly<W>(e, L, nG, nP, arena_used, rm, rc, rn, rsug, p.elim, p.sort_reducers, &status)) break;
+      alg_bytes += 12LL * rn + 8LL * nG_before + 8LL * (nP_before + nP);
     } else zero_red++;
+    alg_bytes += 4LL * nP * 2 * p.nvars * p.k;      // the observation matrix of the new state
     const double reward = (p.rewards_mode == BBX_REW_ADDITIONS) ? (-1.0 - (double)nsteps_red) : -1.0;  // 328
     last_reward = reward;
     total_steps++; total_adds += 1 + nsteps_red; t_agent++; episode_steps++; steps_done++;
@@ -597,7 +602,7 @@ __global__ __launch_bounds__(256) void bbx_step_kernel(BbxParams p) {
     h->nG = nG; h->nP = nP; h->arena_used = arena_used; h->status = status; h->need_reset = need_reset;
     h->q_head = q_head; h->t = t_agent; h->episode_steps = episode_steps; h->total_steps = total_steps;
     h->total_additions = total_adds; h->episodes = episodes; h->zero_reductions = zero_red; h->steps_done = steps_done;
-    h->budget = budget; h->rollout_pos = rollout_pos; h->done_last = done_last;
+    h->budget = budget; h->rollout_pos = rollout_pos; h->done_last = done_last; h->alg_bytes = alg_bytes;
     if (p.rewards) p.rewards[env] = last_reward;
     if (p.dones) p.dones[env] = (uint8_t)((done_last || (nP == 0 && !need_reset)) ? 1 : 0);
     if (p.rows) p.rows[env] = nP;

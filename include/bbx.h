@@ -116,8 +116,9 @@ int bbx_rollout_device(bbx_batch* b, int agent, int nsteps, int auto_reset, doub
 int bbx_sync(bbx_batch* b);
 
 /* ---- introspection (tests, checkpoints) -------------------------------------------------------- */
-/* per environment: [total_steps, total_additions, episodes, zero_reductions, status, ideals_consumed] */
-int bbx_stats(bbx_batch* b, int64_t* out6);
+/* per environment 8 values: total_steps, total_additions, episodes, zero_reductions, status,
+ * ideals_consumed, algorithmic_bytes (the roofline numerator), basis_size */
+int bbx_stats(bbx_batch* b, int64_t* out8);
 int bbx_env_status(bbx_batch* b, int32_t* status);
 int bbx_state_sizes(bbx_batch* b, int idx, int32_t* basis_size, int32_t* npairs, int32_t* nterms_total);
 /* G[0..basis_size): nterms[i], then concatenated coefs and exps (8 ints per term); pairs as (i,j);

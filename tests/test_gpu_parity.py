@@ -151,3 +151,24 @@ def test_capacity_overflow_is_reported_not_wrapped():
     with pytest.raises(_ffi.BbxError) as ei:
         env.rollout("random", 200, auto_reset=True)
     assert ei.value.code == -3
+
+
+def test_algorithmic_byte_counter_matches_oracle():
+    """The roofline numerator counted on the device equals the oracle's count (SURVEY 8d formula)."""
+    from deepgroebner_amd import VecLeadMonomialsEnv
+    bo = ffi.load("bo")
+    B, T, k = 4, 200, 2
+    env = VecLeadMonomialsEnv("3-20-10-weighted", batch=B, k=k)
+    env.seed(np.arange(B) + 1000); env.seed_agent(np.arange(B)); env.reset()
+    env.rollout("random", T, auto_reset=True)
+    st = env.stats()
+    for e in range(B):
+        o = bo.env("3-20-10-weighted"); o.seed(1000 + e); o.reset()
+        total = adds = 0
+        for t in range(T):
+            r = o.step(ffi.agent_hash(e, t) % o.nP)
+            total += o.last_step_bytes() + 4 * o.nP * 2 * 3 * k
+            adds += int(-r)
+            if o.nP == 0:
+                o.reset()
+        assert (st[e, 0], st[e, 1], st[e, 6]) == (T, adds, total)
