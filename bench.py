@@ -85,13 +85,14 @@ def main():
         done = 0
         while done < nsteps:
             n = min(chunk, nsteps - done)
-            env.rollout_device("random", n, True, stream.cuda_stream, d_rew, d_done, d_rows, d_obs, obs_rows, False)
+            env.rollout_device("random", n, True, stream.cuda_stream, d_rew, d_done, d_rows, d_obs, obs_rows, False, True)
             env.sync()
             done += n
 
     if Wm > 0:
         run(Wm)
     st0 = env.stats()
+    env.timing(True)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -105,7 +106,8 @@ def main():
         dist.barrier()
     t1 = time.perf_counter()
     elapsed = t1 - t0
-    kernel_ms = ev0.elapsed_time(ev1)
+    region_ms = ev0.elapsed_time(ev1)
+    kernel_ms, nlaunch = env.timing(False)       # HIP events around each step-kernel launch, on its stream
     st1 = env.stats()
     d = st1 - st0
     steps_done = int(d[:, 0].sum())
@@ -113,7 +115,6 @@ def main():
     assert (st1[:, 4] == 0).all(), "an environment reported an error status"
     additions = int(d[:, 1].sum())
     alg_bytes = int(d[:, 6].sum())
-    nlaunch = (K + chunk - 1) // chunk
 
     if world > 1:
         t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda")
@@ -144,7 +145,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "bbx_step_kernel", "alg_bytes_per_env_step": alg_bytes / steps_done,
-                         "kernel_ms_per_launch": kernel_ms / nlaunch, "launches": nlaunch},
+                         "kernel_ms_per_launch": kernel_ms / nlaunch, "launches": nlaunch, "timed_region_ms": region_ms},
             "cpu_baseline": cpu,
         }
         print(json.dumps(out))

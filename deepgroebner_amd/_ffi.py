@@ -26,7 +26,7 @@ class BbxError(RuntimeError):
 
 class Caps(C.Structure):
     _fields_ = [("max_basis", C.c_int32), ("max_pairs", C.c_int32), ("arena_terms", C.c_int32),
-                ("max_poly_terms", C.c_int32), ("queue_slots", C.c_int32)]
+                ("max_poly_terms", C.c_int32), ("queue_slots", C.c_int32), ("lds_max_basis", C.c_int32)]
 
 
 class TraceRec(C.Structure):
@@ -57,7 +57,8 @@ SIGNATURES = {
     "bbx_batch_size": (C.c_int, [_vp]),
     "bbx_value": (C.c_int, [_vp, C.c_int, C.c_char_p, C.c_double, C.POINTER(C.c_double)]),
     "bbx_step_device": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp]),
-    "bbx_rollout_device": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp]),
+    "bbx_rollout_device": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
+    "bbx_timing": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_double), _i32p]),
     "bbx_sync": (C.c_int, [_vp]),
     "bbx_stats": (C.c_int, [_vp, _vp]),
     "bbx_env_status": (C.c_int, [_vp, _vp]),

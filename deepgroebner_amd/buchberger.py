@@ -149,16 +149,22 @@ class VecLeadMonomialsEnv:
         return basis, pairs[:nP.value].copy(), order[:nG.value].copy()
 
     def rollout_device(self, agent, nsteps, auto_reset=True, stream=0, rewards=None, dones=None, rows=None,
-                       obs=None, obs_rows=0, obs_fill=False):
+                       obs=None, obs_rows=0, obs_fill=False, obs_every_step=False):
         """Asynchronous rollout on caller-owned device buffers (raw device pointers or objects with
         .data_ptr(), e.g. torch tensors); call sync() before reading results."""
         def dp(x):
             return None if x is None else C.c_void_p(x.data_ptr() if hasattr(x, "data_ptr") else int(x))
         _ffi.check(_ffi.lib().bbx_rollout_device(self._h, _ffi.AGENTS[agent], int(nsteps), int(auto_reset), dp(rewards), dp(dones),
-                                                 dp(rows), dp(obs), int(obs_rows), int(obs_fill), C.c_void_p(int(stream))))
+                                                 dp(rows), dp(obs), int(obs_rows), int(obs_fill), int(obs_every_step), C.c_void_p(int(stream))))
 
     def sync(self):
         _ffi.check(_ffi.lib().bbx_sync(self._h))
+
+    def timing(self, enable=True):
+        """(kernel milliseconds, launches) of the step kernel since the last call (HIP events on its stream)."""
+        ms, n = C.c_double(), C.c_int32()
+        _ffi.check(_ffi.lib().bbx_timing(self._h, int(enable), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
 
     def trace_enable(self, capacity):
         _ffi.check(_ffi.lib().bbx_trace_enable(self._h, int(capacity)))

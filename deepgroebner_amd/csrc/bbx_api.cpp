@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -15,7 +16,8 @@
 #include "bbx_common.h"
 #include "bbx_ideals.h"
 
-extern "C" int bbx_launch_step(const BbxParams* p, int staged, int envs_per_block, hipStream_t stream);
+extern "C" int bbx_launch_step(const BbxParams* p, int kind, int envs_per_block, hipStream_t stream);
+extern "C" int bbx_launch_gather_hdr(const char* recs, uint32_t rec_bytes, int B, BbxHdr* out, hipStream_t stream);
 extern "C" int bbx_launch_init(char* recs, uint32_t rec_bytes, int B, const uint32_t* agent_seeds, hipStream_t stream);
 extern "C" int bbx_launch_mark_reset(char* recs, uint32_t rec_bytes, int B, const uint8_t* mask, hipStream_t stream);
 
@@ -63,7 +65,7 @@ struct bbx_batch {
   int B = 0, device = 0, k = 1, nvars = 0, W = 2;
   int elim = 0, rewards = 0, sort_input = 0, sort_reducers = 1;
   bool fixed = false;
-  BbxLayout L{};
+  BbxLayout L{}, LL{};
   std::vector<std::unique_ptr<bbx::IdealGen>> gens;   // one per environment (one shared when fixed)
   uint32_t slot_words = 0, nslots = 0;
   std::vector<uint32_t> h_q;          // host mirror of the ideal queue
@@ -78,6 +80,11 @@ struct bbx_batch {
   int32_t* d_actions = nullptr; uint8_t* d_mask = nullptr; uint32_t* d_seeds = nullptr;
   int32_t* d_obs = nullptr; size_t obs_rows_cap = 0;
   BbxTraceRec* d_trace = nullptr; int trace_cap = 0;
+  BbxHdr* d_hdr = nullptr;            // compact header copy (bbx_gather_hdr_kernel)
+  // HIP-event timing of the step-kernel launches (bbx_timing)
+  bool timing = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_open;
+  double kernel_ms = 0.0; int kernel_launches = 0;
   std::vector<char> h_out;
   // the rollout in flight (so bbx_sync can finish environments that waited for ideals)
   BbxParams last{};
@@ -153,9 +160,12 @@ int fill_queues(bbx_batch* b) {
   return upload_queue(b);
 }
 
-int read_headers(bbx_batch* b) {
+int read_headers(bbx_batch* b, hipStream_t stream = 0) {
   b->h_hdr.resize(b->B);
-  HIPCHK(hipMemcpy2D(b->h_hdr.data(), sizeof(BbxHdr), b->d_recs, b->L.rec_bytes, sizeof(BbxHdr), b->B, hipMemcpyDeviceToHost));
+  int lrc = bbx_launch_gather_hdr(b->d_recs, b->L.rec_bytes, b->B, b->d_hdr, stream);
+  if (lrc) return fail(BBX_E_DEVICE, "gather launch failed: %s", hipGetErrorString((hipError_t)lrc));
+  HIPCHK(hipMemcpyAsync(b->h_hdr.data(), b->d_hdr, (size_t)b->B * sizeof(BbxHdr), hipMemcpyDeviceToHost, stream));
+  HIPCHK(hipStreamSynchronize(stream));
   for (int e = 0; e < b->B; e++) b->h_head[e] = b->h_hdr[e].q_head;
   return BBX_OK;
 }
@@ -174,35 +184,68 @@ const char* status_name(int s) {
 
 void fill_params(bbx_batch* b, BbxParams* p) {
   memset(p, 0, sizeof *p);
-  p->recs = b->d_recs; p->L = b->L; p->B = b->B;
+  p->recs = b->d_recs; p->L = b->L; p->LL = b->LL; p->B = b->B;
   p->q.words = b->d_q; p->q.env_stride = b->fixed ? 0 : b->nslots * b->slot_words; p->q.slot_words = b->slot_words;
   p->q.nslots = b->nslots; p->q.fixed = b->fixed ? 1 : 0; p->q.tail = b->d_tail;
   p->elim = b->elim; p->rewards_mode = b->rewards; p->sort_reducers = b->sort_reducers; p->k = b->k; p->nvars = b->nvars;
   p->trace = b->d_trace; p->trace_stride = b->trace_cap;
 }
 
+// enqueue the kernels of one logical launch: the LDS-staged pass (when the class allows) followed by the
+// HBM-resident pass that serves whatever the first could not hold; aux launches (nsteps == 0) use one kernel
+int enqueue(bbx_batch* b, const BbxParams& p0, bool resume, hipStream_t stream) {
+  BbxParams p = p0;
+  int kinds[2]; int nk = 0;
+  if (p.nsteps == 0 && !resume) kinds[nk++] = 2;
+  else { if (b->staged) kinds[nk++] = 1; kinds[nk++] = 0; }
+  for (int i = 0; i < nk; i++) {
+    if (resume) { p.set_budget = 0; p.pass = 1; }
+    else if (i > 0) { p.set_budget = 0; p.pass = 1; }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    const bool timed = b->timing && i == 0 && kinds[i] != 2;   // the primary (dominant) kernel of the sequence
+    if (timed) {
+      HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+      HIPCHK(hipEventRecord(e0, stream));
+    }
+    int lrc = bbx_launch_step(&p, kinds[i], b->envs_per_block, stream);
+    if (lrc) return fail(BBX_E_DEVICE, "kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
+    if (timed) { HIPCHK(hipEventRecord(e1, stream)); b->ev_open.push_back({e0, e1}); }
+  }
+  return BBX_OK;
+}
+
+int collect_events(bbx_batch* b) {
+  for (auto& ev : b->ev_open) {
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, ev.first, ev.second));
+    b->kernel_ms += ms; b->kernel_launches++;
+    (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second);
+  }
+  b->ev_open.clear();
+  return BBX_OK;
+}
+
 // wait for the launch in flight; serve environments that ran out of queued ideals; surface errors
 int finish(bbx_batch* b, hipStream_t stream) {
   for (int round = 0;; round++) {
-    HIPCHK(hipStreamSynchronize(stream));
-    int rc = read_headers(b);
+    int rc = read_headers(b, stream);
     if (rc) return rc;
-    bool starved = false;
+    rc = collect_events(b);
+    if (rc) return rc;
+    bool again = false;
     for (int e = 0; e < b->B; e++) {
       int st = b->h_hdr[e].status;
-      if (st == BBX_ST_STARVED) starved = true;
+      if (st == BBX_ST_STARVED || st == BBX_ST_SPILL) again = true;
       else if (st == BBX_ST_BAD_ACTION) return fail(BBX_E_ACTION, "environment %d: %s", e, status_name(st));
       else if (st != BBX_ST_OK) return fail(BBX_E_CAPACITY, "environment %d: %s (|G|=%d |P|=%d terms=%d)", e, status_name(st),
                                             b->h_hdr[e].nG, b->h_hdr[e].nP, b->h_hdr[e].arena_used);
     }
-    if (!starved) break;
+    if (!again) break;
     if (round > 100000) return fail(BBX_E_GENERATOR, "ideal queue starvation did not resolve");
     rc = fill_queues(b);
     if (rc) return rc;
-    BbxParams p = b->last;
-    p.set_budget = 0;          // continue the rollout where each environment stopped
-    int lrc = bbx_launch_step(&p, b->staged, b->envs_per_block, stream);
-    if (lrc) return fail(BBX_E_DEVICE, "kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
+    rc = enqueue(b, b->last, true, stream);   // continue the rollout where each environment stopped
+    if (rc) return rc;
   }
   b->in_flight = false;
   return BBX_OK;
@@ -214,9 +257,7 @@ int launch(bbx_batch* b, BbxParams& p, hipStream_t stream) {
   b->last = p;
   b->last_stream = stream;
   b->in_flight = true;
-  int lrc = bbx_launch_step(&p, b->staged, b->envs_per_block, stream);
-  if (lrc) return fail(BBX_E_DEVICE, "kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
-  return BBX_OK;
+  return enqueue(b, p, false, stream);
 }
 
 int copy_out(bbx_batch* b, double* rewards, uint8_t* dones, int32_t* rows) {
@@ -264,12 +305,21 @@ int create_common(std::unique_ptr<bbx::IdealGen> proto, int nvars_obs, int elimi
     if (!c.arena_terms) c.arena_terms = 1 << 20; if (!c.max_poly_terms) c.max_poly_terms = 8192;
   } else if (binomial) {
     if (!c.max_basis) c.max_basis = b->W == 2 ? 512 : 4096; if (!c.max_pairs) c.max_pairs = b->W == 2 ? 2048 : 16384;
-    if (!c.arena_terms) c.arena_terms = 2 * c.max_basis; if (!c.max_poly_terms) c.max_poly_terms = 8;
+    if (!c.arena_terms) c.arena_terms = 2 * c.max_basis + 16; if (!c.max_poly_terms) c.max_poly_terms = 8;
   } else {
     if (!c.max_basis) c.max_basis = 2048; if (!c.max_pairs) c.max_pairs = 8192;
     if (!c.arena_terms) c.arena_terms = 1 << 18; if (!c.max_poly_terms) c.max_poly_terms = 4096;
   }
   if (!c.queue_slots) c.queue_slots = 8;
+  // LDS-resident class: small binomial environments work out of LDS for the whole launch; anything that
+  // outgrows it continues in the HBM-resident pass of the same launch sequence
+  b->staged = 0;
+  if (binomial && b->W == 2 && c.lds_max_basis >= 0 && !getenv("BBX_NO_STAGE")) {
+    int lg = c.lds_max_basis ? c.lds_max_basis : 128;
+    lg = std::min((lg + 15) & ~15, c.max_basis);       // the working copy never exceeds the HBM record
+    b->LL = make_layout(b->W, lg, std::min(2 * lg, c.max_pairs), std::min(2 * lg + 16, c.arena_terms), c.max_poly_terms);
+    b->staged = 1;
+  }
   if (c.max_basis > 65535 || c.max_poly_terms > 65535 || c.max_basis < 2 || c.max_pairs < 2 || c.max_poly_terms < 4 || c.queue_slots < 1)
     return fail(BBX_E_ARG, "capacities out of range");
   b->L = make_layout(b->W, c.max_basis, c.max_pairs, c.arena_terms, c.max_poly_terms);
@@ -299,6 +349,7 @@ int create_common(std::unique_ptr<bbx::IdealGen> proto, int nvars_obs, int elimi
   HIPCHK(hipMalloc((void**)&b->d_actions, (size_t)batch * sizeof(int32_t)));
   HIPCHK(hipMalloc((void**)&b->d_mask, (size_t)batch));
   HIPCHK(hipMalloc((void**)&b->d_seeds, (size_t)batch * sizeof(uint32_t)));
+  HIPCHK(hipMalloc((void**)&b->d_hdr, (size_t)batch * sizeof(BbxHdr)));
   int lrc = bbx_launch_init(b->d_recs, b->L.rec_bytes, batch, nullptr, 0);
   if (lrc) return fail(BBX_E_DEVICE, "init launch failed: %s", hipGetErrorString((hipError_t)lrc));
   lrc = bbx_launch_mark_reset(b->d_recs, b->L.rec_bytes, batch, nullptr, 0);
@@ -348,7 +399,7 @@ void bbx_destroy(bbx_batch* b) {
   if (!b) return;
   (void)hipSetDevice(b->device);
   (void)hipDeviceSynchronize();
-  void* bufs[] = {b->d_recs, b->d_q, b->d_tail, b->d_out, b->d_actions, b->d_mask, b->d_seeds, b->d_obs, b->d_trace};
+  void* bufs[] = {b->d_recs, b->d_q, b->d_tail, b->d_out, b->d_actions, b->d_mask, b->d_seeds, b->d_obs, b->d_trace, b->d_hdr};
   for (void* p : bufs) (void)hipFree(p);
   delete b;
 }
@@ -360,7 +411,7 @@ int bbx_copy(const bbx_batch* s, bbx_batch** out) {
   auto b = std::make_unique<bbx_batch>();
   b->B = s->B; b->device = s->device; b->k = s->k; b->nvars = s->nvars; b->W = s->W;
   b->elim = s->elim; b->rewards = s->rewards; b->sort_input = s->sort_input; b->sort_reducers = s->sort_reducers;
-  b->fixed = s->fixed; b->L = s->L; b->slot_words = s->slot_words; b->nslots = s->nslots;
+  b->fixed = s->fixed; b->L = s->L; b->LL = s->LL; b->slot_words = s->slot_words; b->nslots = s->nslots;
   b->h_q = s->h_q; b->h_tail = s->h_tail; b->h_head = s->h_head; b->q_dirty = true;
   b->staged = s->staged; b->envs_per_block = s->envs_per_block;
   for (auto& g : s->gens) b->gens.push_back(g->clone());
@@ -374,6 +425,7 @@ int bbx_copy(const bbx_batch* s, bbx_batch** out) {
   HIPCHK(hipMalloc((void**)&b->d_actions, (size_t)batch * sizeof(int32_t)));
   HIPCHK(hipMalloc((void**)&b->d_mask, (size_t)batch));
   HIPCHK(hipMalloc((void**)&b->d_seeds, (size_t)batch * sizeof(uint32_t)));
+  HIPCHK(hipMalloc((void**)&b->d_hdr, (size_t)batch * sizeof(BbxHdr)));
   int rc = upload_queue(b.get());
   if (rc) return rc;
   *out = b.release();
@@ -458,10 +510,11 @@ int bbx_step_device(bbx_batch* b, const int32_t* d_actions, double* d_rewards, u
 }
 
 int bbx_rollout_device(bbx_batch* b, int agent, int nsteps, int auto_reset, double* d_rewards, uint8_t* d_dones,
-                       int32_t* d_rows, int32_t* d_obs, int obs_rows, int obs_fill, void* stream) {
+                       int32_t* d_rows, int32_t* d_obs, int obs_rows, int obs_fill, int obs_every_step, void* stream) {
   if (!b || nsteps < 0 || agent < BBX_RANDOM_HASH || agent > BBX_FIRST) return fail(BBX_E_ARG, "bad rollout arguments");
   HIPCHK(hipSetDevice(b->device));
   BbxParams p; fill_params(b, &p);
+  p.obs_every_step = obs_every_step ? 1 : 0;
   p.nsteps = nsteps; p.set_budget = 1; p.agent = agent; p.auto_reset = auto_reset ? 1 : 0;
   p.rewards = d_rewards; p.dones = d_dones; p.rows = d_rows; p.obs = d_obs; p.obs_rows = obs_rows; p.obs_fill = obs_fill;
   return launch(b, p, (hipStream_t)stream);
@@ -472,6 +525,15 @@ int bbx_sync(bbx_batch* b) {
   HIPCHK(hipSetDevice(b->device));
   if (!b->in_flight) { HIPCHK(hipDeviceSynchronize()); return BBX_OK; }
   return finish(b, b->last_stream);
+}
+
+int bbx_timing(bbx_batch* b, int enable, double* kernel_ms, int32_t* launches) {
+  if (!b) return fail(BBX_E_ARG, "null argument");
+  if (kernel_ms) *kernel_ms = b->kernel_ms;
+  if (launches) *launches = b->kernel_launches;
+  b->kernel_ms = 0.0; b->kernel_launches = 0;
+  b->timing = enable != 0;
+  return BBX_OK;
 }
 
 int bbx_obs(bbx_batch* b, int32_t* out, int max_rows, int fill) {

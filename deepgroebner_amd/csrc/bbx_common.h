@@ -41,6 +41,8 @@ enum {
   BBX_ST_DEG_OVERFLOW = 5,  // total degree above 65535
   BBX_ST_STARVED = 6,       // ideal queue empty: the environment waits for the host to refill
   BBX_ST_BAD_ACTION = 7,    // action index outside [0, |P|)
+  BBX_ST_SPILL = 8,         // transient: the state outgrew the LDS-resident class; the HBM-resident pass of the
+                            // same launch sequence continues this environment
 };
 
 struct BbxHdr {             // 128 bytes
@@ -89,7 +91,8 @@ enum { BBX_REW_ADDITIONS = 0, BBX_REW_REDUCTIONS = 1 };
 
 struct BbxParams {
   char* recs;
-  BbxLayout L;
+  BbxLayout L;              // layout of the records in HBM
+  BbxLayout LL;             // layout of the LDS-resident working copy (staged kernel only)
   BbxQueue q;
   int32_t B;
   int32_t nsteps;
@@ -104,6 +107,9 @@ struct BbxParams {
   int32_t* obs;             // [B, obs_rows, 2*n*k] int32 or null
   int32_t obs_rows;         // row capacity per environment in obs
   int32_t obs_fill;         // 1: pad rows [nP, obs_rows) with -1
+  int32_t obs_every_step;   // 1: materialise the observation after every step (what a policy consumes),
+                            // 0: only for the state the caller sees when the launch ends
+  int32_t pass;             // 0: primary launch; 1: follow-up launch serving only environments with work left
   BbxTraceRec* trace;       // [B, trace_stride] or null
   int32_t trace_stride;
 };

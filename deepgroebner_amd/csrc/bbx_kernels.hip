@@ -334,7 +334,7 @@ __device__ bool wave_add_poly(Env<W>& e, const BbxLayout& L, int& nG, int& nP, i
 // BuchbergerEnv::reset (buchberger.cpp:299-315) from the next host-generated ideal(s) of the queue.
 // Returns false if the queue ran dry (status STARVED) or on overflow.
 template <int W>
-__device__ bool wave_reset(Env<W>& e, const BbxParams& p, int env, int& nG, int& nP, int& arena_used, int& q_head, int* status) {
+__device__ bool wave_reset(Env<W>& e, const BbxParams& p, const BbxLayout& L, int env, int& nG, int& nP, int& arena_used, int& q_head, int* status) {
   const int lane = lane_id();
   for (;;) {
     const uint32_t* slot;
@@ -351,7 +351,7 @@ __device__ bool wave_reset(Env<W>& e, const BbxParams& p, int env, int& nG, int&
     for (int f = 0; f < npoly; f++) {
       const int n = (int)w[0], sugar = (int)w[1];
       w += 2;
-      if (n > (int)p.L.maxT) { *status = BBX_ST_POLY_TOO_LONG; return false; }
+      if (n > (int)L.maxT) { *status = BBX_ST_POLY_TOO_LONG; return false; }
       for (int t = lane; t < n; t += WAVE) {
         const uint32_t* tw = w + (size_t)t * (1 + W);
         Mono<W> mm;
@@ -360,7 +360,7 @@ __device__ bool wave_reset(Env<W>& e, const BbxParams& p, int env, int& nG, int&
         sm[t] = mm; sc[t] = (uint16_t)tw[0];
       }
       wave_sync();
-      if (!wave_add_poly<W>(e, p.L, nG, nP, arena_used, sm, sc, n, sugar, p.elim, p.sort_reducers, status)) return false;
+      if (!wave_add_poly<W>(e, L, nG, nP, arena_used, sm, sc, n, sugar, p.elim, p.sort_reducers, status)) return false;
       w += (size_t)n * (1 + W);
     }
     if (!p.q.fixed) q_head++;
@@ -371,7 +371,7 @@ __device__ bool wave_reset(Env<W>& e, const BbxParams& p, int env, int& nG, int&
 
 // lead-monomial observation, buchberger.cpp:354-370 + 391-394 / 403-406: row r = first k monomials of
 // G[i] || first k of G[j] for the r-th pair, n exponents each, zero padded
-template <int W>
+template <int W, bool HASH = false>
 __device__ uint64_t wave_obs(const Env<W>& e, const BbxParams& p, int env, int nP, bool write, bool want_hash) {
   const int lane = lane_id();
   const int n = p.nvars, k = p.k;
@@ -391,13 +391,13 @@ __device__ uint64_t wave_obs(const Env<W>& e, const BbxParams& p, int env, int n
     for (int v = 0; v < n; v++) {
       uint32_t x = m_exp(mm, v);
       if (out) out[base + v] = (int32_t)x;
-      if (want_hash) h += bbx_mix64((uint64_t)(base + v), x);
+      if (HASH && want_hash) h += bbx_mix64((uint64_t)(base + v), x);
     }
   }
   if (out && p.obs_fill) {
     for (int idx = rows * cols + lane; idx < p.obs_rows * cols; idx += WAVE) out[idx] = -1;
   }
-  return want_hash ? wave_sum64(h) : 0;
+  return (HASH && want_hash) ? wave_sum64(h) : 0;
 }
 
 template <int W>
@@ -424,37 +424,57 @@ __device__ uint64_t wave_poly_hash(const Env<W>& e, int g) {
 }
 
 // ------------------------------------------------------------------ the step kernel
-template <int W, bool STAGED>
-__global__ __launch_bounds__(256) void bbx_step_kernel(BbxParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+// copy the live prefix of every persistent array between the HBM record and the LDS working copy
+template <int W>
+__device__ void stage_copy(const Env<W>& dst, const Env<W>& src, int nG, int nP, int nT) {
   const int lane = lane_id();
-  const int wave_in_block = threadIdx.x / WAVE;
+  for (int i = lane; i < nG; i += WAVE) {
+    dst.lm[i] = src.lm[i]; dst.slm[i] = src.slm[i]; dst.sidx[i] = src.sidx[i]; dst.poff[i] = src.poff[i];
+    dst.plen[i] = src.plen[i]; dst.psug[i] = src.psug[i]; dst.pinv[i] = src.pinv[i];
+  }
+  for (int i = lane; i < nP; i += WAVE) dst.pairs[i] = src.pairs[i];
+  for (int i = lane; i < nT; i += WAVE) { dst.am[i] = src.am[i]; dst.ac[i] = src.ac[i]; }
+}
+
+template <int W, bool STAGED, bool TRACE>
+__device__ __forceinline__ void step_body(const BbxParams& p, char* smem) {
+  const int lane = lane_id();
+  const int wave_in_block = uni((int)(threadIdx.x / WAVE));   // provably wave-uniform: record addresses live in SGPRs
   const int env = blockIdx.x * (blockDim.x / WAVE) + wave_in_block;
   if (env >= p.B) return;                       // whole wave exits together
   char* grec = p.recs + (size_t)env * p.L.rec_bytes;
-  char* rec = grec;
-  if (STAGED) {
-    rec = smem + (size_t)wave_in_block * p.L.rec_bytes;
-    // whole-record copy, 16 B per lane per trip (records are tiny in the staged class)
-    const uint4* src = (const uint4*)grec; uint4* dst = (uint4*)rec;
-    for (uint32_t i = lane; i < p.L.rec_bytes / 16; i += WAVE) dst[i] = src[i];
-    wave_sync();
-  }
-  Env<W> e = env_view<W>(rec, p.L);
-  const BbxLayout& L = p.L;
+  BbxHdr* ghdr = (BbxHdr*)grec;
+  const BbxLayout& L = STAGED ? p.LL : p.L;      // the layout this kernel works in
 
-  int nG = uni(e.hdr->nG), nP = uni(e.hdr->nP), arena_used = uni(e.hdr->arena_used);
-  int status = uni(e.hdr->status), need_reset = uni(e.hdr->need_reset), q_head = uni(e.hdr->q_head);
-  int t_agent = uni(e.hdr->t), episode_steps = uni(e.hdr->episode_steps);
-  int episodes = uni(e.hdr->episodes), zero_red = uni(e.hdr->zero_reductions);
-  long long total_steps = e.hdr->total_steps, total_adds = e.hdr->total_additions, alg_bytes = e.hdr->alg_bytes;
-  const uint32_t agent_seed = e.hdr->agent_seed;
-  if (status == BBX_ST_STARVED) status = BBX_ST_OK;   // the host has refilled the queue
-  int budget = uni(e.hdr->budget), rollout_pos = uni(e.hdr->rollout_pos);
-  if (p.set_budget) { budget = p.nsteps; rollout_pos = 0; }
-  int steps_done = 0, done_last = 0;
+  int nG = uni(ghdr->nG), nP = uni(ghdr->nP), arena_used = uni(ghdr->arena_used);
+  int status = uni(ghdr->status), need_reset = uni(ghdr->need_reset), q_head = uni(ghdr->q_head);
+  int t_agent = uni(ghdr->t), episode_steps = uni(ghdr->episode_steps);
+  int episodes = uni(ghdr->episodes), zero_red = uni(ghdr->zero_reductions);
+  long long total_steps = ghdr->total_steps, total_adds = ghdr->total_additions, alg_bytes = ghdr->alg_bytes;
+  const uint32_t agent_seed = uni((int)ghdr->agent_seed);
+  int budget = uni(ghdr->budget), rollout_pos = uni(ghdr->rollout_pos);
+  int done_last = uni(ghdr->done_last);
+  if (status == BBX_ST_STARVED || status == BBX_ST_SPILL) status = BBX_ST_OK;   // transient states: try again
+  if (p.set_budget) { budget = p.nsteps; rollout_pos = 0; done_last = 0; }
+  if (p.pass == 1 && !(status == BBX_ST_OK && (need_reset || (budget > 0 && nP > 0)))) return;  // nothing left to do here
+
+  Env<W> ge = env_view<W>(grec, p.L);
+  Env<W> e = ge;
+  bool staged_in = false;
+  if (STAGED) {
+    if (status == BBX_ST_OK) {
+      if (nG > (int)L.maxG || nP > (int)L.maxP || arena_used > (int)L.arena) status = BBX_ST_SPILL;
+      else {
+        e = env_view<W>(smem + (size_t)wave_in_block * L.rec_bytes, L);
+        stage_copy<W>(e, ge, nG, nP, arena_used);
+        staged_in = true;
+        wave_sync();
+      }
+    }
+  }
+  int steps_done = 0;
   double last_reward = 0.0;
-  const bool tracing = p.trace != nullptr;
+  const bool tracing = TRACE && p.trace != nullptr;   // hashing code exists only in the TRACE instantiations
 
   // scratch polynomials
   const int maxT = (int)L.maxT;
@@ -466,11 +486,23 @@ __global__ __launch_bounds__(256) void bbx_step_kernel(BbxParams p) {
   for (;;) {
     if (status != BBX_ST_OK) break;
     if (need_reset) {                           // also serves a reset left pending by the last step
-      if (!wave_reset<W>(e, p, env, nG, nP, arena_used, q_head, &status)) break;
+      if (!wave_reset<W>(e, p, L, env, nG, nP, arena_used, q_head, &status)) {
+        // the reset restarts from the same queued ideal: in the LDS class a capacity miss is only a spill
+        if (STAGED && (status == BBX_ST_G_FULL || status == BBX_ST_P_FULL || status == BBX_ST_ARENA_FULL)) {
+          status = BBX_ST_SPILL; nG = 0; nP = 0; arena_used = 0;
+        }
+        break;
+      }
       need_reset = 0; episode_steps = 0;
     }
     if (budget <= 0) break;
     if (nP == 0) break;                         // finished episode and no auto-reset: nothing to do
+    // headroom for the worst case of this step, checked BEFORE anything is modified so that a miss leaves a
+    // consistent state: one new basis element of <= maxT terms and at most |G| new pairs
+    if (nG + 1 > (int)L.maxG || nP - 1 + nG > (int)L.maxP || arena_used + maxT > (int)L.arena) {
+      status = STAGED ? BBX_ST_SPILL : (nG + 1 > (int)L.maxG ? BBX_ST_G_FULL : (nP - 1 + nG > (int)L.maxP ? BBX_ST_P_FULL : BBX_ST_ARENA_FULL));
+      break;
+    }
 
     // ---- choose the pair ------------------------------------------------------------------
     int action;
@@ -488,7 +520,7 @@ __global__ __launch_bounds__(256) void bbx_step_kernel(BbxParams p) {
     }
     action = uni(action);
     if (action < 0 || action >= nP) { status = BBX_ST_BAD_ACTION; break; }
-    const uint32_t pr = e.pairs[action];
+    const uint32_t pr = (uint32_t)uni((int)e.pairs[action]);
     const int gi = pr & 0xffffu, gj = pr >> 16;
     // P.erase(remove(action))  buchberger.cpp:319 — stable
     for (int base = action; base < nP - 1; base += WAVE) {
@@ -507,13 +539,14 @@ __global__ __launch_bounds__(256) void bbx_step_kernel(BbxParams p) {
     {
       const Mono<W> lmi = e.lm[gi], lmj = e.lm[gj];
       const Mono<W> gamma = m_lcm(lmi, lmj);
+      const int offi = uni((int)e.poff[gi]), offj = uni((int)e.poff[gj]);
       PView<W> A, Bv;
-      A.m = e.am + e.poff[gi] + 1; A.c = e.ac + e.poff[gi] + 1; A.n = (int)e.plen[gi] - 1;
-      A.shift = m_div(gamma, lmi); A.scale = e.pinv[gi];
-      Bv.m = e.am + e.poff[gj] + 1; Bv.c = e.ac + e.poff[gj] + 1; Bv.n = (int)e.plen[gj] - 1;
-      Bv.shift = m_div(gamma, lmj); Bv.scale = negmod(e.pinv[gj]);
-      int si = (int)e.psug[gi] + (int)m_deg(A.shift), sj = (int)e.psug[gj] + (int)m_deg(Bv.shift);
-      hsug = si > sj ? si : sj;
+      A.m = e.am + offi + 1; A.c = e.ac + offi + 1; A.n = uni((int)e.plen[gi]) - 1;
+      A.shift = m_div(gamma, lmi); A.scale = (uint32_t)uni((int)e.pinv[gi]);
+      Bv.m = e.am + offj + 1; Bv.c = e.ac + offj + 1; Bv.n = uni((int)e.plen[gj]) - 1;
+      Bv.shift = m_div(gamma, lmj); Bv.scale = negmod((uint32_t)uni((int)e.pinv[gj]));
+      int si = uni((int)e.psug[gi]) + (int)m_deg(A.shift), sj = uni((int)e.psug[gj]) + (int)m_deg(Bv.shift);
+      hsug = uni(si > sj ? si : sj);
       if (hsug > 65535) { status = BBX_ST_DEG_OVERFLOW; break; }
       if (A.n + Bv.n > 2 * maxT) { status = BBX_ST_POLY_TOO_LONG; break; }
       hn = wave_merge<W>(A, Bv, tm, tc, hm, hc, maxT);
@@ -534,14 +567,15 @@ __global__ __launch_bounds__(256) void bbx_step_kernel(BbxParams p) {
         if (mask) { found = base + __builtin_ctzll(mask); break; }
       }
       if (found >= 0) {                         // h <- h - (LT h / LT f) f     (34-36)
-        const int g = e.sidx[found];
-        const uint32_t c = mulmod(hc[hoff], e.pinv[g]);
+        const int g = uni((int)e.sidx[found]);
+        const uint32_t c = mulmod((uint32_t)uni((int)hc[hoff]), (uint32_t)uni((int)e.pinv[g]));
+        const int offg = uni((int)e.poff[g]);
         PView<W> A, Bv;
         A.m = hm + hoff + 1; A.c = hc + hoff + 1; A.n = hn - hoff - 1; A.shift = m_zero<W>(); A.scale = 1;
-        Bv.m = e.am + e.poff[g] + 1; Bv.c = e.ac + e.poff[g] + 1; Bv.n = (int)e.plen[g] - 1;
+        Bv.m = e.am + offg + 1; Bv.c = e.ac + offg + 1; Bv.n = uni((int)e.plen[g]) - 1;
         Bv.shift = m_div(lmh, e.lm[g]); Bv.scale = negmod(c);
-        int fs = (int)e.psug[g] + (int)m_deg(Bv.shift);
-        hsug = fs > hsug ? fs : hsug;
+        int fs = uni((int)e.psug[g]) + (int)m_deg(Bv.shift);
+        hsug = uni(fs > hsug ? fs : hsug);
         if (hsug > 65535) { status = BBX_ST_DEG_OVERFLOW; overflow = true; break; }
         if (A.n + Bv.n > 2 * maxT) { status = BBX_ST_POLY_TOO_LONG; overflow = true; break; }
         Mono<W>* nm = (hm == hm0) ? hm1 : hm0; uint16_t* nc = (hc == hc0) ? hc1 : hc0;
@@ -554,7 +588,7 @@ __global__ __launch_bounds__(256) void bbx_step_kernel(BbxParams p) {
         if (rn >= maxT) { status = BBX_ST_POLY_TOO_LONG; overflow = true; break; }
         alg_bytes += 8LL * nG + 12LL * (2 * (hn - hoff) - 1);
         if (lane == 0) { rm[rn] = lmh; rc[rn] = hc[hoff]; }
-        int d = (int)m_deg(lmh);
+        int d = uni((int)m_deg(lmh));
         rsug = d > rsug ? d : rsug;
         rn++; hoff++;
       }
@@ -575,9 +609,11 @@ __global__ __launch_bounds__(256) void bbx_step_kernel(BbxParams p) {
     total_steps++; total_adds += 1 + nsteps_red; t_agent++; episode_steps++; steps_done++;
     const bool done = nP == 0;
 
+    // ---- the observation a policy would consume after this step ---------------------------------
+    if (p.obs_every_step && p.obs) wave_obs<W>(e, p, env, nP, true, false);
     // ---- parity trace (tests): hashes of the post-step observation / pair set / new element ---
-    if (tracing) {
-      uint64_t oh = wave_obs<W>(e, p, env, nP, false, true);
+    if (TRACE && tracing) {
+      uint64_t oh = wave_obs<W, true>(e, p, env, nP, false, true);
       uint64_t ph = wave_pairs_hash<W>(e, nP);
       uint64_t nh = nG > nG_before ? wave_poly_hash<W>(e, nG - 1) : 0;
       if (lane == 0) {
@@ -594,24 +630,39 @@ __global__ __launch_bounds__(256) void bbx_step_kernel(BbxParams p) {
     }
   }
 
+  // an environment that must continue in the follow-up pass reports nothing yet
+  const bool handoff = status == BBX_ST_SPILL;
   // ---- observation of the state the caller sees next ------------------------------------------
   if (p.obs && status == BBX_ST_OK) wave_obs<W>(e, p, env, nP, true, false);
 
+  if (STAGED && staged_in) {
+    wave_sync();
+    stage_copy<W>(ge, e, nG, nP, arena_used);
+  }
   if (lane == 0) {
-    BbxHdr* h = e.hdr;
+    BbxHdr* h = ghdr;
     h->nG = nG; h->nP = nP; h->arena_used = arena_used; h->status = status; h->need_reset = need_reset;
     h->q_head = q_head; h->t = t_agent; h->episode_steps = episode_steps; h->total_steps = total_steps;
     h->total_additions = total_adds; h->episodes = episodes; h->zero_reductions = zero_red; h->steps_done = steps_done;
     h->budget = budget; h->rollout_pos = rollout_pos; h->done_last = done_last; h->alg_bytes = alg_bytes;
-    if (p.rewards) p.rewards[env] = last_reward;
-    if (p.dones) p.dones[env] = (uint8_t)((done_last || (nP == 0 && !need_reset)) ? 1 : 0);
-    if (p.rows) p.rows[env] = nP;
+    if (!handoff) {
+      if (p.rewards && (steps_done > 0 || p.pass == 0)) p.rewards[env] = last_reward;
+      if (p.dones) p.dones[env] = (uint8_t)((done_last || (nP == 0 && !need_reset)) ? 1 : 0);
+      if (p.rows) p.rows[env] = nP;
+    }
   }
-  if (STAGED) {
-    wave_sync();
-    const uint4* src = (const uint4*)rec; uint4* dst = (uint4*)grec;
-    for (uint32_t i = lane; i < p.L.rec_bytes / 16; i += WAVE) dst[i] = src[i];
-  }
+}
+
+template <int W, bool STAGED, bool TRACE>
+__global__ __launch_bounds__(256) void bbx_step_kernel(BbxParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  step_body<W, STAGED, TRACE>(p, smem);
+}
+// the same body under its own name for launches that only reset / refresh observations (nsteps == 0), so that
+// profiles of bbx_step_kernel contain step launches only
+template <int W>
+__global__ __launch_bounds__(256) void bbx_aux_kernel(BbxParams p) {
+  step_body<W, false, false>(p, nullptr);
 }
 
 // ------------------------------------------------------------------ housekeeping kernels
@@ -641,24 +692,40 @@ extern "C" int bbx_launch_mark_reset(char* recs, uint32_t rec_bytes, int B, cons
   return (int)hipGetLastError();
 }
 
+// compact copy of every header so the host reads them with one contiguous transfer
+__global__ void bbx_gather_hdr_kernel(const char* recs, uint32_t rec_bytes, int B, BbxHdr* out) {
+  int env = blockIdx.x * blockDim.x + threadIdx.x;
+  if (env >= B) return;
+  out[env] = *(const BbxHdr*)(recs + (size_t)env * rec_bytes);
+}
+extern "C" int bbx_launch_gather_hdr(const char* recs, uint32_t rec_bytes, int B, BbxHdr* out, hipStream_t stream) {
+  hipLaunchKernelGGL(bbx_gather_hdr_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, recs, rec_bytes, B, out);
+  return (int)hipGetLastError();
+}
+
 // ------------------------------------------------------------------ host-callable launcher
-extern "C" int bbx_launch_step(const BbxParams* p, int staged, int envs_per_block, hipStream_t stream) {
+// kind: 0 = HBM-resident step kernel, 1 = LDS-staged step kernel, 2 = aux (reset / observation only)
+template <int W>
+static int launch_w(const BbxParams* p, int kind, int blocks, int threads, size_t lds, hipStream_t stream) {
+  const bool trace = p->trace != nullptr;
+  if (kind == 2) { hipLaunchKernelGGL((bbx_aux_kernel<W>), dim3(blocks), dim3(threads), 0, stream, *p); return 0; }
+  if (kind == 1) {
+    const void* fn = trace ? (const void*)bbx_step_kernel<W, true, true> : (const void*)bbx_step_kernel<W, true, false>;
+    hipError_t err = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (err != hipSuccess) return (int)err;
+    if (trace) hipLaunchKernelGGL((bbx_step_kernel<W, true, true>), dim3(blocks), dim3(threads), lds, stream, *p);
+    else hipLaunchKernelGGL((bbx_step_kernel<W, true, false>), dim3(blocks), dim3(threads), lds, stream, *p);
+    return 0;
+  }
+  if (trace) hipLaunchKernelGGL((bbx_step_kernel<W, false, true>), dim3(blocks), dim3(threads), 0, stream, *p);
+  else hipLaunchKernelGGL((bbx_step_kernel<W, false, false>), dim3(blocks), dim3(threads), 0, stream, *p);
+  return 0;
+}
+extern "C" int bbx_launch_step(const BbxParams* p, int kind, int envs_per_block, hipStream_t stream) {
   const int threads = envs_per_block * WAVE;
   const int blocks = (p->B + envs_per_block - 1) / envs_per_block;
-  const size_t lds = staged ? (size_t)envs_per_block * p->L.rec_bytes : 0;
-  hipError_t err = hipSuccess;
-  if (p->L.W == 2) {
-    if (staged) {
-      err = hipFuncSetAttribute((const void*)bbx_step_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (err != hipSuccess) return (int)err;
-      hipLaunchKernelGGL((bbx_step_kernel<2, true>), dim3(blocks), dim3(threads), lds, stream, *p);
-    } else hipLaunchKernelGGL((bbx_step_kernel<2, false>), dim3(blocks), dim3(threads), 0, stream, *p);
-  } else {
-    if (staged) {
-      err = hipFuncSetAttribute((const void*)bbx_step_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (err != hipSuccess) return (int)err;
-      hipLaunchKernelGGL((bbx_step_kernel<4, true>), dim3(blocks), dim3(threads), lds, stream, *p);
-    } else hipLaunchKernelGGL((bbx_step_kernel<4, false>), dim3(blocks), dim3(threads), 0, stream, *p);
-  }
+  const size_t lds = kind == 1 ? (size_t)envs_per_block * p->LL.rec_bytes : 0;
+  int rc = p->L.W == 2 ? launch_w<2>(p, kind, blocks, threads, lds, stream) : launch_w<4>(p, kind, blocks, threads, lds, stream);
+  if (rc) return rc;
   return (int)hipGetLastError();
 }

@@ -46,6 +46,8 @@ typedef struct bbx_caps {
   int32_t arena_terms;    /* total terms of all basis polynomials */
   int32_t max_poly_terms; /* longest intermediate polynomial during spoly/reduce (<= 65535) */
   int32_t queue_slots;    /* pre-generated ideals buffered per environment for device-side resets */
+  int32_t lds_max_basis;  /* |G| up to which a small (3-variable binomial) environment is kept LDS-resident
+                             for a whole launch; 0 = default (128), negative = never */
 } bbx_caps;
 
 /* One record per environment per step of a traced rollout (parity tests). */
@@ -109,11 +111,17 @@ int bbx_value(bbx_batch* b, int idx, const char* strategy, double gamma, double*
  * (hipStream_t passed as void*; NULL = the default stream).  obs may be NULL. */
 int bbx_step_device(bbx_batch* b, const int32_t* d_actions, double* d_rewards, uint8_t* d_dones, int32_t* d_rows,
                     int32_t* d_obs, int obs_rows, int obs_fill, void* stream);
+/* obs_every_step != 0 materialises the observation in d_obs after every step (what a device-side policy
+ * would consume), otherwise only the state at the end of the rollout is written */
 int bbx_rollout_device(bbx_batch* b, int agent, int nsteps, int auto_reset, double* d_rewards, uint8_t* d_dones,
-                       int32_t* d_rows, int32_t* d_obs, int obs_rows, int obs_fill, void* stream);
+                       int32_t* d_rows, int32_t* d_obs, int obs_rows, int obs_fill, int obs_every_step, void* stream);
 /* after asynchronous rollouts: waits, refills the ideal queues, finishes environments that had to
  * wait for ideals; returns BBX_E_CAPACITY etc. if any environment failed */
 int bbx_sync(bbx_batch* b);
+
+/* HIP-event timing of the step-kernel launches on their own stream: returns the milliseconds and launch
+ * count accumulated since the previous call, then enables/disables further collection */
+int bbx_timing(bbx_batch* b, int enable, double* kernel_ms, int32_t* launches);
 
 /* ---- introspection (tests, checkpoints) -------------------------------------------------------- */
 /* per environment 8 values: total_steps, total_additions, episodes, zero_reductions, status,

@@ -34,13 +34,21 @@ def compare_with_trace(env, e, want, T, label):
     assert np.array_equal(np.concatenate(words) if words else np.zeros(0, np.int32), want["final_basis"]), label
 
 
+# residency classes of the step kernel: default (LDS-resident where the class allows), HBM-resident only,
+# and an LDS class so small that environments keep spilling into the HBM-resident follow-up pass
+RESIDENCY = {"default": None, "hbm": {"lds_max_basis": -1}, "spill": {"lds_max_basis": 16}}
+
+
+@pytest.mark.parametrize("residency", sorted(RESIDENCY))
 @pytest.mark.parametrize("name", trace_names())
-def test_golden_trace(name):
+def test_golden_trace(name, residency):
     m = meta()["traces"][name]
+    if residency != "default" and not (m["dist"].startswith("3-") and m["dist"].count("-") >= 3 and "." not in m["dist"]):
+        pytest.skip("only 3-variable binomial distributions have an LDS-resident class")
     gold = load_trace(name)
     B = m["nenvs"]
     T = len(gold["e0_action"])
-    env = make_env(m, B)
+    env = make_env(m, B, caps=RESIDENCY[residency])
     env.seed(np.arange(B) + m["seed0"])
     env.seed_agent(np.arange(B) + m["agent_seed0"])
     env.trace_enable(max(T, 1))
@@ -172,3 +180,38 @@ def test_algorithmic_byte_counter_matches_oracle():
             if o.nP == 0:
                 o.reset()
         assert (st[e, 0], st[e, 1], st[e, 6]) == (T, adds, total)
+
+
+def _state_words(basis, pairs, order):
+    words = [poly_words(c, x) for c, x in basis]
+    return np.concatenate(words + [np.asarray(pairs, np.int32).ravel(), np.asarray(order, np.int32)])
+
+
+def test_full_size_headline_untraced_vs_oracle():
+    """BASELINE configs[1] at full size (B=4096, T=256, the bench workload) on the production
+    (non-tracing) kernel: per environment the step/addition/byte counters and the complete final
+    state (basis term for term, pair list, reducer order) must equal the oracle's."""
+    from deepgroebner_amd import VecLeadMonomialsEnv
+    bo = ffi.load("bo")
+    B, T, k = 4096, 256, 2
+    env = VecLeadMonomialsEnv("3-20-10-weighted", batch=B, k=k, caps={"queue_slots": T // 4 + 16})
+    env.seed(np.arange(B) + 1000); env.seed_agent(np.arange(B)); env.reset()
+    env.rollout("random", T, auto_reset=True)
+    st = env.stats()
+    assert (st[:, 0] == T).all() and (st[:, 4] == 0).all()
+    check_full = set(range(0, B, 64)) | {B - 1}
+    for e in range(B):
+        o = bo.env("3-20-10-weighted"); o.seed(1000 + e); o.reset()
+        adds = total = 0
+        for t in range(T):
+            r = o.step(ffi.agent_hash(e, t) % o.nP)
+            adds += int(-r)
+            total += o.last_step_bytes() + 4 * o.nP * 2 * 3 * k
+            if o.nP == 0:
+                o.reset()
+        assert (st[e, 1], st[e, 6], st[e, 7]) == (adds, total, o.nG), e
+        assert int(env.rows[e]) == o.nP, e
+        if e in check_full:
+            basis, pairs, order = env.state(e)
+            want = _state_words(o.basis(), o.pairs(), o.reducer_order())
+            assert np.array_equal(_state_words(basis, pairs, order), want), e
