@@ -58,6 +58,7 @@ SIGNATURES = {
     "bbx_value": (C.c_int, [_vp, C.c_int, C.c_char_p, C.c_double, C.POINTER(C.c_double)]),
     "bbx_step_device": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp]),
     "bbx_rollout_device": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
+    "bbx_prefetch": (C.c_int, [_vp]),
     "bbx_timing": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_double), _i32p]),
     "bbx_sync": (C.c_int, [_vp]),
     "bbx_stats": (C.c_int, [_vp, _vp]),

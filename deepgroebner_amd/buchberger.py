@@ -160,6 +160,10 @@ class VecLeadMonomialsEnv:
     def sync(self):
         _ffi.check(_ffi.lib().bbx_sync(self._h))
 
+    def prefetch(self):
+        """Generate and upload ideals until every environment's ring is full."""
+        _ffi.check(_ffi.lib().bbx_prefetch(self._h))
+
     def timing(self, enable=True):
         """(kernel milliseconds, launches) of the step kernel since the last call (HIP events on its stream)."""
         ms, n = C.c_double(), C.c_int32()

@@ -72,6 +72,7 @@ struct bbx_batch {
   std::vector<int32_t> h_tail, h_head;
   std::vector<BbxHdr> h_hdr;
   bool q_dirty = true;
+  std::vector<uint8_t> q_dirty_env;
   // device
   char* d_recs = nullptr;
   uint32_t* d_q = nullptr;
@@ -136,18 +137,34 @@ int pack_ideal(const bbx_batch* b, bbx::HIdeal F, uint32_t* slot) {
 
 int upload_queue(bbx_batch* b) {
   if (!b->q_dirty) return BBX_OK;
-  HIPCHK(hipMemcpy(b->d_q, b->h_q.data(), b->h_q.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  const size_t stride = b->fixed ? b->h_q.size() : (size_t)b->nslots * b->slot_words;
+  if (b->fixed || b->q_dirty_env.empty()) {
+    HIPCHK(hipMemcpy(b->d_q, b->h_q.data(), b->h_q.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  } else {
+    // upload runs of consecutive environments whose rings changed
+    for (int e = 0; e < b->B;) {
+      if (!b->q_dirty_env[e]) { e++; continue; }
+      int f = e;
+      while (f < b->B && b->q_dirty_env[f]) f++;
+      HIPCHK(hipMemcpy(b->d_q + (size_t)e * stride, b->h_q.data() + (size_t)e * stride, (size_t)(f - e) * stride * sizeof(uint32_t), hipMemcpyHostToDevice));
+      e = f;
+    }
+    std::fill(b->q_dirty_env.begin(), b->q_dirty_env.end(), 0);
+  }
   HIPCHK(hipMemcpy(b->d_tail, b->h_tail.data(), b->h_tail.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   b->q_dirty = false;
   return BBX_OK;
 }
 
-// top every environment's ring up to nslots pre-generated ideals
-int fill_queues(bbx_batch* b) {
+// refill the ring of every environment that holds fewer than min_avail pre-generated ideals
+// (launches pass 1: only rings that are empty; bbx_prefetch passes the ring size: top everything up)
+int fill_queues(bbx_batch* b, int min_avail = 1) {
   if (b->fixed) return upload_queue(b);
   std::string err;
   bbx::HIdeal F;
+  if (b->q_dirty_env.size() != (size_t)b->B) b->q_dirty_env.assign(b->B, b->q_dirty ? 1 : 0);
   for (int e = 0; e < b->B; e++) {
+    if (b->h_tail[e] - b->h_head[e] >= std::min(min_avail, (int)b->nslots)) continue;
     while (b->h_tail[e] - b->h_head[e] < (int)b->nslots) {
       if (!b->gens[e]->next(F, &err)) return fail(BBX_E_GENERATOR, "%s", err.c_str());
       uint32_t* slot = b->h_q.data() + (size_t)e * b->nslots * b->slot_words + (size_t)(b->h_tail[e] % (int)b->nslots) * b->slot_words;
@@ -155,6 +172,7 @@ int fill_queues(bbx_batch* b) {
       if (rc) return rc;
       b->h_tail[e]++;
       b->q_dirty = true;
+      b->q_dirty_env[e] = 1;
     }
   }
   return upload_queue(b);
@@ -439,7 +457,7 @@ int bbx_seed(bbx_batch* b, const int64_t* seeds) {
   int rc = read_headers(b);                    // ideals generated ahead from the old stream are dropped
   if (rc) return rc;
   for (int e = 0; e < b->B; e++) { b->gens[e]->seed(seeds[e]); b->h_tail[e] = b->h_head[e]; }
-  b->q_dirty = true;
+  b->q_dirty = true; b->q_dirty_env.clear();
   return BBX_OK;
 }
 
@@ -525,6 +543,14 @@ int bbx_sync(bbx_batch* b) {
   HIPCHK(hipSetDevice(b->device));
   if (!b->in_flight) { HIPCHK(hipDeviceSynchronize()); return BBX_OK; }
   return finish(b, b->last_stream);
+}
+
+int bbx_prefetch(bbx_batch* b) {
+  if (!b) return fail(BBX_E_ARG, "null argument");
+  HIPCHK(hipSetDevice(b->device));
+  if (b->in_flight) { int rc = finish(b, b->last_stream); if (rc) return rc; }
+  else { int rc = read_headers(b); if (rc) return rc; }
+  return fill_queues(b, (int)b->nslots);
 }
 
 int bbx_timing(bbx_batch* b, int enable, double* kernel_ms, int32_t* launches) {

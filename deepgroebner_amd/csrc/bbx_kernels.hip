@@ -459,13 +459,14 @@ __device__ __forceinline__ void step_body(const BbxParams& p, char* smem) {
   if (p.pass == 1 && !(status == BBX_ST_OK && (need_reset || (budget > 0 && nP > 0)))) return;  // nothing left to do here
 
   Env<W> ge = env_view<W>(grec, p.L);
-  Env<W> e = ge;
+  // In the staged instantiation the working view is ALWAYS the LDS copy (never a select between an LDS and
+  // a global pointer), so that every access below compiles to ds_read/ds_write instead of flat_*.
+  Env<W> e = STAGED ? env_view<W>(smem + (size_t)wave_in_block * L.rec_bytes, L) : ge;
   bool staged_in = false;
   if (STAGED) {
     if (status == BBX_ST_OK) {
       if (nG > (int)L.maxG || nP > (int)L.maxP || arena_used > (int)L.arena) status = BBX_ST_SPILL;
       else {
-        e = env_view<W>(smem + (size_t)wave_in_block * L.rec_bytes, L);
         stage_copy<W>(e, ge, nG, nP, arena_used);
         staged_in = true;
         wave_sync();

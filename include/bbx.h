@@ -119,6 +119,10 @@ int bbx_rollout_device(bbx_batch* b, int agent, int nsteps, int auto_reset, doub
  * wait for ideals; returns BBX_E_CAPACITY etc. if any environment failed */
 int bbx_sync(bbx_batch* b);
 
+/* Tops every environment's ring of pre-generated ideals up to queue_slots and uploads them, so that the
+ * following rollouts find their inputs resident in HBM (launches themselves only refill EMPTY rings). */
+int bbx_prefetch(bbx_batch* b);
+
 /* HIP-event timing of the step-kernel launches on their own stream: returns the milliseconds and launch
  * count accumulated since the previous call, then enables/disables further collection */
 int bbx_timing(bbx_batch* b, int enable, double* kernel_ms, int32_t* launches);
