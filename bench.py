@@ -68,9 +68,10 @@ def main():
     # the library refills and resumes if an environment still runs dry, so this only affects speed)
     slots = (K + Wm) // 4 + 16
     env = VecLeadMonomialsEnv(args.dist, batch=B, k=K_LEADS, device=local_rank, caps={"queue_slots": slots})
-    g0 = rank * B                                     # contiguous block of global environment ids
-    env.seed(np.arange(B, dtype=np.int64) + 1000 + g0)
-    env.seed_agent((np.arange(B, dtype=np.int64) + g0).astype(np.uint32))
+    from deepgroebner_amd.shard import plan
+    pl = plan(rank, world, B)                         # contiguous block of global environment ids
+    env.seed(pl["ideal_seeds"])
+    env.seed_agent(pl["agent_seeds"])
     env.reset()
 
     stream = torch.cuda.current_stream()

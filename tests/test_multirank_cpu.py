@@ -1,0 +1,74 @@
+"""N>1 path on CPU: two gloo ranks each run their shard of the global batch (the oracle stands in for
+the device here — this test is about the placement logic: ids, seeds, aggregation); the gathered
+result must equal a single-process run over the whole batch, i.e. results do not depend on placement."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run_shard(rank, world, per_rank, T):
+    sys.path.insert(0, ROOT)
+    from deepgroebner_amd.shard import plan
+    from oracle import ffi
+    bo = ffi.load("bo")
+    pl = plan(rank, world, per_rank)
+    out = np.zeros((per_rank, 3), dtype=np.int64)
+    for i in range(per_rank):
+        env = bo.env("3-20-10-weighted")
+        env.seed(int(pl["ideal_seeds"][i]))
+        env.reset()
+        adds = 0
+        for t in range(T):
+            adds += int(-env.step(ffi.agent_hash(int(pl["agent_seeds"][i]), t) % env.nP))
+            if env.nP == 0:
+                env.reset()
+        out[i] = (pl["ids"][i], adds, env.nG)
+    return out
+
+
+def _worker(rank, world, port, per_rank, T, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = torch.from_numpy(_run_shard(rank, world, per_rank, T))
+    gathered = [torch.zeros_like(mine) for _ in range(world)]
+    dist.barrier()
+    dist.all_gather(gathered, mine)                       # test-side aggregation only
+    total = mine[:, 1].sum().clone()
+    dist.all_reduce(total, op=dist.ReduceOp.SUM)          # what bench.py does with its counters
+    if rank == 0:
+        q.put((torch.cat(gathered).numpy(), int(total)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_equal_one_process():
+    world, per_rank, T = 2, 6, 80
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, per_rank, T, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got, total = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = _run_shard(0, 1, world * per_rank, T)          # the same global batch in one process
+    assert np.array_equal(got, want)
+    assert total == int(want[:, 1].sum())
+
+
+def test_plan_is_a_partition():
+    sys.path.insert(0, ROOT)
+    from deepgroebner_amd.shard import plan
+    ids = np.concatenate([plan(r, 8, 4096)["ids"] for r in range(8)])
+    assert np.array_equal(ids, np.arange(8 * 4096))
+    assert plan(3, 8, 4096)["ideal_seeds"][0] == 1000 + 3 * 4096
