@@ -49,6 +49,20 @@ BbxLayout make_layout(int W, int maxG, int maxP, int arena, int maxT) {
   return L;
 }
 
+// binomial class: no arena, fixed two-term polynomials (bbx_common.h)
+BbxLayout make_layout_binom(int W, int maxG, int maxP) {
+  BbxLayout L{};
+  L.W = W; L.maxG = maxG; L.maxP = maxP; L.arena = 0; L.maxT = 2; L.kind = 1;
+  const uint32_t MW = 4u * W;
+  uint32_t o = sizeof(BbxHdr);
+  auto take = [&o](uint32_t bytes) { uint32_t at = o; o = align16(o + bytes); return at; };
+  L.off_lm = take(MW * maxG); L.off_tm = take(MW * maxG); L.off_slm = take(MW * maxG); L.off_stm = take(MW * maxG);
+  L.off_lcm = take(MW * maxG); L.off_ginfo = take(8u * maxG); L.off_sinfo = take(8u * maxG);
+  L.off_pairs = take(4u * maxP); L.off_cp = take(maxG);
+  L.rec_bytes = (o + 255u) & ~255u;
+  return L;
+}
+
 struct OutBuf {            // one contiguous device block so a step needs a single D2H copy
   double* rewards; int32_t* rows; uint8_t* dones;
   size_t bytes;
@@ -64,8 +78,9 @@ struct bbx_gen {
 struct bbx_batch {
   int B = 0, device = 0, k = 1, nvars = 0, W = 2;
   int elim = 0, rewards = 0, sort_input = 0, sort_reducers = 1;
-  bool fixed = false;
+  bool fixed = false, binom = false;
   BbxLayout L{}, LL{};
+  uint16_t* d_inv = nullptr;           // GF(32003) inverse table
   std::vector<std::unique_ptr<bbx::IdealGen>> gens;   // one per environment (one shared when fixed)
   uint32_t slot_words = 0, nslots = 0;
   std::vector<uint32_t> h_q;          // host mirror of the ideal queue
@@ -196,6 +211,7 @@ const char* status_name(int s) {
     case BBX_ST_POLY_TOO_LONG: return "intermediate polynomial longer than max_poly_terms";
     case BBX_ST_DEG_OVERFLOW: return "degree above 65535";
     case BBX_ST_BAD_ACTION: return "action index outside [0, rows)";
+    case BBX_ST_RUNAWAY: return "reduction did not terminate within 2^24 rounds";
     default: return "unknown";
   }
 }
@@ -207,6 +223,7 @@ void fill_params(bbx_batch* b, BbxParams* p) {
   p->q.nslots = b->nslots; p->q.fixed = b->fixed ? 1 : 0; p->q.tail = b->d_tail;
   p->elim = b->elim; p->rewards_mode = b->rewards; p->sort_reducers = b->sort_reducers; p->k = b->k; p->nvars = b->nvars;
   p->trace = b->d_trace; p->trace_stride = b->trace_cap;
+  p->inv_table = b->d_inv;
 }
 
 // enqueue the kernels of one logical launch: the LDS-staged pass (when the class allows) followed by the
@@ -329,18 +346,21 @@ int create_common(std::unique_ptr<bbx::IdealGen> proto, int nvars_obs, int elimi
     if (!c.arena_terms) c.arena_terms = 1 << 18; if (!c.max_poly_terms) c.max_poly_terms = 4096;
   }
   if (!c.queue_slots) c.queue_slots = 8;
+  b->binom = binomial && !c.general_class && !getenv("BBX_NO_BINOM");
   // LDS-resident class: small binomial environments work out of LDS for the whole launch; anything that
   // outgrows it continues in the HBM-resident pass of the same launch sequence
   b->staged = 0;
   if (binomial && b->W == 2 && c.lds_max_basis >= 0 && !getenv("BBX_NO_STAGE")) {
     int lg = c.lds_max_basis ? c.lds_max_basis : 128;
     lg = std::min((lg + 15) & ~15, c.max_basis);       // the working copy never exceeds the HBM record
-    b->LL = make_layout(b->W, lg, std::min(2 * lg, c.max_pairs), std::min(2 * lg + 16, c.arena_terms), c.max_poly_terms);
+    b->LL = b->binom ? make_layout_binom(b->W, lg, std::min(2 * lg, c.max_pairs))
+                     : make_layout(b->W, lg, std::min(2 * lg, c.max_pairs), std::min(2 * lg + 16, c.arena_terms), c.max_poly_terms);
     b->staged = 1;
   }
   if (c.max_basis > 65535 || c.max_poly_terms > 65535 || c.max_basis < 2 || c.max_pairs < 2 || c.max_poly_terms < 4 || c.queue_slots < 1)
     return fail(BBX_E_ARG, "capacities out of range");
-  b->L = make_layout(b->W, c.max_basis, c.max_pairs, c.arena_terms, c.max_poly_terms);
+  b->L = b->binom ? make_layout_binom(b->W, c.max_basis, c.max_pairs)
+                  : make_layout(b->W, c.max_basis, c.max_pairs, c.arena_terms, c.max_poly_terms);
   b->nslots = b->fixed ? 1 : (uint32_t)c.queue_slots;
   b->slot_words = 1 + (uint32_t)proto->npolys() * (2 + (uint32_t)std::min(proto->max_terms_hint(), c.max_poly_terms) * (1 + b->W));
   b->slot_words = (b->slot_words + 3u) & ~3u;
@@ -368,6 +388,12 @@ int create_common(std::unique_ptr<bbx::IdealGen> proto, int nvars_obs, int elimi
   HIPCHK(hipMalloc((void**)&b->d_mask, (size_t)batch));
   HIPCHK(hipMalloc((void**)&b->d_seeds, (size_t)batch * sizeof(uint32_t)));
   HIPCHK(hipMalloc((void**)&b->d_hdr, (size_t)batch * sizeof(BbxHdr)));
+  {
+    std::vector<uint16_t> inv(BBX_P, 0);
+    for (uint32_t x = 1; x < BBX_P; x++) inv[x] = (uint16_t)bbx::coef_inv((int)x);
+    HIPCHK(hipMalloc((void**)&b->d_inv, BBX_P * sizeof(uint16_t)));
+    HIPCHK(hipMemcpy(b->d_inv, inv.data(), BBX_P * sizeof(uint16_t), hipMemcpyHostToDevice));
+  }
   int lrc = bbx_launch_init(b->d_recs, b->L.rec_bytes, batch, nullptr, 0);
   if (lrc) return fail(BBX_E_DEVICE, "init launch failed: %s", hipGetErrorString((hipError_t)lrc));
   lrc = bbx_launch_mark_reset(b->d_recs, b->L.rec_bytes, batch, nullptr, 0);
@@ -417,7 +443,7 @@ void bbx_destroy(bbx_batch* b) {
   if (!b) return;
   (void)hipSetDevice(b->device);
   (void)hipDeviceSynchronize();
-  void* bufs[] = {b->d_recs, b->d_q, b->d_tail, b->d_out, b->d_actions, b->d_mask, b->d_seeds, b->d_obs, b->d_trace, b->d_hdr};
+  void* bufs[] = {b->d_recs, b->d_q, b->d_tail, b->d_out, b->d_actions, b->d_mask, b->d_seeds, b->d_obs, b->d_trace, b->d_hdr, b->d_inv};
   for (void* p : bufs) (void)hipFree(p);
   delete b;
 }
@@ -429,7 +455,7 @@ int bbx_copy(const bbx_batch* s, bbx_batch** out) {
   auto b = std::make_unique<bbx_batch>();
   b->B = s->B; b->device = s->device; b->k = s->k; b->nvars = s->nvars; b->W = s->W;
   b->elim = s->elim; b->rewards = s->rewards; b->sort_input = s->sort_input; b->sort_reducers = s->sort_reducers;
-  b->fixed = s->fixed; b->L = s->L; b->LL = s->LL; b->slot_words = s->slot_words; b->nslots = s->nslots;
+  b->fixed = s->fixed; b->binom = s->binom; b->L = s->L; b->LL = s->LL; b->slot_words = s->slot_words; b->nslots = s->nslots;
   b->h_q = s->h_q; b->h_tail = s->h_tail; b->h_head = s->h_head; b->q_dirty = true;
   b->staged = s->staged; b->envs_per_block = s->envs_per_block;
   for (auto& g : s->gens) b->gens.push_back(g->clone());
@@ -444,6 +470,8 @@ int bbx_copy(const bbx_batch* s, bbx_batch** out) {
   HIPCHK(hipMalloc((void**)&b->d_mask, (size_t)batch));
   HIPCHK(hipMalloc((void**)&b->d_seeds, (size_t)batch * sizeof(uint32_t)));
   HIPCHK(hipMalloc((void**)&b->d_hdr, (size_t)batch * sizeof(BbxHdr)));
+  HIPCHK(hipMalloc((void**)&b->d_inv, BBX_P * sizeof(uint16_t)));
+  HIPCHK(hipMemcpy(b->d_inv, s->d_inv, BBX_P * sizeof(uint16_t), hipMemcpyDeviceToDevice));
   int rc = upload_queue(b.get());
   if (rc) return rc;
   *out = b.release();
@@ -627,7 +655,7 @@ int bbx_state_sizes(bbx_batch* b, int idx, int32_t* basis_size, int32_t* npairs,
   HIPCHK(hipMemcpy(&h, b->d_recs + (size_t)idx * b->L.rec_bytes, sizeof h, hipMemcpyDeviceToHost));
   if (basis_size) *basis_size = h.nG;
   if (npairs) *npairs = h.nP;
-  if (nterms_total) *nterms_total = h.arena_used;
+  if (nterms_total) *nterms_total = b->binom ? 2 * h.nG : h.arena_used;   // binomial class: upper bound
   return BBX_OK;
 }
 
@@ -638,6 +666,38 @@ int bbx_state_get(bbx_batch* b, int idx, int32_t* nterms, int32_t* coefs, int32_
   const char* rec = b->d_recs + (size_t)idx * b->L.rec_bytes;
   BbxHdr h;
   HIPCHK(hipMemcpy(&h, rec, sizeof h, hipMemcpyDeviceToHost));
+  if (b->binom) {
+    const int W = b->W, nG = h.nG, nP = h.nP;
+    std::vector<uint32_t> lm((size_t)std::max(nG, 1) * W), tm((size_t)std::max(nG, 1) * W), gi((size_t)std::max(nG, 1) * 2),
+        si((size_t)std::max(nG, 1) * 2), pr(std::max(nP, 1));
+    if (nG) {
+      HIPCHK(hipMemcpy(lm.data(), rec + b->L.off_lm, (size_t)nG * W * 4, hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy(tm.data(), rec + b->L.off_tm, (size_t)nG * W * 4, hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy(gi.data(), rec + b->L.off_ginfo, (size_t)nG * 8, hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy(si.data(), rec + b->L.off_sinfo, (size_t)nG * 8, hipMemcpyDeviceToHost));
+    }
+    if (nP) HIPCHK(hipMemcpy(pr.data(), rec + b->L.off_pairs, (size_t)nP * 4, hipMemcpyDeviceToHost));
+    auto unpack = [W](const uint32_t* w, int32_t* e8) {
+      for (int v = 0; v < bbx::kN; v++)
+        e8[v] = v < 2 * W - 1 ? ((v & 1) ? (int)(w[v >> 1] >> 16) : (int)(w[v >> 1] & 0xffffu)) : 0;
+    };
+    size_t at = 0;
+    for (int g = 0; g < nG; g++) {
+      const uint32_t c0 = gi[2 * g] & 0xffffu, c1 = gi[2 * g] >> 16;
+      if (nterms) nterms[g] = c1 ? 2 : 1;
+      if (coefs) coefs[at] = (int)c0;
+      if (exps) unpack(lm.data() + (size_t)g * W, exps + at * bbx::kN);
+      at++;
+      if (c1) {
+        if (coefs) coefs[at] = (int)c1;
+        if (exps) unpack(tm.data() + (size_t)g * W, exps + at * bbx::kN);
+        at++;
+      }
+      if (order) order[g] = (int)(si[2 * g + 1] >> 16);
+    }
+    if (pairs) for (int r = 0; r < nP; r++) { pairs[2 * r] = (int)(pr[r] & 0xffffu); pairs[2 * r + 1] = (int)(pr[r] >> 16); }
+    return BBX_OK;
+  }
   const int W = b->W, nG = h.nG, nP = h.nP, nt = h.arena_used;
   std::vector<uint32_t> am((size_t)std::max(nt, 1) * W), poff(std::max(nG, 1)), pr(std::max(nP, 1));
   std::vector<uint16_t> ac(std::max(nt, 1)), plen(std::max(nG, 1)), sidx(std::max(nG, 1));

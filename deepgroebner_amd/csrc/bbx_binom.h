@@ -1,0 +1,418 @@
+// Binomial class of the step kernel (included by bbx_kernels.hip).
+//
+// For the random binomial distributions (3-20-10-weighted, 5-10-5-uniform, ... ; reference
+// ideals.cpp:156-201) every basis element has at most two terms for the whole computation: an
+// S-polynomial of binomials is a binomial, and reducing a binomial by binomials yields a binomial,
+// a monomial or zero.  The class exploits that: no term arena, the S-polynomial h and the remainder
+// r live in registers (two terms each), one reduction round is the ballot scan of the reducers' lead
+// monomials plus two independent loads of the chosen reducer, and all merging is a handful of
+// wave-uniform compares.  The observable results are identical to the general path (same tests).
+//
+// Reference semantics reproduced: buchberger.cpp:18-21 (spoly), 24-49 (reduce), 52-99 (update),
+// 299-329 (reset/step), 354-408 (observation); polynomials.cpp:148-202 (merge, negate, term product).
+#pragma once
+
+template <int W> struct BEnv {
+  BbxHdr* hdr;
+  Mono<W>*lm, *tm, *slm, *stm, *lcm;
+  uint2 *ginfo, *sinfo;
+  uint32_t* pairs;
+  uint8_t* cp;
+};
+template <int W> __device__ __forceinline__ BEnv<W> benv_view(char* rec, const BbxLayout& L) {
+  BEnv<W> e;
+  e.hdr = (BbxHdr*)rec;
+  e.lm = (Mono<W>*)(rec + L.off_lm); e.tm = (Mono<W>*)(rec + L.off_tm); e.slm = (Mono<W>*)(rec + L.off_slm);
+  e.stm = (Mono<W>*)(rec + L.off_stm); e.lcm = (Mono<W>*)(rec + L.off_lcm);
+  e.ginfo = (uint2*)(rec + L.off_ginfo); e.sinfo = (uint2*)(rec + L.off_sinfo);
+  e.pairs = (uint32_t*)(rec + L.off_pairs); e.cp = (uint8_t*)(rec + L.off_cp);
+  return e;
+}
+
+// a term with c == 0 is "absent"
+template <int W> struct BTerm { Mono<W> m; uint32_t c; };
+
+// (x) + (y) for single optional terms: polynomials.cpp:148-177 restricted to one term per side
+template <int W>
+__device__ __forceinline__ void merge2(const BTerm<W>& x, const BTerm<W>& y, BTerm<W>& o0, BTerm<W>& o1) {
+  o1.m = m_zero<W>(); o1.c = 0;
+  if (x.c == 0) { o0 = y; return; }
+  if (y.c == 0) { o0 = x; return; }
+  if (m_gt(x.m, y.m)) { o0 = x; o1 = y; return; }
+  if (m_gt(y.m, x.m)) { o0 = y; o1 = x; return; }
+  o0.m = x.m; o0.c = addmod(x.c, y.c);          // equal monomials: sum, a zero sum drops the term
+}
+
+template <int W>
+__device__ void bstage_copy(const BEnv<W>& dst, const BEnv<W>& src, int nG, int nP) {
+  const int lane = lane_id();
+  for (int i = lane; i < nG; i += WAVE) {
+    dst.lm[i] = src.lm[i]; dst.tm[i] = src.tm[i]; dst.slm[i] = src.slm[i]; dst.stm[i] = src.stm[i];
+    dst.ginfo[i] = src.ginfo[i]; dst.sinfo[i] = src.sinfo[i];
+  }
+  for (int i = lane; i < nP; i += WAVE) dst.pairs[i] = src.pairs[i];
+}
+
+// append the binomial (t0, t1) as G[nG]: metadata, update(), sorted reducer insert (buchberger.cpp:321-326)
+template <int W>
+__device__ bool bin_add_poly(BEnv<W>& e, const BbxParams& p, const BbxLayout& L, int& nG, int& nP,
+                             const BTerm<W>& t0, const BTerm<W>& t1, int sugar, int* status) {
+  const int lane = lane_id();
+  if (nG >= (int)L.maxG) { *status = BBX_ST_G_FULL; return false; }
+  const int g = nG;
+  const uint32_t inv = t0.c == 1 ? 1u : (uint32_t)uni((int)p.inv_table[t0.c]);   // 1/LC (polynomials.cpp:11-23)
+  if (lane == 0) {
+    e.lm[g] = t0.m; e.tm[g] = t1.m;
+    e.ginfo[g] = make_uint2(t0.c | (t1.c << 16), inv | ((uint32_t)sugar << 16));
+  }
+  wave_sync();
+  if (!wave_update<W>(e, L, nG, nP, t0.m, p.elim, status)) return false;
+  // reducer order: std::upper_bound by lead monomial
+  int pos = g;
+  if (p.sort_reducers) {
+    pos = 0;
+    for (int base = 0; base < g; base += WAVE) {
+      int k = base + lane;
+      bool le = k < g && !m_gt(e.slm[k], t0.m);
+      pos += __popcll(ballot64(le));
+    }
+    for (int hi = g; hi > pos; hi -= WAVE) {     // shift [pos, g) up by one, top chunk first
+      int k = hi - 1 - lane;
+      Mono<W> a, b; uint2 s = make_uint2(0, 0);
+      if (k >= pos) { a = e.slm[k]; b = e.stm[k]; s = e.sinfo[k]; }
+      wave_sync();
+      if (k >= pos) { e.slm[k + 1] = a; e.stm[k + 1] = b; e.sinfo[k + 1] = s; }
+      wave_sync();
+    }
+  }
+  if (lane == 0) {
+    e.slm[pos] = t0.m; e.stm[pos] = t1.m;
+    e.sinfo[pos] = make_uint2(t1.c | (inv << 16), (uint32_t)sugar | ((uint32_t)g << 16));
+  }
+  wave_sync();
+  nG = g + 1;
+  return true;
+}
+
+template <int W>
+__device__ bool bin_reset(BEnv<W>& e, const BbxParams& p, const BbxLayout& L, int env, int& nG, int& nP, int& q_head, int* status) {
+  for (;;) {
+    const uint32_t* slot;
+    if (p.q.fixed) slot = p.q.words;
+    else {
+      int tail = p.q.tail[env];
+      if (q_head >= tail) { *status = BBX_ST_STARVED; return false; }
+      slot = p.q.words + (size_t)env * p.q.env_stride + (size_t)(q_head % (int)p.q.nslots) * p.q.slot_words;
+    }
+    nG = 0; nP = 0;
+    const int npoly = (int)slot[0];
+    const uint32_t* w = slot + 1;
+    for (int f = 0; f < npoly; f++) {
+      const int n = uni((int)w[0]), sugar = uni((int)w[1]);
+      w += 2;
+      if (n < 1 || n > 2) { *status = BBX_ST_POLY_TOO_LONG; return false; }
+      BTerm<W> t0, t1;
+      t0.c = w[0];
+#pragma unroll
+      for (int i = 0; i < W; i++) t0.m.w[i] = w[1 + i];
+      t1.c = 0; t1.m = m_zero<W>();
+      if (n == 2) {
+        t1.c = w[1 + W];
+#pragma unroll
+        for (int i = 0; i < W; i++) t1.m.w[i] = w[2 + W + i];
+      }
+      if (!bin_add_poly<W>(e, p, L, nG, nP, t0, t1, sugar, status)) return false;
+      w += (size_t)n * (1 + W);
+    }
+    if (!p.q.fixed) q_head++;
+    if (nP != 0 || p.q.fixed) return true;        // buchberger.cpp:313-314: redraw while the pair set is empty
+  }
+}
+
+// observation rows (buchberger.cpp:354-370, 391-394): one lane per monomial slot of the matrix
+template <int W, bool HASH>
+__device__ uint64_t bin_obs(const BEnv<W>& e, const BbxParams& p, int env, int nP, bool write, bool want_hash) {
+  const int lane = lane_id();
+  const int n = p.nvars, k = p.k;
+  const int cols = 2 * n * k;
+  int32_t* out = (write && p.obs) ? p.obs + (size_t)env * p.obs_rows * cols : nullptr;
+  const int rows = out ? (nP < p.obs_rows ? nP : p.obs_rows) : nP;
+  // lane -> (row within the sweep, half, term) is fixed for the launch: no division inside the loop
+  const int per_row = 2 * k;
+  const int rows_per_sweep = per_row <= WAVE ? WAVE / per_row : 1;
+  uint64_t h = 0;
+  if (per_row <= WAVE) {
+    const int rl = lane / per_row, slot = lane - rl * per_row;
+    const int half = slot >= k ? 1 : 0, t = slot - half * k;
+    const bool active = rl < rows_per_sweep;
+    for (int r0 = 0; r0 < rows; r0 += rows_per_sweep) {
+      const int r = r0 + rl;
+      if (active && r < rows) {
+        uint32_t pr = e.pairs[r];
+        int g = half ? (int)(pr >> 16) : (int)(pr & 0xffffu);
+        Mono<W> mm = m_zero<W>();
+        if (t == 0) mm = e.lm[g];
+        else if (t == 1 && (e.ginfo[g].x >> 16) != 0) mm = e.tm[g];
+        const int base = (r * per_row + slot) * n;
+        for (int v = 0; v < n; v++) {
+          uint32_t x = m_exp(mm, v);
+          if (out) out[base + v] = (int32_t)x;
+          if (HASH && want_hash) h += bbx_mix64((uint64_t)(base + v), x);
+        }
+      }
+    }
+  } else {                                        // k > 32: generic item loop
+    const int items = rows * per_row;
+    for (int it = lane; it < items; it += WAVE) {
+      int r = it / per_row, slot = it - r * per_row;
+      int half = slot >= k ? 1 : 0, t = slot - half * k;
+      uint32_t pr = e.pairs[r];
+      int g = half ? (int)(pr >> 16) : (int)(pr & 0xffffu);
+      Mono<W> mm = m_zero<W>();
+      if (t == 0) mm = e.lm[g];
+      else if (t == 1 && (e.ginfo[g].x >> 16) != 0) mm = e.tm[g];
+      const int base = it * n;
+      for (int v = 0; v < n; v++) {
+        uint32_t x = m_exp(mm, v);
+        if (out) out[base + v] = (int32_t)x;
+        if (HASH && want_hash) h += bbx_mix64((uint64_t)(base + v), x);
+      }
+    }
+  }
+  if (out && p.obs_fill) {
+    for (int idx = rows * cols + lane; idx < p.obs_rows * cols; idx += WAVE) out[idx] = -1;
+  }
+  return (HASH && want_hash) ? wave_sum64(h) : 0;
+}
+
+// words of oracle/trace.py poly_words: [nterms, c0, e0[8], c1, e1[8]]
+template <int W>
+__device__ uint64_t bin_poly_hash(const BEnv<W>& e, int g) {
+  uint64_t h = 0;
+  if (lane_id() == 0) {
+    uint2 gi = e.ginfo[g];
+    const uint32_t c0 = gi.x & 0xffffu, c1 = gi.x >> 16;
+    const int n = c1 ? 2 : 1;
+    h = bbx_mix64(0, (uint32_t)n);
+    Mono<W> m0 = e.lm[g], m1 = e.tm[g];
+    h += bbx_mix64(1, c0);
+    for (int v = 0; v < BBX_MAXVARS; v++) h += bbx_mix64(2 + v, v < 2 * W - 1 ? m_exp(m0, v) : 0u);
+    if (c1) {
+      h += bbx_mix64(10, c1);
+      for (int v = 0; v < BBX_MAXVARS; v++) h += bbx_mix64(11 + v, v < 2 * W - 1 ? m_exp(m1, v) : 0u);
+    }
+  }
+  return wave_sum64(h);
+}
+
+template <int W, bool STAGED, bool TRACE>
+__device__ __forceinline__ void binom_body(const BbxParams& p, char* smem) {
+  const int lane = lane_id();
+  const int wave_in_block = uni((int)(threadIdx.x / WAVE));
+  const int env = blockIdx.x * (blockDim.x / WAVE) + wave_in_block;
+  if (env >= p.B) return;
+  char* grec = p.recs + (size_t)env * p.L.rec_bytes;
+  BbxHdr* ghdr = (BbxHdr*)grec;
+  const BbxLayout& L = STAGED ? p.LL : p.L;
+
+  int nG = uni(ghdr->nG), nP = uni(ghdr->nP);
+  int status = uni(ghdr->status), need_reset = uni(ghdr->need_reset), q_head = uni(ghdr->q_head);
+  int t_agent = uni(ghdr->t), episode_steps = uni(ghdr->episode_steps);
+  int episodes = uni(ghdr->episodes), zero_red = uni(ghdr->zero_reductions);
+  long long total_steps = ghdr->total_steps, total_adds = ghdr->total_additions, alg_bytes = ghdr->alg_bytes;
+  const uint32_t agent_seed = (uint32_t)uni((int)ghdr->agent_seed);
+  int budget = uni(ghdr->budget), rollout_pos = uni(ghdr->rollout_pos);
+  int done_last = uni(ghdr->done_last);
+  if (status == BBX_ST_STARVED || status == BBX_ST_SPILL) status = BBX_ST_OK;
+  if (p.set_budget) { budget = p.nsteps; rollout_pos = 0; done_last = 0; }
+  if (p.pass == 1 && !(status == BBX_ST_OK && (need_reset || (budget > 0 && nP > 0)))) return;
+
+  BEnv<W> ge = benv_view<W>(grec, p.L);
+  BEnv<W> e = STAGED ? benv_view<W>(smem + (size_t)wave_in_block * L.rec_bytes, L) : ge;
+  bool staged_in = false;
+  if (STAGED && status == BBX_ST_OK) {
+    if (nG > (int)L.maxG || nP > (int)L.maxP) status = BBX_ST_SPILL;
+    else { bstage_copy<W>(e, ge, nG, nP); staged_in = true; wave_sync(); }
+  }
+  int steps_done = 0;
+  double last_reward = 0.0;
+  const bool tracing = TRACE && p.trace != nullptr;
+  const int obs_term_bytes = 4 * 2 * p.nvars * p.k;
+
+  for (;;) {
+    if (status != BBX_ST_OK) break;
+    if (need_reset) {
+      if (!bin_reset<W>(e, p, L, env, nG, nP, q_head, &status)) {
+        if (STAGED && (status == BBX_ST_G_FULL || status == BBX_ST_P_FULL)) { status = BBX_ST_SPILL; nG = 0; nP = 0; }
+        break;
+      }
+      need_reset = 0; episode_steps = 0;
+    }
+    if (budget <= 0) break;
+    if (nP == 0) break;
+    if (nG + 1 > (int)L.maxG || nP - 1 + nG > (int)L.maxP) {          // worst-case headroom, before any mutation
+      status = STAGED ? BBX_ST_SPILL : (nG + 1 > (int)L.maxG ? BBX_ST_G_FULL : BBX_ST_P_FULL);
+      break;
+    }
+
+    // ---- choose the pair ------------------------------------------------------------------------
+    int action;
+    if (p.agent == BBX_AGENT_EXTERNAL) action = p.actions[env];
+    else if (p.agent == BBX_AGENT_HASH) action = (int)(bbx_agent_hash32(agent_seed, (uint32_t)t_agent) % (uint32_t)nP);
+    else if (p.agent == BBX_AGENT_FIRST) action = 0;
+    else {
+      uint64_t best = ~0ull;
+      for (int r = lane; r < nP; r += WAVE) {
+        uint32_t pr = e.pairs[r];
+        uint64_t key = ((uint64_t)m_deg(m_lcm(e.lm[pr & 0xffffu], e.lm[pr >> 16])) << 32) | (uint32_t)r;
+        best = key < best ? key : best;
+      }
+      action = (int)(uint32_t)wave_min64(best);
+    }
+    action = uni(action);
+    if (action < 0 || action >= nP) { status = BBX_ST_BAD_ACTION; break; }
+    const uint32_t pr = (uint32_t)uni((int)e.pairs[action]);
+    const int gi = pr & 0xffffu, gj = pr >> 16;
+    for (int base = action; base < nP - 1; base += WAVE) {             // P.erase(remove(action)), stable
+      int k = base + lane;
+      uint32_t v = 0;
+      if (k < nP - 1) v = e.pairs[k + 1];
+      wave_sync();
+      if (k < nP - 1) e.pairs[k] = v;
+      wave_sync();
+    }
+    nP -= 1;
+
+    // ---- S-polynomial (buchberger.cpp:18-21): the lead terms cancel, the two tails remain -------------
+    BTerm<W> h0, h1;
+    int hsug;
+    int bytes = 0;                                                     // algorithmic bytes of this step
+    {
+      const Mono<W> lmi = e.lm[gi], lmj = e.lm[gj];
+      const uint2 ii = e.ginfo[gi], ij = e.ginfo[gj];
+      const Mono<W> gamma = m_lcm(lmi, lmj);
+      const Mono<W> si = m_div(gamma, lmi), sj = m_div(gamma, lmj);
+      BTerm<W> a, b;
+      const uint32_t tci = ii.x >> 16, tcj = ij.x >> 16;
+      a.c = tci ? mulmod(tci, ii.y & 0xffffu) : 0u;               a.m = m_mul(e.tm[gi], si);
+      b.c = tcj ? negmod(mulmod(tcj, ij.y & 0xffffu)) : 0u;       b.m = m_mul(e.tm[gj], sj);
+      int sgi = (int)(ii.y >> 16) + (int)m_deg(si), sgj = (int)(ij.y >> 16) + (int)m_deg(sj);
+      hsug = uni(sgi > sgj ? sgi : sgj);
+      if (hsug > 65535) { status = BBX_ST_DEG_OVERFLOW; break; }
+      merge2<W>(a, b, h0, h1);
+      bytes += 12 * ((tci ? 2 : 1) + (tcj ? 2 : 1) + (h0.c ? 1 : 0) + (h1.c ? 1 : 0));
+    }
+
+    // ---- reduce (buchberger.cpp:24-49) --------------------------------------------------------------
+    BTerm<W> r0, r1;
+    r0.c = 0; r1.c = 0; r0.m = m_zero<W>(); r1.m = m_zero<W>();
+    int nsteps_red = 0, rsug = 0;
+    bool overflow = false;
+    while (h0.c != 0) {
+      const int hn = h1.c ? 2 : 1;
+      int found = -1;
+      Mono<W> lmg = m_zero<W>();
+      for (int base = 0; base < nG; base += WAVE) {                    // first reducer whose LM divides LM(h)
+        int k = base + lane;
+        Mono<W> s = m_zero<W>();
+        bool d = false;
+        if (k < nG) { s = e.slm[k]; d = m_divides(s, h0.m); }
+        uint64_t mask = ballot64(d);
+        if (mask) {
+          const int src = __builtin_ctzll(mask);
+          found = base + src;
+#pragma unroll
+          for (int i = 0; i < W; i++) lmg.w[i] = (uint32_t)__builtin_amdgcn_readlane((int)s.w[i], src);
+          break;
+        }
+      }
+      if (found >= 0) {                                                 // h <- h - (LT h / LT f) f
+        const uint2 si = e.sinfo[found];
+        const Mono<W> tmg = e.stm[found];
+        const uint32_t tcg = si.x & 0xffffu, invg = si.x >> 16;
+        const Mono<W> q = m_div(h0.m, lmg);
+        const uint32_t c = mulmod(h0.c, invg);
+        BTerm<W> b;
+        b.c = tcg ? negmod(mulmod(c, tcg)) : 0u;
+        b.m = m_mul(tmg, q);
+        int fs = (int)(si.y & 0xffffu) + (int)m_deg(q);
+        hsug = uni(fs > hsug ? fs : hsug);
+        if (hsug > 65535) { status = BBX_ST_DEG_OVERFLOW; overflow = true; break; }
+        BTerm<W> n0, n1;
+        merge2<W>(h1, b, n0, n1);
+        bytes += 8 * (found + 1) + 12 * (tcg ? 2 : 1) + 12 * (hn + (n0.c ? 1 : 0) + (n1.c ? 1 : 0));
+        h0 = n0; h1 = n1;
+        nsteps_red++;
+        if (nsteps_red > (1 << 24)) { status = BBX_ST_RUNAWAY; overflow = true; break; }
+      } else {                                                          // r <- r + LT h ; h <- h - LT h
+        bytes += 8 * nG + 12 * (2 * hn - 1);
+        if (r0.c == 0) r0 = h0; else r1 = h0;
+        int d = (int)m_deg(h0.m);
+        rsug = d > rsug ? d : rsug;
+        h0 = h1; h1.c = 0;
+      }
+    }
+    if (overflow) break;
+    rsug = uni(rsug > hsug ? rsug : hsug);
+
+    // ---- basis / pair-set update (buchberger.cpp:321-327) ---------------------------------------------
+    const int nG_before = nG, nP_before = nP;
+    if (r0.c != 0) {
+      if (!bin_add_poly<W>(e, p, L, nG, nP, r0, r1, rsug, &status)) break;
+      bytes += 12 * (r1.c ? 2 : 1) + 8 * nG_before + 8 * (nP_before + nP);
+    } else zero_red++;
+    bytes += nP * obs_term_bytes;
+    alg_bytes += bytes;
+    const double reward = (p.rewards_mode == BBX_REW_ADDITIONS) ? (-1.0 - (double)nsteps_red) : -1.0;
+    last_reward = reward;
+    total_steps++; total_adds += 1 + nsteps_red; t_agent++; episode_steps++; steps_done++;
+    const bool done = nP == 0;
+
+    if (p.obs_every_step && p.obs) bin_obs<W, false>(e, p, env, nP, true, false);
+    if (TRACE && tracing) {
+      uint64_t oh = bin_obs<W, true>(e, p, env, nP, false, true);
+      uint64_t ph = wave_pairs_hash<W, BEnv<W>>(e, nP);
+      uint64_t nh = nG > nG_before ? bin_poly_hash<W>(e, nG - 1) : 0;
+      if (lane == 0) {
+        BbxTraceRec& tr = p.trace[(size_t)env * p.trace_stride + rollout_pos];
+        tr.action = action; tr.nP = nP; tr.nG = nG; tr.done = done ? 1 : 0; tr.reward = reward;
+        tr.obs_hash = oh; tr.pairs_hash = ph; tr.newpoly_hash = nh;
+      }
+    }
+    budget--; rollout_pos++;
+    done_last = done ? 1 : 0;
+    if (done) {
+      episodes++;
+      if (p.auto_reset) need_reset = 1;
+    }
+  }
+
+  const bool handoff = status == BBX_ST_SPILL;
+  if (p.obs && status == BBX_ST_OK) bin_obs<W, false>(e, p, env, nP, true, false);
+  if (STAGED && staged_in) {
+    wave_sync();
+    bstage_copy<W>(ge, e, nG, nP);
+  }
+  if (lane == 0) {
+    BbxHdr* h = ghdr;
+    h->nG = nG; h->nP = nP; h->arena_used = 0; h->status = status; h->need_reset = need_reset;
+    h->q_head = q_head; h->t = t_agent; h->episode_steps = episode_steps; h->total_steps = total_steps;
+    h->total_additions = total_adds; h->episodes = episodes; h->zero_reductions = zero_red; h->steps_done = steps_done;
+    h->budget = budget; h->rollout_pos = rollout_pos; h->done_last = done_last; h->alg_bytes = alg_bytes;
+    if (!handoff) {
+      if (p.rewards && (steps_done > 0 || p.pass == 0)) p.rewards[env] = last_reward;
+      if (p.dones) p.dones[env] = (uint8_t)((done_last || (nP == 0 && !need_reset)) ? 1 : 0);
+      if (p.rows) p.rows[env] = nP;
+    }
+  }
+}
+
+template <int W, bool STAGED, bool TRACE>
+__global__ __launch_bounds__(256) void bbx_binom_kernel(BbxParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  binom_body<W, STAGED, TRACE>(p, smem);
+}
+template <int W>
+__global__ __launch_bounds__(256) void bbx_binom_aux_kernel(BbxParams p) {
+  binom_body<W, false, false>(p, nullptr);
+}

@@ -41,6 +41,7 @@ enum {
   BBX_ST_DEG_OVERFLOW = 5,  // total degree above 65535
   BBX_ST_STARVED = 6,       // ideal queue empty: the environment waits for the host to refill
   BBX_ST_BAD_ACTION = 7,    // action index outside [0, |P|)
+  BBX_ST_RUNAWAY = 9,       // a reduction exceeded 2^24 rounds (corrupt state guard; never seen in practice)
   BBX_ST_SPILL = 8,         // transient: the state outgrew the LDS-resident class; the HBM-resident pass of the
                             // same launch sequence continues this environment
 };
@@ -66,6 +67,12 @@ struct BbxLayout {
   uint32_t off_lm, off_slm, off_lcm, off_am, off_hm, off_poff, off_pairs;
   uint32_t off_sidx, off_plen, off_psug, off_pinv, off_ac, off_hc, off_cp;
   uint32_t rec_bytes;
+  // binomial class (kind == 1): every basis polynomial has <= 2 terms, so there is no arena; the
+  // record holds, in BASIS order, lm[] / tm[] (lead and tail monomial) and ginfo[] = {lc | tc<<16,
+  // 1/lc | sugar<<16}, and in REDUCER order slm[] / stm[] and sinfo[] = {tc | (1/lc)<<16, sugar | g<<16},
+  // so that one reduction round needs the scan of slm[] plus two independent loads.  tc == 0: no tail.
+  uint32_t kind;
+  uint32_t off_tm, off_stm, off_ginfo, off_sinfo;
 };
 
 // Ideal queue: per environment a ring of `nslots` ideals (or ONE shared slot when fixed != 0).
@@ -110,6 +117,7 @@ struct BbxParams {
   int32_t obs_every_step;   // 1: materialise the observation after every step (what a policy consumes),
                             // 0: only for the state the caller sees when the launch ends
   int32_t pass;             // 0: primary launch; 1: follow-up launch serving only environments with work left
+  const uint16_t* inv_table; // [32003] inverses in GF(32003) (L2-resident), binomial class
   BbxTraceRec* trace;       // [B, trace_stride] or null
   int32_t trace_stride;
 };

@@ -213,8 +213,8 @@ __device__ int wave_merge(const PView<W>& A, const PView<W>& B, Mono<W>* tm, uin
 // ------------------------------------------------------------------ update()   buchberger.cpp:52-99
 // Adds the polynomial whose lead monomial is lmf as G[m] (the caller has already stored its terms and
 // metadata) and updates the pair set.  Returns false on capacity overflow.
-template <int W>
-__device__ bool wave_update(Env<W>& e, const BbxLayout& L, int& nG, int& nP, const Mono<W> lmf, int elim, int* status) {
+template <int W, class EnvT>
+__device__ bool wave_update(EnvT& e, const BbxLayout& L, int& nG, int& nP, const Mono<W> lmf, int elim, int* status) {
   const int lane = lane_id();
   const int m = nG;
   if (elim == BBX_ELIM_GM) {
@@ -256,7 +256,7 @@ __device__ bool wave_update(Env<W>& e, const BbxLayout& L, int& nG, int& nP, con
         for (int k = 0; k < m; k++) {
           Mono<W> Lk = e.lcm[k];              // same address in every lane: broadcast read
           bool eq = m_eq(Lk, Li);
-          bad |= (!eq && m_divides(Lk, Li)) || (eq && (k < i || e.cp[k]));
+          bad |= m_divides(Lk, Li) && (!eq || k < i || e.cp[k]);
         }
         emit = !bad;
       }
@@ -400,8 +400,8 @@ __device__ uint64_t wave_obs(const Env<W>& e, const BbxParams& p, int env, int n
   return (HASH && want_hash) ? wave_sum64(h) : 0;
 }
 
-template <int W>
-__device__ uint64_t wave_pairs_hash(const Env<W>& e, int nP) {
+template <int W, class EnvT>
+__device__ uint64_t wave_pairs_hash(const EnvT& e, int nP) {
   uint64_t h = 0;
   for (int r = lane_id(); r < nP; r += WAVE) {
     uint32_t pr = e.pairs[r];
@@ -585,6 +585,7 @@ __device__ __forceinline__ void step_body(const BbxParams& p, char* smem) {
         alg_bytes += 8LL * (found + 1) + 12LL * (Bv.n + 1) + 12LL * (A.n + 1 + nn);
         hm = nm; hc = nc; hn = nn; hoff = 0;
         nsteps_red++;
+        if (nsteps_red > (1 << 24)) { status = BBX_ST_RUNAWAY; overflow = true; break; }
       } else {                                  // r <- r + LT h ; h <- h - LT h   (41-44)
         if (rn >= maxT) { status = BBX_ST_POLY_TOO_LONG; overflow = true; break; }
         alg_bytes += 8LL * nG + 12LL * (2 * (hn - hoff) - 1);
@@ -615,7 +616,7 @@ __device__ __forceinline__ void step_body(const BbxParams& p, char* smem) {
     // ---- parity trace (tests): hashes of the post-step observation / pair set / new element ---
     if (TRACE && tracing) {
       uint64_t oh = wave_obs<W, true>(e, p, env, nP, false, true);
-      uint64_t ph = wave_pairs_hash<W>(e, nP);
+      uint64_t ph = wave_pairs_hash<W, Env<W>>(e, nP);
       uint64_t nh = nG > nG_before ? wave_poly_hash<W>(e, nG - 1) : 0;
       if (lane == 0) {
         BbxTraceRec& tr = p.trace[(size_t)env * p.trace_stride + rollout_pos];
@@ -666,6 +667,8 @@ __global__ __launch_bounds__(256) void bbx_aux_kernel(BbxParams p) {
   step_body<W, false, false>(p, nullptr);
 }
 
+#include "bbx_binom.h"
+
 // ------------------------------------------------------------------ housekeeping kernels
 // zero the headers and set the per-environment agent seeds
 __global__ void bbx_init_kernel(char* recs, uint32_t rec_bytes, int B, const uint32_t* agent_seeds) {
@@ -706,20 +709,26 @@ extern "C" int bbx_launch_gather_hdr(const char* recs, uint32_t rec_bytes, int B
 
 // ------------------------------------------------------------------ host-callable launcher
 // kind: 0 = HBM-resident step kernel, 1 = LDS-staged step kernel, 2 = aux (reset / observation only)
+#define BBX_LAUNCH(KERN) hipLaunchKernelGGL((KERN), dim3(blocks), dim3(threads), lds, stream, *p)
 template <int W>
 static int launch_w(const BbxParams* p, int kind, int blocks, int threads, size_t lds, hipStream_t stream) {
   const bool trace = p->trace != nullptr;
-  if (kind == 2) { hipLaunchKernelGGL((bbx_aux_kernel<W>), dim3(blocks), dim3(threads), 0, stream, *p); return 0; }
-  if (kind == 1) {
-    const void* fn = trace ? (const void*)bbx_step_kernel<W, true, true> : (const void*)bbx_step_kernel<W, true, false>;
-    hipError_t err = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (err != hipSuccess) return (int)err;
-    if (trace) hipLaunchKernelGGL((bbx_step_kernel<W, true, true>), dim3(blocks), dim3(threads), lds, stream, *p);
-    else hipLaunchKernelGGL((bbx_step_kernel<W, true, false>), dim3(blocks), dim3(threads), lds, stream, *p);
+  const bool binom = p->L.kind == 1;
+  if (kind == 2) {
+    if (binom) BBX_LAUNCH(bbx_binom_aux_kernel<W>); else BBX_LAUNCH(bbx_aux_kernel<W>);
     return 0;
   }
-  if (trace) hipLaunchKernelGGL((bbx_step_kernel<W, false, true>), dim3(blocks), dim3(threads), 0, stream, *p);
-  else hipLaunchKernelGGL((bbx_step_kernel<W, false, false>), dim3(blocks), dim3(threads), 0, stream, *p);
+  if (kind == 1) {
+    const void* fn = binom ? (trace ? (const void*)bbx_binom_kernel<W, true, true> : (const void*)bbx_binom_kernel<W, true, false>)
+                           : (trace ? (const void*)bbx_step_kernel<W, true, true> : (const void*)bbx_step_kernel<W, true, false>);
+    hipError_t err = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (err != hipSuccess) return (int)err;
+    if (binom) { if (trace) BBX_LAUNCH((bbx_binom_kernel<W, true, true>)); else BBX_LAUNCH((bbx_binom_kernel<W, true, false>)); }
+    else { if (trace) BBX_LAUNCH((bbx_step_kernel<W, true, true>)); else BBX_LAUNCH((bbx_step_kernel<W, true, false>)); }
+    return 0;
+  }
+  if (binom) { if (trace) BBX_LAUNCH((bbx_binom_kernel<W, false, true>)); else BBX_LAUNCH((bbx_binom_kernel<W, false, false>)); }
+  else { if (trace) BBX_LAUNCH((bbx_step_kernel<W, false, true>)); else BBX_LAUNCH((bbx_step_kernel<W, false, false>)); }
   return 0;
 }
 extern "C" int bbx_launch_step(const BbxParams* p, int kind, int envs_per_block, hipStream_t stream) {

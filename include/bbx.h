@@ -48,6 +48,8 @@ typedef struct bbx_caps {
   int32_t queue_slots;    /* pre-generated ideals buffered per environment for device-side resets */
   int32_t lds_max_basis;  /* |G| up to which a small (3-variable binomial) environment is kept LDS-resident
                              for a whole launch; 0 = default (128), negative = never */
+  int32_t general_class;  /* non-zero: never use the binomial kernel class (term arena + general merges even for
+                             binomial ideals); for testing the general path on the same inputs */
 } bbx_caps;
 
 /* One record per environment per step of a traced rollout (parity tests). */

@@ -36,15 +36,21 @@ def compare_with_trace(env, e, want, T, label):
 
 # residency classes of the step kernel: default (LDS-resident where the class allows), HBM-resident only,
 # and an LDS class so small that environments keep spilling into the HBM-resident follow-up pass
-RESIDENCY = {"default": None, "hbm": {"lds_max_basis": -1}, "spill": {"lds_max_basis": 16}}
+RESIDENCY = {"default": None, "hbm": {"lds_max_basis": -1}, "spill": {"lds_max_basis": 16},
+             "general": {"general_class": 1}, "general_hbm": {"general_class": 1, "lds_max_basis": -1},
+             "general_spill": {"general_class": 1, "lds_max_basis": 16}}
 
 
 @pytest.mark.parametrize("residency", sorted(RESIDENCY))
 @pytest.mark.parametrize("name", trace_names())
 def test_golden_trace(name, residency):
     m = meta()["traces"][name]
-    if residency != "default" and not (m["dist"].startswith("3-") and m["dist"].count("-") >= 3 and "." not in m["dist"]):
-        pytest.skip("only 3-variable binomial distributions have an LDS-resident class")
+    binomial = "." not in m["dist"] and not m["dist"].startswith("cyclic")
+    three_var = m["dist"].startswith("3-") or m["dist"].startswith("2-")
+    if residency != "default" and not binomial:
+        pytest.skip("kernel classes only differ for binomial distributions")
+    if residency in ("spill", "general_spill", "hbm") and not three_var:
+        pytest.skip("only <=3-variable binomial distributions have an LDS-resident class")
     gold = load_trace(name)
     B = m["nenvs"]
     T = len(gold["e0_action"])
