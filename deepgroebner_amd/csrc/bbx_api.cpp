@@ -106,7 +106,7 @@ struct bbx_batch {
   BbxParams last{};
   hipStream_t last_stream = 0;
   bool in_flight = false;
-  int staged = 0, envs_per_block = 4;
+  int staged = 0, fast = 0, envs_per_block = 4;
 };
 
 namespace {
@@ -232,7 +232,7 @@ int enqueue(bbx_batch* b, const BbxParams& p0, bool resume, hipStream_t stream) 
   BbxParams p = p0;
   int kinds[2]; int nk = 0;
   if (p.nsteps == 0 && !resume) kinds[nk++] = 2;
-  else { if (b->staged) kinds[nk++] = 1; kinds[nk++] = 0; }
+  else { if (b->staged) kinds[nk++] = b->fast ? 3 : 1; kinds[nk++] = 0; }
   for (int i = 0; i < nk; i++) {
     if (resume) { p.set_budget = 0; p.pass = 1; }
     else if (i > 0) { p.set_budget = 0; p.pass = 1; }
@@ -356,6 +356,8 @@ int create_common(std::unique_ptr<bbx::IdealGen> proto, int nvars_obs, int elimi
     b->LL = b->binom ? make_layout_binom(b->W, lg, std::min(2 * lg, c.max_pairs))
                      : make_layout(b->W, lg, std::min(2 * lg, c.max_pairs), std::min(2 * lg + 16, c.arena_terms), c.max_poly_terms);
     b->staged = 1;
+    // the hand-tuned kernel covers exactly the reference C++ class's fixed options
+    b->fast = b->binom && elimination == BBX_GEBAUERMOELLER && sort_reducers && lg <= 128 && !getenv("BBX_NO_FAST");
   }
   if (c.max_basis > 65535 || c.max_poly_terms > 65535 || c.max_basis < 2 || c.max_pairs < 2 || c.max_poly_terms < 4 || c.queue_slots < 1)
     return fail(BBX_E_ARG, "capacities out of range");
@@ -457,7 +459,7 @@ int bbx_copy(const bbx_batch* s, bbx_batch** out) {
   b->elim = s->elim; b->rewards = s->rewards; b->sort_input = s->sort_input; b->sort_reducers = s->sort_reducers;
   b->fixed = s->fixed; b->binom = s->binom; b->L = s->L; b->LL = s->LL; b->slot_words = s->slot_words; b->nslots = s->nslots;
   b->h_q = s->h_q; b->h_tail = s->h_tail; b->h_head = s->h_head; b->q_dirty = true;
-  b->staged = s->staged; b->envs_per_block = s->envs_per_block;
+  b->staged = s->staged; b->fast = s->fast; b->envs_per_block = s->envs_per_block;
   for (auto& g : s->gens) b->gens.push_back(g->clone());
   const int batch = s->B;
   HIPCHK(hipMalloc((void**)&b->d_recs, (size_t)batch * b->L.rec_bytes));

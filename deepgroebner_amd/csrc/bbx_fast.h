@@ -1,0 +1,458 @@
+// The hand-tuned kernel for the headline class (included by bbx_kernels.hip):
+//   <= 3 variables (8-byte monomials), binomial ideals, Gebauer-Moeller elimination, sorted reducers —
+//   i.e. what the reference's C++ LeadMonomialsEnv always runs (buchberger.cpp:377) on 3-20-10-weighted.
+//
+// One wavefront owns one environment for the whole launch.  Where the state lives:
+//   registers  reducer-order arrays (lead monomial, tail monomial, {tc, 1/lc, sugar, basis index}), lane l holds
+//              reducers l and l+64: the first-divisor scan is pure VALU + ballot, the chosen reducer is fetched with
+//              v_readlane, and the sorted insert is a DPP wave shift (no memory traffic at all in a reduction round)
+//   LDS        basis-order arrays (lm, tm, ginfo) and the pair list, which are gathered by per-lane index
+//              (pair criteria, observation): 4 KB per environment at compile-time offsets
+//   HBM        the record (binomial layout, bbx_common.h) is read at launch start and written back at launch end;
+//              observations are written every step
+// An environment that outgrows |G| <= 128 / |P| <= 256 leaves a consistent record behind (BBX_ST_SPILL) and is
+// continued by the HBM-resident binomial kernel (bbx_binom.h) launched right behind on the same stream.
+//
+// Gebauer-Moeller new pairs without the std::map walk (buchberger.cpp:78-91): the lcms L_i = lcm(LM G_i, LM f) that
+// survive are exactly those minimal under divisibility.  They are peeled by increasing degree: all candidates of
+// minimal degree are minimal (a proper divisor has strictly smaller degree); each such bucket of equal lcms emits the
+// pair of its smallest index unless a member is coprime to f, then every multiple of it is discarded.  Cost is
+// proportional to the number of minimal lcms (a handful) instead of |G|^2/64.
+#pragma once
+
+typedef Mono<2> M2;
+constexpr int FG = 128, FP = 256;                      // LDS-class capacities
+constexpr int FOFF_LM = 0, FOFF_TM = 1024, FOFF_GI = 2048, FOFF_PR = 3072, FLDS_BYTES = 4096;
+constexpr uint32_t FSENT = 0xFFFFFFFFu;               // sentinel monomial word: divides nothing, greater than everything
+
+struct BbxFastParams {
+  char* recs; const uint32_t* qwords; const int32_t* qtail; const uint16_t* inv_table;
+  const int32_t* actions; double* rewards; uint8_t* dones; int32_t* rows; int32_t* obs; BbxTraceRec* trace;
+  uint32_t rec_bytes, hbmG;                           // HBM record stride and its basis capacity (offsets follow from it)
+  uint32_t q_env_stride, q_slot_words, q_nslots, q_fixed;
+  int32_t B, nsteps, obs_rows, trace_stride, k, nvars, lim_G, lim_P;
+  int32_t agent, auto_reset, set_budget, pass, obs_every_step, obs_fill, rewards_mode;
+};
+
+__device__ __forceinline__ uint32_t f_readlane(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
+__device__ __forceinline__ M2 f_readlane(const M2& v, int l) { M2 r; r.w[0] = f_readlane(v.w[0], l); r.w[1] = f_readlane(v.w[1], l); return r; }
+__device__ __forceinline__ uint2 f_readlane(const uint2& v, int l) { return make_uint2(f_readlane(v.x, l), f_readlane(v.y, l)); }
+__device__ __forceinline__ uint32_t f_wave_shr(uint32_t v) {           // lane i <- lane i-1 (lane 0 undefined: fixed by caller)
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xF, 0xF, false);
+}
+__device__ __forceinline__ uint32_t f_wave_min(uint32_t x) {
+#define FDPPMIN(ctrl, rmask) { uint32_t y_ = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)x, ctrl, rmask, 0xF, false); x = y_ < x ? y_ : x; }
+  FDPPMIN(0x111, 0xF) FDPPMIN(0x112, 0xF) FDPPMIN(0x114, 0xF) FDPPMIN(0x118, 0xF) FDPPMIN(0x142, 0xA) FDPPMIN(0x143, 0xC)
+#undef FDPPMIN
+  return f_readlane(x, 63);
+}
+__device__ __forceinline__ uint64_t f_u64(const M2& m) { return ((uint64_t)m.w[1] << 32) | m.w[0]; }
+__device__ __forceinline__ uint64_t f_lowmask(int n) { return n >= 64 ? ~0ull : ((1ull << n) - 1ull); }   // n in [0,64]
+
+// shift-insert `nv` at position p (0..63) of a 64-lane register array; returns the element shifted out of lane 63
+__device__ __forceinline__ uint32_t f_insert(uint32_t& arr, uint32_t nv, int p, int lane) {
+  uint32_t out = f_readlane(arr, 63);
+  uint32_t sh = f_wave_shr(arr);
+  arr = lane > p ? sh : (lane == p ? nv : arr);
+  return out;
+}
+// shift the whole array up by one, `carry` enters lane 0
+__device__ __forceinline__ void f_shift_in(uint32_t& arr, uint32_t carry, int lane) {
+  uint32_t sh = f_wave_shr(arr);
+  arr = lane == 0 ? carry : sh;
+}
+
+struct FastState {                 // reducer-order arrays, lane l <-> reducers l (A) and l + 64 (B)
+  M2 slmA, slmB, stmA, stmB;
+  uint2 sinA, sinB;                // .x = tc | (1/lc) << 16 ; .y = sugar | basis index << 16
+};
+
+template <bool TRACE>
+__device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
+  const int lane = lane_id();
+  const int wave_in_block = uni((int)(threadIdx.x / WAVE));
+  const int env = blockIdx.x * (blockDim.x / WAVE) + wave_in_block;
+  if (env >= p.B) return;
+  char* grec = p.recs + (size_t)env * p.rec_bytes;
+  BbxHdr* ghdr = (BbxHdr*)grec;
+
+  int nG = uni(ghdr->nG), nP = uni(ghdr->nP);
+  int status = uni(ghdr->status), need_reset = uni(ghdr->need_reset), q_head = uni(ghdr->q_head);
+  int t_agent = uni(ghdr->t);
+  const uint32_t agent_seed = (uint32_t)uni((int)ghdr->agent_seed);
+  int budget = uni(ghdr->budget), rollout_pos = uni(ghdr->rollout_pos), done_last = uni(ghdr->done_last);
+  if (status == BBX_ST_STARVED || status == BBX_ST_SPILL) status = BBX_ST_OK;
+  if (p.set_budget) { budget = p.nsteps; rollout_pos = 0; done_last = 0; }
+  if (p.pass == 1 && !(status == BBX_ST_OK && (need_reset || (budget > 0 && nP > 0)))) return;
+
+  // HBM record arrays (binomial layout: every array 16-B aligned, capacities hbmG / maxP)
+  const uint32_t HG = p.hbmG;
+  M2* g_lm = (M2*)(grec + 128);            M2* g_tm = (M2*)(grec + 128 + 8 * HG);
+  M2* g_slm = (M2*)(grec + 128 + 16 * HG); M2* g_stm = (M2*)(grec + 128 + 24 * HG);
+  uint2* g_gi = (uint2*)(grec + 128 + 40 * HG); uint2* g_si = (uint2*)(grec + 128 + 48 * HG);
+  uint32_t* g_pr = (uint32_t*)(grec + 128 + 56 * HG);
+  // LDS working arrays at compile-time offsets
+  char* lbase = smem + wave_in_block * FLDS_BYTES;
+  M2* lm = (M2*)(lbase + FOFF_LM); M2* tm = (M2*)(lbase + FOFF_TM);
+  uint2* gi = (uint2*)(lbase + FOFF_GI); uint32_t* pairs = (uint32_t*)(lbase + FOFF_PR);
+  const int limG = p.lim_G < FG ? p.lim_G : FG, limP = p.lim_P < FP ? p.lim_P : FP;
+
+  FastState S;
+  S.slmA.w[0] = S.slmA.w[1] = S.slmB.w[0] = S.slmB.w[1] = FSENT;
+  S.stmA = S.stmB = m_zero<2>(); S.sinA = S.sinB = make_uint2(0, 0);
+  bool staged_in = false;
+  if (status == BBX_ST_OK) {
+    if (nG > limG || nP > limP) status = BBX_ST_SPILL;
+    else {
+      if (lane < nG) { S.slmA = g_slm[lane]; S.stmA = g_stm[lane]; S.sinA = g_si[lane]; lm[lane] = g_lm[lane]; tm[lane] = g_tm[lane]; gi[lane] = g_gi[lane]; }
+      if (lane + 64 < nG) { S.slmB = g_slm[lane + 64]; S.stmB = g_stm[lane + 64]; S.sinB = g_si[lane + 64];
+                            lm[lane + 64] = g_lm[lane + 64]; tm[lane + 64] = g_tm[lane + 64]; gi[lane + 64] = g_gi[lane + 64]; }
+      for (int i = lane; i < nP; i += WAVE) pairs[i] = g_pr[i];
+      staged_in = true;
+      wave_sync();
+    }
+  }
+
+  int steps_done = 0, adds = 0, episodes = 0, zero_red = 0;
+  long long bytes_total = 0;
+  double last_reward = 0.0;
+  const bool tracing = TRACE && p.trace != nullptr;
+  const int n = p.nvars, kk = p.k;
+  const int per_row = 2 * kk;
+  const int obs_row_bytes = 4 * per_row * n;
+  // lane -> (row within a sweep, slot) of the observation matrix, fixed for the launch
+  const int o_rl = lane / per_row, o_slot = lane - o_rl * per_row;
+  const int rows_per_sweep = per_row <= WAVE ? WAVE / per_row : 0;
+
+  // ---- helpers as lambdas over the state above ----------------------------------------------------------------------
+  auto write_obs = [&](bool write, bool want_hash) -> uint64_t {
+    const int cols = per_row * n;
+    int32_t* out = (write && p.obs) ? p.obs + (size_t)env * p.obs_rows * cols : nullptr;
+    const int rows = out ? (nP < p.obs_rows ? nP : p.obs_rows) : nP;
+    uint64_t h = 0;
+    if (rows_per_sweep > 0) {
+      const int half = o_slot >= kk ? 1 : 0, t = o_slot - half * kk;
+      for (int r0 = 0; r0 < rows; r0 += rows_per_sweep) {
+        const int r = r0 + o_rl;
+        if (o_rl < rows_per_sweep && r < rows) {
+          const uint32_t pr = pairs[r];
+          const int g = half ? (int)(pr >> 16) : (int)(pr & 0xffffu);
+          M2 mm = m_zero<2>();
+          if (t == 0) mm = lm[g]; else if (t == 1) mm = tm[g];      // tm[g] is the zero monomial when G[g] has no tail
+          const int base = (r * per_row + o_slot) * n;
+          const uint32_t e0 = mm.w[0] & 0xffffu, e1 = mm.w[0] >> 16, e2 = mm.w[1] & 0xffffu;
+          if (out) {
+            if (n == 3) { int3 v3 = make_int3((int)e0, (int)e1, (int)e2); *(int3*)(out + base) = v3; }
+            else { out[base] = (int)e0; if (n > 1) out[base + 1] = (int)e1; }
+          }
+          if (TRACE && want_hash) {
+            h += bbx_mix64((uint64_t)base, e0);
+            if (n > 1) h += bbx_mix64((uint64_t)(base + 1), e1);
+            if (n > 2) h += bbx_mix64((uint64_t)(base + 2), e2);
+          }
+        }
+      }
+    } else {
+      for (int it = lane; it < rows * per_row; it += WAVE) {
+        const int r = it / per_row, slot = it - r * per_row;
+        const int half = slot >= kk ? 1 : 0, t = slot - half * kk;
+        const uint32_t pr = pairs[r];
+        const int g = half ? (int)(pr >> 16) : (int)(pr & 0xffffu);
+        M2 mm = m_zero<2>();
+        if (t == 0) mm = lm[g]; else if (t == 1) mm = tm[g];
+        for (int v = 0; v < n; v++) {
+          uint32_t x = m_exp(mm, v);
+          if (out) out[it * n + v] = (int)x;
+          if (TRACE && want_hash) h += bbx_mix64((uint64_t)(it * n + v), x);
+        }
+      }
+    }
+    if (out && p.obs_fill) for (int idx = rows * cols + lane; idx < p.obs_rows * cols; idx += WAVE) out[idx] = -1;
+    return (TRACE && want_hash) ? wave_sum64(h) : 0;
+  };
+
+  // append the binomial (t0, t1) to the basis: G-order arrays, Gebauer-Moeller update, sorted reducer insert
+  // (buchberger.cpp:52-99 + 321-326).  The caller has checked the capacities.
+  auto add_poly = [&](const BTerm<2>& t0, const BTerm<2>& t1, int sugar) {
+    const int g = nG;                                     // == m of update()
+    const uint32_t inv = t0.c == 1 ? 1u : (uint32_t)uni((int)p.inv_table[t0.c]);
+    const M2 f = t0.m;
+    const M2 tail = t1.c ? t1.m : m_zero<2>();
+    if (lane == 0) { lm[g] = f; tm[g] = tail; gi[g] = make_uint2(t0.c | (t1.c << 16), inv | ((uint32_t)sugar << 16)); }
+    // (70-76) drop old pairs (i,j): LM f | lcm_ij and lcm_ij != lcm_if and lcm_ij != lcm_jf.  Only exponents matter,
+    // so the lcms are raw v_pk_max words with the degree slot masked out of the comparisons.
+    int w = 0;
+    for (int base = 0; base < nP; base += WAVE) {
+      const int k = base + lane;
+      const bool valid = k < nP;
+      const uint32_t pr = valid ? pairs[k] : 0u;
+      const M2 li = lm[pr & 0xffffu], lj = lm[pr >> 16];
+      const uint32_t a0 = pk_max(li.w[0], lj.w[0]), a1 = pk_max(li.w[1], lj.w[1]);
+      const uint32_t b0 = pk_max(li.w[0], f.w[0]), b1 = pk_max(li.w[1], f.w[1]);
+      const uint32_t c0 = pk_max(lj.w[0], f.w[0]), c1 = pk_max(lj.w[1], f.w[1]);
+      const bool fdiv = (pk_subsat(f.w[0], a0) | (pk_subsat(f.w[1], a1) & 0xffffu)) == 0;
+      const bool eqi = ((a0 ^ b0) | ((a1 ^ b1) & 0xffffu)) == 0;
+      const bool eqj = ((a0 ^ c0) | ((a1 ^ c1) & 0xffffu)) == 0;
+      const bool keep = valid && !(fdiv && !eqi && !eqj);
+      const uint64_t mask = ballot64(keep);
+      if (keep) pairs[w + prefix_of(mask, lane)] = pr;
+      w += __popcll(mask);
+    }
+    nP = w;
+    // (78-91) new pairs (i, g): minimal lcms by degree peeling
+    {
+      const M2 lA = lm[lane], lB = lm[lane + 64];          // basis order; lanes >= g hold garbage (masked by valid)
+      const uint64_t validA = f_lowmask(g < 64 ? g : 64), validB = g > 64 ? f_lowmask(g - 64) : 0ull;
+      const M2 LA = m_lcm(lA, f), LB = m_lcm(lB, f);
+      const uint64_t cpA = ballot64(m_coprime(lA, f)) & validA, cpB = validB ? (ballot64(m_coprime(lB, f)) & validB) : 0ull;
+      const uint32_t dA = LA.w[1] >> 16, dB = LB.w[1] >> 16;
+      uint64_t candA = validA, candB = validB, emitA = 0, emitB = 0;
+      while (candA | candB) {
+        const bool inA = (candA >> lane) & 1, inB = (candB >> lane) & 1;
+        uint32_t dm = inA ? dA : 0xFFFFFFFFu;
+        if (candB) { const uint32_t t = inB ? dB : 0xFFFFFFFFu; dm = t < dm ? t : dm; }
+        const uint32_t dmin = f_wave_min(dm);
+        uint64_t survA = ballot64(inA && dA == dmin), survB = candB ? ballot64(inB && dB == dmin) : 0ull;
+        while (survA | survB) {
+          M2 Ls; int s;
+          if (survA) { s = __builtin_ctzll(survA); Ls = f_readlane(LA, s); }
+          else { s = __builtin_ctzll(survB); Ls = f_readlane(LB, s); s += 64; }
+          const uint64_t ls = f_u64(Ls);
+          const uint64_t eqA = ballot64(f_u64(LA) == ls), divA = ballot64(m_divides(Ls, LA));
+          uint64_t eqB = 0, divB = 0;
+          if (validB) { eqB = ballot64(f_u64(LB) == ls) & validB; divB = ballot64(m_divides(Ls, LB)); }
+          if (((eqA & validA & cpA) | (eqB & cpB)) == 0) { if (s < 64) emitA |= 1ull << s; else emitB |= 1ull << (s - 64); }
+          survA &= ~eqA; survB &= ~eqB;
+          candA &= ~divA; candB &= ~divB;
+        }
+      }
+      // (92) ascending i, appended behind the surviving old pairs (98)
+      if ((emitA >> lane) & 1) pairs[nP + prefix_of(emitA, lane)] = (uint32_t)lane | ((uint32_t)g << 16);
+      nP += __popcll(emitA);
+      if (emitB) {
+        if ((emitB >> lane) & 1) pairs[nP + prefix_of(emitB, lane)] = (uint32_t)(lane + 64) | ((uint32_t)g << 16);
+        nP += __popcll(emitB);
+      }
+    }
+    // sorted reducer insert: std::upper_bound by lead monomial (buchberger.cpp:323-324); sentinels compare greater
+    {
+      int pos = __popcll(ballot64(!m_gt(S.slmA, f)));
+      if (g >= 64) pos += __popcll(ballot64(!m_gt(S.slmB, f)));
+      const uint2 ns = make_uint2(t1.c | (inv << 16), (uint32_t)sugar | ((uint32_t)g << 16));
+      if (pos < 64) {
+        const uint32_t c0 = f_insert(S.slmA.w[0], f.w[0], pos, lane), c1 = f_insert(S.slmA.w[1], f.w[1], pos, lane);
+        const uint32_t c2 = f_insert(S.stmA.w[0], tail.w[0], pos, lane), c3 = f_insert(S.stmA.w[1], tail.w[1], pos, lane);
+        const uint32_t c4 = f_insert(S.sinA.x, ns.x, pos, lane), c5 = f_insert(S.sinA.y, ns.y, pos, lane);
+        if (g >= 64) {
+          f_shift_in(S.slmB.w[0], c0, lane); f_shift_in(S.slmB.w[1], c1, lane);
+          f_shift_in(S.stmB.w[0], c2, lane); f_shift_in(S.stmB.w[1], c3, lane);
+          f_shift_in(S.sinB.x, c4, lane); f_shift_in(S.sinB.y, c5, lane);
+        }
+      } else {
+        const int q = pos - 64;
+        f_insert(S.slmB.w[0], f.w[0], q, lane); f_insert(S.slmB.w[1], f.w[1], q, lane);
+        f_insert(S.stmB.w[0], tail.w[0], q, lane); f_insert(S.stmB.w[1], tail.w[1], q, lane);
+        f_insert(S.sinB.x, ns.x, q, lane); f_insert(S.sinB.y, ns.y, q, lane);
+      }
+    }
+    nG = g + 1;
+    wave_sync();
+  };
+
+  for (;;) {
+    if (status != BBX_ST_OK) break;
+    if (need_reset) {                                      // BuchbergerEnv::reset from the next queued ideal(s)
+      bool ok = true;
+      for (;;) {
+        const uint32_t* slot;
+        if (p.q_fixed) slot = p.qwords;
+        else {
+          const int tail = p.qtail[env];
+          if (q_head >= tail) { status = BBX_ST_STARVED; ok = false; break; }
+          slot = p.qwords + (size_t)env * p.q_env_stride + (size_t)(q_head % (int)p.q_nslots) * p.q_slot_words;
+        }
+        nG = 0; nP = 0;
+        S.slmA.w[0] = S.slmA.w[1] = S.slmB.w[0] = S.slmB.w[1] = FSENT;
+        const int npoly = uni((int)slot[0]);
+        const uint32_t* wq = slot + 1;
+        for (int fidx = 0; fidx < npoly; fidx++) {
+          const int nt = uni((int)wq[0]), sugar = uni((int)wq[1]);
+          if (nG + 1 > limG || nP + nG > limP) { status = BBX_ST_SPILL; ok = false; break; }
+          BTerm<2> t0, t1;
+          t0.c = (uint32_t)uni((int)wq[2]); t0.m.w[0] = (uint32_t)uni((int)wq[3]); t0.m.w[1] = (uint32_t)uni((int)wq[4]);
+          t1.c = 0; t1.m = m_zero<2>();
+          if (nt == 2) { t1.c = (uint32_t)uni((int)wq[5]); t1.m.w[0] = (uint32_t)uni((int)wq[6]); t1.m.w[1] = (uint32_t)uni((int)wq[7]); }
+          add_poly(t0, t1, sugar);
+          wq += 2 + nt * 3;
+        }
+        if (!ok) break;
+        if (!p.q_fixed) q_head++;
+        if (nP != 0 || p.q_fixed) break;                   // buchberger.cpp:313-314: redraw while the pair set is empty
+      }
+      if (!ok) { if (status == BBX_ST_SPILL) { nG = 0; nP = 0; } break; }
+      need_reset = 0;
+    }
+    if (budget <= 0 || nP == 0) break;
+    if (nG + 1 > limG || nP - 1 + nG > limP) { status = BBX_ST_SPILL; break; }   // before anything is modified
+
+    // ---- choose the pair -----------------------------------------------------------------------------------------
+    int action;
+    if (p.agent == BBX_AGENT_HASH) action = (int)(bbx_agent_hash32(agent_seed, (uint32_t)t_agent) % (uint32_t)nP);
+    else if (p.agent == BBX_AGENT_EXTERNAL) action = uni(p.actions[env]);
+    else if (p.agent == BBX_AGENT_FIRST) action = 0;
+    else {                                                 // degree: first row of minimal deg lcm (buchberger.cpp:171-176)
+      uint32_t best = 0xFFFFFFFFu;
+      for (int r = lane; r < nP; r += WAVE) {
+        const uint32_t pr = pairs[r];
+        const uint32_t key = (m_deg(m_lcm(lm[pr & 0xffffu], lm[pr >> 16])) << 16) | (uint32_t)r;   // deg < 2^16, r < 2^16
+        best = key < best ? key : best;
+      }
+      action = (int)(f_wave_min(best) & 0xffffu);
+    }
+    if (action < 0 || action >= nP) { status = BBX_ST_BAD_ACTION; break; }
+    const uint32_t pr = (uint32_t)uni((int)pairs[action]);
+    const int gi_ = pr & 0xffffu, gj_ = pr >> 16;
+    for (int base = action; base < nP - 1; base += WAVE) { // P.erase(remove(action)), stable
+      const int k = base + lane;
+      uint32_t v = 0;
+      if (k < nP - 1) v = pairs[k + 1];
+      wave_sync();
+      if (k < nP - 1) pairs[k] = v;
+      wave_sync();
+    }
+    nP -= 1;
+
+    // ---- S-polynomial (buchberger.cpp:18-21): the lead terms cancel, the scaled tails remain ------------------------
+    BTerm<2> h0, h1;
+    int hsug, bytes;
+    {
+      const M2 lmi = lm[gi_], lmj = lm[gj_];
+      const uint2 ii = gi[gi_], ij = gi[gj_];
+      const M2 gamma = m_lcm(lmi, lmj);
+      const M2 si = m_div(gamma, lmi), sj = m_div(gamma, lmj);
+      BTerm<2> a, b;
+      const uint32_t tci = ii.x >> 16, tcj = ij.x >> 16;
+      a.c = tci ? mulmod(tci, ii.y & 0xffffu) : 0u;           a.m = m_mul(tm[gi_], si);
+      b.c = tcj ? negmod(mulmod(tcj, ij.y & 0xffffu)) : 0u;   b.m = m_mul(tm[gj_], sj);
+      const int sgi = (int)(ii.y >> 16) + (int)m_deg(si), sgj = (int)(ij.y >> 16) + (int)m_deg(sj);
+      hsug = uni(sgi > sgj ? sgi : sgj);
+      if (hsug > 65535) { status = BBX_ST_DEG_OVERFLOW; break; }
+      merge2<2>(a, b, h0, h1);
+      bytes = 12 * ((tci ? 2 : 1) + (tcj ? 2 : 1) + (h0.c ? 1 : 0) + (h1.c ? 1 : 0));
+    }
+
+    // ---- reduce (buchberger.cpp:24-49), entirely in registers -----------------------------------------------------------
+    BTerm<2> r0, r1;
+    r0.c = 0; r1.c = 0; r0.m = m_zero<2>(); r1.m = m_zero<2>();
+    int nred = 0, rsug = 0;
+    bool overflow = false;
+    while (h0.c != 0) {
+      const int hn = h1.c ? 2 : 1;
+      const uint64_t mA = ballot64(m_divides(S.slmA, h0.m));        // sentinels never divide
+      int found = -1;
+      M2 lmg, tmg; uint2 sg;
+      if (mA) { found = __builtin_ctzll(mA); lmg = f_readlane(S.slmA, found); tmg = f_readlane(S.stmA, found); sg = f_readlane(S.sinA, found); }
+      else if (nG > 64) {
+        const uint64_t mB = ballot64(m_divides(S.slmB, h0.m));
+        if (mB) { const int l = __builtin_ctzll(mB); found = 64 + l; lmg = f_readlane(S.slmB, l); tmg = f_readlane(S.stmB, l); sg = f_readlane(S.sinB, l); }
+      }
+      if (found >= 0) {                                              // h <- h - (LT h / LT f) f
+        const uint32_t tcg = sg.x & 0xffffu, invg = sg.x >> 16;
+        const M2 q = m_div(h0.m, lmg);
+        const uint32_t c = mulmod(h0.c, invg);
+        BTerm<2> b;
+        b.c = tcg ? negmod(mulmod(c, tcg)) : 0u;
+        b.m = m_mul(tmg, q);
+        const int fs = (int)(sg.y & 0xffffu) + (int)m_deg(q);
+        hsug = fs > hsug ? fs : hsug;
+        if (hsug > 65535) { status = BBX_ST_DEG_OVERFLOW; overflow = true; break; }
+        BTerm<2> n0, n1;
+        merge2<2>(h1, b, n0, n1);
+        bytes += 8 * (found + 1) + 12 * (tcg ? 2 : 1) + 12 * (hn + (n0.c ? 1 : 0) + (n1.c ? 1 : 0));
+        h0 = n0; h1 = n1;
+        nred++;
+        if (nred > (1 << 24)) { status = BBX_ST_RUNAWAY; overflow = true; break; }
+      } else {                                                       // r <- r + LT h ; h <- h - LT h
+        bytes += 8 * nG + 12 * (2 * hn - 1);
+        if (r0.c == 0) r0 = h0; else r1 = h0;
+        const int d = (int)m_deg(h0.m);
+        rsug = d > rsug ? d : rsug;
+        h0 = h1; h1.c = 0;
+      }
+    }
+    if (overflow) break;
+    rsug = uni(rsug > hsug ? rsug : hsug);
+
+    // ---- basis / pair-set update (buchberger.cpp:321-327) ------------------------------------------------------------
+    const int nG_before = nG, nP_before = nP;
+    if (r0.c != 0) {
+      add_poly(r0, r1, rsug);
+      bytes += 12 * (r1.c ? 2 : 1) + 8 * nG_before + 8 * (nP_before + nP);
+    } else zero_red++;
+    bytes += nP * obs_row_bytes;
+    bytes_total += bytes;
+    const double reward = p.rewards_mode == BBX_REW_ADDITIONS ? (-1.0 - (double)nred) : -1.0;
+    last_reward = reward;
+    adds += 1 + nred; t_agent++; steps_done++;
+    const bool done = nP == 0;
+
+    if (p.obs_every_step && p.obs) write_obs(true, false);
+    if (TRACE && tracing) {
+      const uint64_t oh = write_obs(false, true);
+      uint64_t ph = 0;
+      for (int r = lane; r < nP; r += WAVE) {
+        const uint32_t q = pairs[r];
+        ph += bbx_mix64((uint64_t)(2 * r), q & 0xffffu) + bbx_mix64((uint64_t)(2 * r + 1), q >> 16);
+      }
+      ph = wave_sum64(ph);
+      uint64_t nh = 0;
+      if (nG > nG_before) {                                          // oracle/trace.py poly_words of the new element
+        if (lane == 0) {
+          nh = bbx_mix64(0, r1.c ? 2u : 1u) + bbx_mix64(1, r0.c);
+          for (int v = 0; v < BBX_MAXVARS; v++) nh += bbx_mix64(2 + v, v < 3 ? m_exp(r0.m, v) : 0u);
+          if (r1.c) {
+            nh += bbx_mix64(10, r1.c);
+            for (int v = 0; v < BBX_MAXVARS; v++) nh += bbx_mix64(11 + v, v < 3 ? m_exp(r1.m, v) : 0u);
+          }
+        }
+        nh = wave_sum64(nh);
+      }
+      if (lane == 0) {
+        BbxTraceRec& tr = p.trace[(size_t)env * p.trace_stride + rollout_pos];
+        tr.action = action; tr.nP = nP; tr.nG = nG; tr.done = done ? 1 : 0; tr.reward = reward;
+        tr.obs_hash = oh; tr.pairs_hash = ph; tr.newpoly_hash = nh;
+      }
+    }
+    budget--; rollout_pos++;
+    done_last = done ? 1 : 0;
+    if (done) { episodes++; if (p.auto_reset) need_reset = 1; }
+  }
+
+  const bool handoff = status == BBX_ST_SPILL;
+  if (p.obs && status == BBX_ST_OK) write_obs(true, false);
+  if (staged_in) {                                                   // write the live prefixes back to the HBM record
+    wave_sync();
+    if (lane < nG) { g_slm[lane] = S.slmA; g_stm[lane] = S.stmA; g_si[lane] = S.sinA; g_lm[lane] = lm[lane]; g_tm[lane] = tm[lane]; g_gi[lane] = gi[lane]; }
+    if (lane + 64 < nG) { g_slm[lane + 64] = S.slmB; g_stm[lane + 64] = S.stmB; g_si[lane + 64] = S.sinB;
+                          g_lm[lane + 64] = lm[lane + 64]; g_tm[lane + 64] = tm[lane + 64]; g_gi[lane + 64] = gi[lane + 64]; }
+    for (int i = lane; i < nP; i += WAVE) g_pr[i] = pairs[i];
+  }
+  if (lane == 0) {
+    BbxHdr* h = ghdr;
+    h->nG = nG; h->nP = nP; h->arena_used = 0; h->status = status; h->need_reset = need_reset;
+    h->q_head = q_head; h->t = t_agent; h->total_steps += steps_done; h->total_additions += adds;
+    h->episodes += episodes; h->zero_reductions += zero_red; h->steps_done = steps_done;
+    h->budget = budget; h->rollout_pos = rollout_pos; h->done_last = done_last; h->alg_bytes += bytes_total;
+    if (!handoff) {
+      if (p.rewards && (steps_done > 0 || p.pass == 0)) p.rewards[env] = last_reward;
+      if (p.dones) p.dones[env] = (uint8_t)((done_last || (nP == 0 && !need_reset)) ? 1 : 0);
+      if (p.rows) p.rows[env] = nP;
+    }
+  }
+}
+
+template <bool TRACE>
+__global__ __launch_bounds__(256) void bbx_fast_kernel(BbxFastParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  fast_body<TRACE>(p, smem);
+}

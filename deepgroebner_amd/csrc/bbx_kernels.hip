@@ -668,6 +668,7 @@ __global__ __launch_bounds__(256) void bbx_aux_kernel(BbxParams p) {
 }
 
 #include "bbx_binom.h"
+#include "bbx_fast.h"
 
 // ------------------------------------------------------------------ housekeeping kernels
 // zero the headers and set the per-environment agent seeds
@@ -731,9 +732,26 @@ static int launch_w(const BbxParams* p, int kind, int blocks, int threads, size_
   else { if (trace) BBX_LAUNCH((bbx_step_kernel<W, false, true>)); else BBX_LAUNCH((bbx_step_kernel<W, false, false>)); }
   return 0;
 }
+// kind 3: the hand-tuned LDS/register-resident kernel (bbx_fast.h) for W == 2 binomial, GM, sorted reducers
+static int launch_fast(const BbxParams* p, int blocks, int threads, int envs_per_block, hipStream_t stream) {
+  BbxFastParams f{};
+  f.recs = p->recs; f.qwords = p->q.words; f.qtail = p->q.tail; f.inv_table = p->inv_table;
+  f.actions = p->actions; f.rewards = p->rewards; f.dones = p->dones; f.rows = p->rows; f.obs = p->obs; f.trace = p->trace;
+  f.rec_bytes = p->L.rec_bytes; f.hbmG = p->L.maxG;
+  f.q_env_stride = p->q.env_stride; f.q_slot_words = p->q.slot_words; f.q_nslots = p->q.nslots; f.q_fixed = p->q.fixed;
+  f.B = p->B; f.nsteps = p->nsteps; f.obs_rows = p->obs_rows; f.trace_stride = p->trace_stride; f.k = p->k; f.nvars = p->nvars;
+  f.lim_G = (int)p->LL.maxG; f.lim_P = (int)p->LL.maxP;
+  f.agent = p->agent; f.auto_reset = p->auto_reset; f.set_budget = p->set_budget; f.pass = p->pass;
+  f.obs_every_step = p->obs_every_step; f.obs_fill = p->obs_fill; f.rewards_mode = p->rewards_mode;
+  const size_t lds = (size_t)envs_per_block * FLDS_BYTES;
+  if (p->trace) hipLaunchKernelGGL((bbx_fast_kernel<true>), dim3(blocks), dim3(threads), lds, stream, f);
+  else hipLaunchKernelGGL((bbx_fast_kernel<false>), dim3(blocks), dim3(threads), lds, stream, f);
+  return 0;
+}
 extern "C" int bbx_launch_step(const BbxParams* p, int kind, int envs_per_block, hipStream_t stream) {
   const int threads = envs_per_block * WAVE;
   const int blocks = (p->B + envs_per_block - 1) / envs_per_block;
+  if (kind == 3) { launch_fast(p, blocks, threads, envs_per_block, stream); return (int)hipGetLastError(); }
   const size_t lds = kind == 1 ? (size_t)envs_per_block * p->LL.rec_bytes : 0;
   int rc = p->L.W == 2 ? launch_w<2>(p, kind, blocks, threads, lds, stream) : launch_w<4>(p, kind, blocks, threads, lds, stream);
   if (rc) return rc;

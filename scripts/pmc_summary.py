@@ -1,0 +1,19 @@
+"""Summarise rocprofv3 --pmc passes written by scripts/pmc_passes.sh: counters of the longest step-kernel dispatch."""
+import collections, csv, glob, json, sys
+tag = sys.argv[1]
+out = {}
+kname = None
+for f in sorted(glob.glob('gpurun_out/pmc_%s_*/p_counter_collection.csv' % tag)):
+    by = collections.defaultdict(dict)
+    names = {}
+    dur = {}
+    for r in csv.DictReader(open(f)):
+        if 'bbx_' in r['Kernel_Name'] and ('step_kernel' in r['Kernel_Name'] or 'binom_kernel' in r['Kernel_Name']):
+            by[r['Dispatch_Id']][r['Counter_Name']] = float(r['Counter_Value'])
+            names[r['Dispatch_Id']] = r['Kernel_Name']
+            dur[r['Dispatch_Id']] = int(r['End_Timestamp']) - int(r['Start_Timestamp'])
+    if not by:
+        continue
+    d = max(dur, key=dur.get)
+    out.update(by[d]); kname = names[d]; out.setdefault('_dispatch_ns', []).append(dur[d])
+print(json.dumps({"kernel": kname, "counters": out}, indent=1))
