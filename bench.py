@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--dist", default=DIST)
     ap.add_argument("--chunk", type=int, default=0, help="steps per kernel launch (0 = all K in one launch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ablate-obs", action="store_true", help="diagnostic only: do not write per-step observations")
     ap.add_argument("--cpu-sample-envs", type=int, default=0)
     args = ap.parse_args()
 
@@ -86,7 +87,7 @@ def main():
         done = 0
         while done < nsteps:
             n = min(chunk, nsteps - done)
-            env.rollout_device("random", n, True, stream.cuda_stream, d_rew, d_done, d_rows, d_obs, obs_rows, False, True)
+            env.rollout_device("random", n, True, stream.cuda_stream, d_rew, d_done, d_rows, d_obs, obs_rows, False, not args.ablate_obs)
             env.sync()
             done += n
 
@@ -94,6 +95,8 @@ def main():
         run(Wm)
     env.prefetch()                                  # inputs for the timed region resident in HBM
     st0 = env.stats()
+    twin = env.copy()                               # same state, same queued ideals: used after the timed region
+    env.accounting(False)                           # timed run: lean kernel (no per-step byte counting)
     env.timing(True)
     torch.cuda.synchronize()
     if world > 1:
@@ -116,7 +119,13 @@ def main():
     assert steps_done == K * B, "every environment must have executed exactly K steps (%d != %d)" % (steps_done, K * B)
     assert (st1[:, 4] == 0).all(), "an environment reported an error status"
     additions = int(d[:, 1].sum())
-    alg_bytes = int(d[:, 6].sum())
+    # algorithmic bytes of exactly these K steps: replay them on the twin with the accounting kernel (untimed)
+    twin.accounting(True)
+    twin.rollout("random", K, auto_reset=True)
+    dt = twin.stats() - st0
+    assert np.array_equal(dt[:, :2], d[:, :2]) and np.array_equal(twin.stats()[:, 7], st1[:, 7]), "accounting replay diverged"
+    alg_bytes = int(dt[:, 6].sum())
+    del twin
 
     if world > 1:
         t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda")

@@ -60,6 +60,7 @@ SIGNATURES = {
     "bbx_step_device": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp]),
     "bbx_rollout_device": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "bbx_prefetch": (C.c_int, [_vp]),
+    "bbx_accounting": (C.c_int, [_vp, C.c_int]),
     "bbx_timing": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_double), _i32p]),
     "bbx_sync": (C.c_int, [_vp]),
     "bbx_stats": (C.c_int, [_vp, _vp]),

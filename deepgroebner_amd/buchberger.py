@@ -160,6 +160,10 @@ class VecLeadMonomialsEnv:
     def sync(self):
         _ffi.check(_ffi.lib().bbx_sync(self._h))
 
+    def accounting(self, enable):
+        """Toggle per-step algorithmic-byte accounting (stats()[:, 6]); off selects the leanest kernel."""
+        _ffi.check(_ffi.lib().bbx_accounting(self._h, int(enable)))
+
     def prefetch(self):
         """Generate and upload ideals until every environment's ring is full."""
         _ffi.check(_ffi.lib().bbx_prefetch(self._h))

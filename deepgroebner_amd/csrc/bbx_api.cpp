@@ -98,6 +98,7 @@ struct bbx_batch {
   BbxTraceRec* d_trace = nullptr; int trace_cap = 0;
   BbxHdr* d_hdr = nullptr;            // compact header copy (bbx_gather_hdr_kernel)
   // HIP-event timing of the step-kernel launches (bbx_timing)
+  bool accounting = true;             // count algorithmic bytes (bbx_accounting)
   bool timing = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_open;
   double kernel_ms = 0.0; int kernel_launches = 0;
@@ -224,6 +225,7 @@ void fill_params(bbx_batch* b, BbxParams* p) {
   p->elim = b->elim; p->rewards_mode = b->rewards; p->sort_reducers = b->sort_reducers; p->k = b->k; p->nvars = b->nvars;
   p->trace = b->d_trace; p->trace_stride = b->trace_cap;
   p->inv_table = b->d_inv;
+  p->accounting = b->accounting ? 1 : 0;
 }
 
 // enqueue the kernels of one logical launch: the LDS-staged pass (when the class allows) followed by the
@@ -459,7 +461,7 @@ int bbx_copy(const bbx_batch* s, bbx_batch** out) {
   b->elim = s->elim; b->rewards = s->rewards; b->sort_input = s->sort_input; b->sort_reducers = s->sort_reducers;
   b->fixed = s->fixed; b->binom = s->binom; b->L = s->L; b->LL = s->LL; b->slot_words = s->slot_words; b->nslots = s->nslots;
   b->h_q = s->h_q; b->h_tail = s->h_tail; b->h_head = s->h_head; b->q_dirty = true;
-  b->staged = s->staged; b->fast = s->fast; b->envs_per_block = s->envs_per_block;
+  b->accounting = s->accounting; b->staged = s->staged; b->fast = s->fast; b->envs_per_block = s->envs_per_block;
   for (auto& g : s->gens) b->gens.push_back(g->clone());
   const int batch = s->B;
   HIPCHK(hipMalloc((void**)&b->d_recs, (size_t)batch * b->L.rec_bytes));
@@ -573,6 +575,12 @@ int bbx_sync(bbx_batch* b) {
   HIPCHK(hipSetDevice(b->device));
   if (!b->in_flight) { HIPCHK(hipDeviceSynchronize()); return BBX_OK; }
   return finish(b, b->last_stream);
+}
+
+int bbx_accounting(bbx_batch* b, int enable) {
+  if (!b) return fail(BBX_E_ARG, "null argument");
+  b->accounting = enable != 0;
+  return BBX_OK;
 }
 
 int bbx_prefetch(bbx_batch* b) {

@@ -35,12 +35,16 @@ template <int W> struct BTerm { Mono<W> m; uint32_t c; };
 // (x) + (y) for single optional terms: polynomials.cpp:148-177 restricted to one term per side
 template <int W>
 __device__ __forceinline__ void merge2(const BTerm<W>& x, const BTerm<W>& y, BTerm<W>& o0, BTerm<W>& o1) {
-  o1.m = m_zero<W>(); o1.c = 0;
-  if (x.c == 0) { o0 = y; return; }
-  if (y.c == 0) { o0 = x; return; }
-  if (m_gt(x.m, y.m)) { o0 = x; o1 = y; return; }
-  if (m_gt(y.m, x.m)) { o0 = y; o1 = x; return; }
-  o0.m = x.m; o0.c = addmod(x.c, y.c);          // equal monomials: sum, a zero sum drops the term
+  // select form (no branches): which of x / y leads, or both collapse into one term
+  const bool hx = x.c != 0, hy = y.c != 0;
+  const bool xgt = m_gt(x.m, y.m), ygt = m_gt(y.m, x.m);
+  const bool same = hx && hy && !xgt && !ygt;             // equal monomials: sum, a zero sum drops the term
+  const bool xfirst = hx && (!hy || xgt || same);
+  const uint32_t sum = addmod(x.c, y.c);
+  o0.c = same ? sum : (xfirst ? x.c : y.c);
+  o1.c = (hx && hy && !same) ? (xfirst ? y.c : x.c) : 0u;
+#pragma unroll
+  for (int i = 0; i < W; i++) { o0.m.w[i] = xfirst ? x.m.w[i] : y.m.w[i]; o1.m.w[i] = xfirst ? y.m.w[i] : x.m.w[i]; }
 }
 
 template <int W>

@@ -116,6 +116,7 @@ struct BbxParams {
   int32_t obs_fill;         // 1: pad rows [nP, obs_rows) with -1
   int32_t obs_every_step;   // 1: materialise the observation after every step (what a policy consumes),
                             // 0: only for the state the caller sees when the launch ends
+  int32_t accounting;       // 1: count algorithmic bytes per step (BbxHdr.alg_bytes); the lean fast kernel omits it
   int32_t pass;             // 0: primary launch; 1: follow-up launch serving only environments with work left
   const uint16_t* inv_table; // [32003] inverses in GF(32003) (L2-resident), binomial class
   BbxTraceRec* trace;       // [B, trace_stride] or null

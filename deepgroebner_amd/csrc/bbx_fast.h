@@ -46,6 +46,11 @@ __device__ __forceinline__ uint32_t f_wave_min(uint32_t x) {
 #undef FDPPMIN
   return f_readlane(x, 63);
 }
+// fetch element l of a register array INTO A VGPR (ds_bpermute: LDS crossbar, no LDS memory): the arithmetic that
+// follows then runs on the under-used vector ALUs instead of the scalar unit all 16 waves of a CU share
+__device__ __forceinline__ uint32_t f_fetch(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_ds_bpermute(l << 2, (int)v); }
+__device__ __forceinline__ M2 f_fetch(const M2& v, int l) { M2 r; r.w[0] = f_fetch(v.w[0], l); r.w[1] = f_fetch(v.w[1], l); return r; }
+__device__ __forceinline__ uint2 f_fetch(const uint2& v, int l) { return make_uint2(f_fetch(v.x, l), f_fetch(v.y, l)); }
 __device__ __forceinline__ uint64_t f_u64(const M2& m) { return ((uint64_t)m.w[1] << 32) | m.w[0]; }
 __device__ __forceinline__ uint64_t f_lowmask(int n) { return n >= 64 ? ~0ull : ((1ull << n) - 1ull); }   // n in [0,64]
 
@@ -67,7 +72,10 @@ struct FastState {                 // reducer-order arrays, lane l <-> reducers 
   uint2 sinA, sinB;                // .x = tc | (1/lc) << 16 ; .y = sugar | basis index << 16
 };
 
-template <bool TRACE>
+// TRACE: per-step parity hashes (tests).  ACCT: count the algorithmic bytes of every step (roofline numerator;
+// a property of the workload, so the lean production variant leaves it out and bench.py obtains it from an
+// accounting run over a copy of the same batch).
+template <bool TRACE, bool ACCT>
 __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
   const int lane = lane_id();
   const int wave_in_block = uni((int)(threadIdx.x / WAVE));
@@ -338,23 +346,22 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
       hsug = uni(sgi > sgj ? sgi : sgj);
       if (hsug > 65535) { status = BBX_ST_DEG_OVERFLOW; break; }
       merge2<2>(a, b, h0, h1);
-      bytes = 12 * ((tci ? 2 : 1) + (tcj ? 2 : 1) + (h0.c ? 1 : 0) + (h1.c ? 1 : 0));
+      bytes = ACCT ? 12 * ((tci ? 2 : 1) + (tcj ? 2 : 1) + (h0.c ? 1 : 0) + (h1.c ? 1 : 0)) : 0;
     }
 
     // ---- reduce (buchberger.cpp:24-49), entirely in registers -----------------------------------------------------------
     BTerm<2> r0, r1;
     r0.c = 0; r1.c = 0; r0.m = m_zero<2>(); r1.m = m_zero<2>();
     int nred = 0, rsug = 0;
-    bool overflow = false;
-    while (h0.c != 0) {
+    while (uni((int)h0.c) != 0) {
       const int hn = h1.c ? 2 : 1;
       const uint64_t mA = ballot64(m_divides(S.slmA, h0.m));        // sentinels never divide
       int found = -1;
       M2 lmg, tmg; uint2 sg;
-      if (mA) { found = __builtin_ctzll(mA); lmg = f_readlane(S.slmA, found); tmg = f_readlane(S.stmA, found); sg = f_readlane(S.sinA, found); }
+      if (mA) { found = __builtin_ctzll(mA); lmg = f_fetch(S.slmA, found); tmg = f_fetch(S.stmA, found); sg = f_fetch(S.sinA, found); }
       else if (nG > 64) {
         const uint64_t mB = ballot64(m_divides(S.slmB, h0.m));
-        if (mB) { const int l = __builtin_ctzll(mB); found = 64 + l; lmg = f_readlane(S.slmB, l); tmg = f_readlane(S.stmB, l); sg = f_readlane(S.sinB, l); }
+        if (mB) { const int l = __builtin_ctzll(mB); found = 64 + l; lmg = f_fetch(S.slmB, l); tmg = f_fetch(S.stmB, l); sg = f_fetch(S.sinB, l); }
       }
       if (found >= 0) {                                              // h <- h - (LT h / LT f) f
         const uint32_t tcg = sg.x & 0xffffu, invg = sg.x >> 16;
@@ -364,33 +371,30 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
         b.c = tcg ? negmod(mulmod(c, tcg)) : 0u;
         b.m = m_mul(tmg, q);
         const int fs = (int)(sg.y & 0xffffu) + (int)m_deg(q);
-        hsug = fs > hsug ? fs : hsug;
-        if (hsug > 65535) { status = BBX_ST_DEG_OVERFLOW; overflow = true; break; }
+        hsug = fs > hsug ? fs : hsug;                  // checked once after the loop: nothing is modified until then
         BTerm<2> n0, n1;
         merge2<2>(h1, b, n0, n1);
-        bytes += 8 * (found + 1) + 12 * (tcg ? 2 : 1) + 12 * (hn + (n0.c ? 1 : 0) + (n1.c ? 1 : 0));
+        if (ACCT) bytes += 8 * (found + 1) + 12 * (tcg ? 2 : 1) + 12 * (hn + (n0.c ? 1 : 0) + (n1.c ? 1 : 0));
         h0 = n0; h1 = n1;
-        nred++;
-        if (nred > (1 << 24)) { status = BBX_ST_RUNAWAY; overflow = true; break; }
+        nred++;                                        // (terminates: the lead monomial strictly decreases)
       } else {                                                       // r <- r + LT h ; h <- h - LT h
-        bytes += 8 * nG + 12 * (2 * hn - 1);
+        if (ACCT) bytes += 8 * nG + 12 * (2 * hn - 1);
         if (r0.c == 0) r0 = h0; else r1 = h0;
         const int d = (int)m_deg(h0.m);
         rsug = d > rsug ? d : rsug;
         h0 = h1; h1.c = 0;
       }
     }
-    if (overflow) break;
+    if (hsug > 65535) { status = BBX_ST_DEG_OVERFLOW; break; }
     rsug = uni(rsug > hsug ? rsug : hsug);
 
     // ---- basis / pair-set update (buchberger.cpp:321-327) ------------------------------------------------------------
     const int nG_before = nG, nP_before = nP;
     if (r0.c != 0) {
       add_poly(r0, r1, rsug);
-      bytes += 12 * (r1.c ? 2 : 1) + 8 * nG_before + 8 * (nP_before + nP);
+      if (ACCT) bytes += 12 * (r1.c ? 2 : 1) + 8 * nG_before + 8 * (nP_before + nP);
     } else zero_red++;
-    bytes += nP * obs_row_bytes;
-    bytes_total += bytes;
+    if (ACCT) { bytes += nP * obs_row_bytes; bytes_total += bytes; }
     const double reward = p.rewards_mode == BBX_REW_ADDITIONS ? (-1.0 - (double)nred) : -1.0;
     last_reward = reward;
     adds += 1 + nred; t_agent++; steps_done++;
@@ -451,8 +455,8 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
   }
 }
 
-template <bool TRACE>
+template <bool TRACE, bool ACCT>
 __global__ __launch_bounds__(256) void bbx_fast_kernel(BbxFastParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  fast_body<TRACE>(p, smem);
+  fast_body<TRACE, ACCT>(p, smem);
 }

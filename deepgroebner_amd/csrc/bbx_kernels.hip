@@ -744,8 +744,9 @@ static int launch_fast(const BbxParams* p, int blocks, int threads, int envs_per
   f.agent = p->agent; f.auto_reset = p->auto_reset; f.set_budget = p->set_budget; f.pass = p->pass;
   f.obs_every_step = p->obs_every_step; f.obs_fill = p->obs_fill; f.rewards_mode = p->rewards_mode;
   const size_t lds = (size_t)envs_per_block * FLDS_BYTES;
-  if (p->trace) hipLaunchKernelGGL((bbx_fast_kernel<true>), dim3(blocks), dim3(threads), lds, stream, f);
-  else hipLaunchKernelGGL((bbx_fast_kernel<false>), dim3(blocks), dim3(threads), lds, stream, f);
+  if (p->trace) hipLaunchKernelGGL((bbx_fast_kernel<true, true>), dim3(blocks), dim3(threads), lds, stream, f);
+  else if (p->accounting) hipLaunchKernelGGL((bbx_fast_kernel<false, true>), dim3(blocks), dim3(threads), lds, stream, f);
+  else hipLaunchKernelGGL((bbx_fast_kernel<false, false>), dim3(blocks), dim3(threads), lds, stream, f);
   return 0;
 }
 extern "C" int bbx_launch_step(const BbxParams* p, int kind, int envs_per_block, hipStream_t stream) {

@@ -121,6 +121,11 @@ int bbx_rollout_device(bbx_batch* b, int agent, int nsteps, int auto_reset, doub
  * wait for ideals; returns BBX_E_CAPACITY etc. if any environment failed */
 int bbx_sync(bbx_batch* b);
 
+/* Algorithmic-byte accounting (stats column 6, the roofline numerator) is on by default; the hand-tuned kernel
+ * has a leaner variant without it, selected by bbx_accounting(b, 0).  The count is a property of the workload:
+ * bench.py times the lean variant and takes the bytes from an accounting run over a bbx_copy of the same batch. */
+int bbx_accounting(bbx_batch* b, int enable);
+
 /* Tops every environment's ring of pre-generated ideals up to queue_slots and uploads them, so that the
  * following rollouts find their inputs resident in HBM (launches themselves only refill EMPTY rings). */
 int bbx_prefetch(bbx_batch* b);

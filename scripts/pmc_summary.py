@@ -8,7 +8,7 @@ for f in sorted(glob.glob('gpurun_out/pmc_%s_*/p_counter_collection.csv' % tag))
     names = {}
     dur = {}
     for r in csv.DictReader(open(f)):
-        if 'bbx_' in r['Kernel_Name'] and ('step_kernel' in r['Kernel_Name'] or 'binom_kernel' in r['Kernel_Name']):
+        if 'bbx_' in r['Kernel_Name'] and any(t in r['Kernel_Name'] for t in ('step_kernel', 'binom_kernel', 'fast_kernel')):
             by[r['Dispatch_Id']][r['Counter_Name']] = float(r['Counter_Value'])
             names[r['Dispatch_Id']] = r['Kernel_Name']
             dur[r['Dispatch_Id']] = int(r['End_Timestamp']) - int(r['Start_Timestamp'])
