@@ -32,8 +32,8 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=256)
-    ap.add_argument("--warmup", type=int, default=32)
+    ap.add_argument("--steps", type=int, default=1024)
+    ap.add_argument("--warmup", type=int, default=64)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--dist", default=DIST)
     ap.add_argument("--chunk", type=int, default=0, help="steps per kernel launch (0 = all K in one launch)")
@@ -155,7 +155,7 @@ def main():
             "additions_per_s": additions / elapsed,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "bbx_step_kernel", "alg_bytes_per_env_step": alg_bytes / steps_done,
+                         "kernel": "bbx_fast_kernel<false,false>", "alg_bytes_per_env_step": alg_bytes / steps_done,
                          "kernel_ms_per_launch": kernel_ms / nlaunch, "launches": nlaunch, "timed_region_ms": region_ms},
             "cpu_baseline": cpu,
         }

@@ -76,6 +76,7 @@ SIGNATURES = {
     "bbx_gen_next": (C.c_int, [_vp, _i32p, _i32p]),
     "bbx_gen_get": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "bbx_agent_hash": (C.c_uint32, [C.c_uint32, C.c_uint32]),
+    "bbx_agent_action": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_uint32]),
     "bbx_last_error": (C.c_char_p, []),
     "bbx_version": (C.c_char_p, []),
 }

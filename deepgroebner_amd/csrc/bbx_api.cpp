@@ -341,7 +341,7 @@ int create_common(std::unique_ptr<bbx::IdealGen> proto, int nvars_obs, int elimi
     if (!c.max_basis) c.max_basis = 4096; if (!c.max_pairs) c.max_pairs = 16384;
     if (!c.arena_terms) c.arena_terms = 1 << 20; if (!c.max_poly_terms) c.max_poly_terms = 8192;
   } else if (binomial) {
-    if (!c.max_basis) c.max_basis = b->W == 2 ? 512 : 4096; if (!c.max_pairs) c.max_pairs = b->W == 2 ? 2048 : 16384;
+    if (!c.max_basis) c.max_basis = b->W == 2 ? 512 : 4096; if (!c.max_pairs) c.max_pairs = b->W == 2 ? (elimination == BBX_GEBAUERMOELLER ? 4096 : 32768) : 16384;
     if (!c.arena_terms) c.arena_terms = 2 * c.max_basis + 16; if (!c.max_poly_terms) c.max_poly_terms = 8;
   } else {
     if (!c.max_basis) c.max_basis = 2048; if (!c.max_pairs) c.max_pairs = 8192;
@@ -414,6 +414,7 @@ extern "C" {
 const char* bbx_last_error(void) { return g_err.c_str(); }
 const char* bbx_version(void) { return "bbx 0.1 (gfx950)"; }
 uint32_t bbx_agent_hash(uint32_t seed, uint32_t t) { return bbx_agent_hash32(seed, t); }
+uint32_t bbx_agent_action(uint32_t seed, uint32_t t, uint32_t rows) { return bbx_agent_action32(seed, t, rows); }
 
 int bbx_create(const char* ideal_dist, int elimination, int rewards, int sort_input, int sort_reducers,
                int k, int batch, int device, const bbx_caps* caps, bbx_batch** out) {

@@ -262,7 +262,7 @@ __device__ __forceinline__ void binom_body(const BbxParams& p, char* smem) {
     // ---- choose the pair ------------------------------------------------------------------------
     int action;
     if (p.agent == BBX_AGENT_EXTERNAL) action = p.actions[env];
-    else if (p.agent == BBX_AGENT_HASH) action = (int)(bbx_agent_hash32(agent_seed, (uint32_t)t_agent) % (uint32_t)nP);
+    else if (p.agent == BBX_AGENT_HASH) action = (int)bbx_agent_action32(agent_seed, (uint32_t)t_agent, (uint32_t)nP);
     else if (p.agent == BBX_AGENT_FIRST) action = 0;
     else {
       uint64_t best = ~0ull;

@@ -142,3 +142,11 @@ __host__ __device__
 uint32_t bbx_agent_hash32(uint32_t seed, uint32_t t) {
   return (uint32_t)(bbx_mix64((uint64_t)seed, t) >> 32);
 }
+// the row the built-in random agent picks among `rows`: multiply-shift range reduction (one mul_hi on the device)
+static inline
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+uint32_t bbx_agent_action32(uint32_t seed, uint32_t t, uint32_t rows) {
+  return (uint32_t)(((uint64_t)bbx_agent_hash32(seed, t) * rows) >> 32);
+}

@@ -32,6 +32,7 @@ struct BbxFastParams {
   uint32_t q_env_stride, q_slot_words, q_nslots, q_fixed;
   int32_t B, nsteps, obs_rows, trace_stride, k, nvars, lim_G, lim_P;
   int32_t agent, auto_reset, set_budget, pass, obs_every_step, obs_fill, rewards_mode;
+  unsigned long long* prof;                           // diagnostic build only: [B][8] cycle sums per phase
 };
 
 __device__ __forceinline__ uint32_t f_readlane(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
@@ -75,8 +76,11 @@ struct FastState {                 // reducer-order arrays, lane l <-> reducers 
 // TRACE: per-step parity hashes (tests).  ACCT: count the algorithmic bytes of every step (roofline numerator;
 // a property of the workload, so the lean production variant leaves it out and bench.py obtains it from an
 // accounting run over a copy of the same batch).
-template <bool TRACE, bool ACCT>
+#define FSTAMP(slot) do { if (PROF) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); prof_sum[slot] += t_ - prof_last; prof_last = t_; } } while (0)
+template <bool TRACE, bool ACCT, bool PROF = false>
 __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
+  unsigned long long prof_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long prof_last = PROF ? __builtin_amdgcn_s_memtime() : 0;
   const int lane = lane_id();
   const int wave_in_block = uni((int)(threadIdx.x / WAVE));
   const int env = blockIdx.x * (blockDim.x / WAVE) + wave_in_block;
@@ -121,6 +125,8 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
     }
   }
 
+  // the random agent's hashes for 64 consecutive steps at a time, one per lane (recomputed every 64 steps)
+  uint32_t hv = bbx_agent_hash32(agent_seed, (uint32_t)((t_agent & ~63) + lane));
   int steps_done = 0, adds = 0, episodes = 0, zero_red = 0;
   long long bytes_total = 0;
   double last_reward = 0.0;
@@ -140,25 +146,30 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
     uint64_t h = 0;
     if (rows_per_sweep > 0) {
       const int half = o_slot >= kk ? 1 : 0, t = o_slot - half * kk;
-      for (int r0 = 0; r0 < rows; r0 += rows_per_sweep) {
-        const int r = r0 + o_rl;
-        if (o_rl < rows_per_sweep && r < rows) {
-          const uint32_t pr = pairs[r];
-          const int g = half ? (int)(pr >> 16) : (int)(pr & 0xffffu);
-          M2 mm = m_zero<2>();
-          if (t == 0) mm = lm[g]; else if (t == 1) mm = tm[g];      // tm[g] is the zero monomial when G[g] has no tail
-          const int base = (r * per_row + o_slot) * n;
-          const uint32_t e0 = mm.w[0] & 0xffffu, e1 = mm.w[0] >> 16, e2 = mm.w[1] & 0xffffu;
-          if (out) {
-            if (n == 3) { int3 v3 = make_int3((int)e0, (int)e1, (int)e2); *(int3*)(out + base) = v3; }
-            else { out[base] = (int)e0; if (n > 1) out[base + 1] = (int)e1; }
-          }
-          if (TRACE && want_hash) {
-            h += bbx_mix64((uint64_t)base, e0);
-            if (n > 1) h += bbx_mix64((uint64_t)(base + 1), e1);
-            if (n > 2) h += bbx_mix64((uint64_t)(base + 2), e2);
-          }
+      const bool lane_on = o_rl < rows_per_sweep;
+      auto emit = [&](int r, const M2& mm) {
+        const int base = (r * per_row + o_slot) * n;
+        const uint32_t e0 = mm.w[0] & 0xffffu, e1 = mm.w[0] >> 16, e2 = mm.w[1] & 0xffffu;
+        if (out) {
+          if (n == 3) { int3 v3 = make_int3((int)e0, (int)e1, (int)e2); *(int3*)(out + base) = v3; }
+          else { out[base] = (int)e0; if (n > 1) out[base + 1] = (int)e1; }
         }
+        if (TRACE && want_hash) {
+          h += bbx_mix64((uint64_t)base, e0);
+          if (n > 1) h += bbx_mix64((uint64_t)(base + 1), e1);
+          if (n > 2) h += bbx_mix64((uint64_t)(base + 2), e2);
+        }
+      };
+      // two sweeps per trip: both pair loads, then both monomial loads, are in flight together
+      for (int r0 = 0; r0 < rows; r0 += 2 * rows_per_sweep) {
+        const int ra = r0 + o_rl, rb = ra + rows_per_sweep;
+        const bool oa = lane_on && ra < rows, ob = lane_on && rb < rows;
+        const uint32_t pa = oa ? pairs[ra] : 0u, pb = ob ? pairs[rb] : 0u;
+        const int ga = half ? (int)(pa >> 16) : (int)(pa & 0xffffu), gb = half ? (int)(pb >> 16) : (int)(pb & 0xffffu);
+        M2 ma = m_zero<2>(), mb = m_zero<2>();
+        if (t == 0) { ma = lm[ga]; mb = lm[gb]; } else if (t == 1) { ma = tm[ga]; mb = tm[gb]; }   // tm is zero when G has no tail
+        if (oa) emit(ra, ma);
+        if (ob) emit(rb, mb);
       }
     } else {
       for (int it = lane; it < rows * per_row; it += WAVE) {
@@ -181,12 +192,16 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
 
   // append the binomial (t0, t1) to the basis: G-order arrays, Gebauer-Moeller update, sorted reducer insert
   // (buchberger.cpp:52-99 + 321-326).  The caller has checked the capacities.
-  auto add_poly = [&](const BTerm<2>& t0, const BTerm<2>& t1, int sugar) {
+  // `skip` >= 0: the pair at that index has just been selected and is removed by the same compaction pass
+  // (P.erase(remove(action)), buchberger.cpp:319) instead of a separate shift of the list
+  auto add_poly = [&](const BTerm<2>& t0, const BTerm<2>& t1, int sugar, int skip) {
     const int g = nG;                                     // == m of update()
-    const uint32_t inv = t0.c == 1 ? 1u : (uint32_t)uni((int)p.inv_table[t0.c]);
+    // 1/LC comes from a table in HBM/L2: issue the load now, consume it at the very end (the pair update below
+    // does not need it), so its latency overlaps the Gebauer-Moeller work
+    const uint32_t inv_raw = t0.c == 1 ? 1u : (uint32_t)p.inv_table[t0.c];
     const M2 f = t0.m;
     const M2 tail = t1.c ? t1.m : m_zero<2>();
-    if (lane == 0) { lm[g] = f; tm[g] = tail; gi[g] = make_uint2(t0.c | (t1.c << 16), inv | ((uint32_t)sugar << 16)); }
+    if (lane == 0) { lm[g] = f; tm[g] = tail; }
     // (70-76) drop old pairs (i,j): LM f | lcm_ij and lcm_ij != lcm_if and lcm_ij != lcm_jf.  Only exponents matter,
     // so the lcms are raw v_pk_max words with the degree slot masked out of the comparisons.
     int w = 0;
@@ -201,7 +216,7 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
       const bool fdiv = (pk_subsat(f.w[0], a0) | (pk_subsat(f.w[1], a1) & 0xffffu)) == 0;
       const bool eqi = ((a0 ^ b0) | ((a1 ^ b1) & 0xffffu)) == 0;
       const bool eqj = ((a0 ^ c0) | ((a1 ^ c1) & 0xffffu)) == 0;
-      const bool keep = valid && !(fdiv && !eqi && !eqj);
+      const bool keep = valid && k != skip && !(fdiv && !eqi && !eqj);
       const uint64_t mask = ballot64(keep);
       if (keep) pairs[w + prefix_of(mask, lane)] = pr;
       w += __popcll(mask);
@@ -246,6 +261,8 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
     {
       int pos = __popcll(ballot64(!m_gt(S.slmA, f)));
       if (g >= 64) pos += __popcll(ballot64(!m_gt(S.slmB, f)));
+      const uint32_t inv = inv_raw;
+      if (lane == 0) gi[g] = make_uint2(t0.c | (t1.c << 16), inv | ((uint32_t)sugar << 16));
       const uint2 ns = make_uint2(t1.c | (inv << 16), (uint32_t)sugar | ((uint32_t)g << 16));
       if (pos < 64) {
         const uint32_t c0 = f_insert(S.slmA.w[0], f.w[0], pos, lane), c1 = f_insert(S.slmA.w[1], f.w[1], pos, lane);
@@ -281,17 +298,29 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
         }
         nG = 0; nP = 0;
         S.slmA.w[0] = S.slmA.w[1] = S.slmB.w[0] = S.slmB.w[1] = FSENT;
-        const int npoly = uni((int)slot[0]);
-        const uint32_t* wq = slot + 1;
+        // the whole ideal (<= 128 words for up to 15 binomials) comes in with two coalesced loads, one word per
+        // lane; fields are then picked with v_readlane instead of a chain of dependent scalar-address loads
+        const bool small_slot = p.q_slot_words <= 128;
+        uint32_t qA = 0, qB = 0;
+        if (small_slot) {
+          if (lane < (int)p.q_slot_words) qA = slot[lane];
+          if (lane + 64 < (int)p.q_slot_words) qB = slot[lane + 64];
+        }
+        auto qword = [&](int j) -> uint32_t {
+          if (!small_slot) return (uint32_t)uni((int)slot[j]);
+          return j < 64 ? f_readlane(qA, j) : f_readlane(qB, j - 64);
+        };
+        const int npoly = (int)qword(0);
+        int at = 1;
         for (int fidx = 0; fidx < npoly; fidx++) {
-          const int nt = uni((int)wq[0]), sugar = uni((int)wq[1]);
+          const int nt = (int)qword(at), sugar = (int)qword(at + 1);
           if (nG + 1 > limG || nP + nG > limP) { status = BBX_ST_SPILL; ok = false; break; }
           BTerm<2> t0, t1;
-          t0.c = (uint32_t)uni((int)wq[2]); t0.m.w[0] = (uint32_t)uni((int)wq[3]); t0.m.w[1] = (uint32_t)uni((int)wq[4]);
+          t0.c = qword(at + 2); t0.m.w[0] = qword(at + 3); t0.m.w[1] = qword(at + 4);
           t1.c = 0; t1.m = m_zero<2>();
-          if (nt == 2) { t1.c = (uint32_t)uni((int)wq[5]); t1.m.w[0] = (uint32_t)uni((int)wq[6]); t1.m.w[1] = (uint32_t)uni((int)wq[7]); }
-          add_poly(t0, t1, sugar);
-          wq += 2 + nt * 3;
+          if (nt == 2) { t1.c = qword(at + 5); t1.m.w[0] = qword(at + 6); t1.m.w[1] = qword(at + 7); }
+          add_poly(t0, t1, sugar, -1);
+          at += 2 + nt * 3;
         }
         if (!ok) break;
         if (!p.q_fixed) q_head++;
@@ -300,12 +329,13 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
       if (!ok) { if (status == BBX_ST_SPILL) { nG = 0; nP = 0; } break; }
       need_reset = 0;
     }
+    FSTAMP(0);                                             // 0: loop top / reset
     if (budget <= 0 || nP == 0) break;
     if (nG + 1 > limG || nP - 1 + nG > limP) { status = BBX_ST_SPILL; break; }   // before anything is modified
 
     // ---- choose the pair -----------------------------------------------------------------------------------------
     int action;
-    if (p.agent == BBX_AGENT_HASH) action = (int)(bbx_agent_hash32(agent_seed, (uint32_t)t_agent) % (uint32_t)nP);
+    if (p.agent == BBX_AGENT_HASH) action = (int)(((uint64_t)f_readlane(hv, t_agent & 63) * (uint32_t)nP) >> 32);   // bbx_agent_action32
     else if (p.agent == BBX_AGENT_EXTERNAL) action = uni(p.actions[env]);
     else if (p.agent == BBX_AGENT_FIRST) action = 0;
     else {                                                 // degree: first row of minimal deg lcm (buchberger.cpp:171-176)
@@ -319,17 +349,8 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
     }
     if (action < 0 || action >= nP) { status = BBX_ST_BAD_ACTION; break; }
     const uint32_t pr = (uint32_t)uni((int)pairs[action]);
-    const int gi_ = pr & 0xffffu, gj_ = pr >> 16;
-    for (int base = action; base < nP - 1; base += WAVE) { // P.erase(remove(action)), stable
-      const int k = base + lane;
-      uint32_t v = 0;
-      if (k < nP - 1) v = pairs[k + 1];
-      wave_sync();
-      if (k < nP - 1) pairs[k] = v;
-      wave_sync();
-    }
-    nP -= 1;
-
+    const int gi_ = pr & 0xffffu, gj_ = pr >> 16;            // the pair leaves P below, fused with the update's compaction
+    FSTAMP(1);                                             // 1: agent + pair removal
     // ---- S-polynomial (buchberger.cpp:18-21): the lead terms cancel, the scaled tails remain ------------------------
     BTerm<2> h0, h1;
     int hsug, bytes;
@@ -349,6 +370,7 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
       bytes = ACCT ? 12 * ((tci ? 2 : 1) + (tcj ? 2 : 1) + (h0.c ? 1 : 0) + (h1.c ? 1 : 0)) : 0;
     }
 
+    FSTAMP(2);                                             // 2: S-polynomial
     // ---- reduce (buchberger.cpp:24-49), entirely in registers -----------------------------------------------------------
     BTerm<2> r0, r1;
     r0.c = 0; r1.c = 0; r0.m = m_zero<2>(); r1.m = m_zero<2>();
@@ -388,16 +410,30 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
     if (hsug > 65535) { status = BBX_ST_DEG_OVERFLOW; break; }
     rsug = uni(rsug > hsug ? rsug : hsug);
 
+    FSTAMP(3);                                             // 3: reduce
     // ---- basis / pair-set update (buchberger.cpp:321-327) ------------------------------------------------------------
-    const int nG_before = nG, nP_before = nP;
-    if (r0.c != 0) {
-      add_poly(r0, r1, rsug);
+    const int nG_before = nG, nP_before = nP - 1;
+    if (r0.c == 0) {                                       // zero reduction: only P.erase(remove(action)), stable
+      for (int base = action; base < nP - 1; base += WAVE) {
+        const int k = base + lane;
+        uint32_t v = 0;
+        if (k < nP - 1) v = pairs[k + 1];
+        wave_sync();
+        if (k < nP - 1) pairs[k] = v;
+        wave_sync();
+      }
+      nP -= 1;
+      zero_red++;
+    } else {
+      add_poly(r0, r1, rsug, action);
       if (ACCT) bytes += 12 * (r1.c ? 2 : 1) + 8 * nG_before + 8 * (nP_before + nP);
-    } else zero_red++;
+    }
+    FSTAMP(4);                                             // 4: add_poly (pair update, insert)
     if (ACCT) { bytes += nP * obs_row_bytes; bytes_total += bytes; }
     const double reward = p.rewards_mode == BBX_REW_ADDITIONS ? (-1.0 - (double)nred) : -1.0;
     last_reward = reward;
     adds += 1 + nred; t_agent++; steps_done++;
+    if ((t_agent & 63) == 0) hv = bbx_agent_hash32(agent_seed, (uint32_t)(t_agent + lane));
     const bool done = nP == 0;
 
     if (p.obs_every_step && p.obs) write_obs(true, false);
@@ -430,7 +466,9 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
     budget--; rollout_pos++;
     done_last = done ? 1 : 0;
     if (done) { episodes++; if (p.auto_reset) need_reset = 1; }
+    FSTAMP(5);                                             // 5: observation + bookkeeping
   }
+  if (PROF && p.prof && lane == 0) for (int i = 0; i < 8; i++) p.prof[(size_t)env * 8 + i] = prof_sum[i];
 
   const bool handoff = status == BBX_ST_SPILL;
   if (p.obs && status == BBX_ST_OK) write_obs(true, false);
@@ -459,4 +497,9 @@ template <bool TRACE, bool ACCT>
 __global__ __launch_bounds__(256) void bbx_fast_kernel(BbxFastParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   fast_body<TRACE, ACCT>(p, smem);
+}
+// diagnostic build with s_memtime stamps between the phases of a step (never timed, never shipped as a result)
+__global__ __launch_bounds__(256) void bbx_fast_prof_kernel(BbxFastParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  fast_body<false, false, true>(p, smem);
 }

@@ -22,6 +22,9 @@
 //  * no inter-workgroup communication at all: environments are independent.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
 
 #include "bbx_common.h"
 
@@ -508,7 +511,7 @@ __device__ __forceinline__ void step_body(const BbxParams& p, char* smem) {
     // ---- choose the pair ------------------------------------------------------------------
     int action;
     if (p.agent == BBX_AGENT_EXTERNAL) action = p.actions[env];
-    else if (p.agent == BBX_AGENT_HASH) action = (int)(bbx_agent_hash32(agent_seed, (uint32_t)t_agent) % (uint32_t)nP);
+    else if (p.agent == BBX_AGENT_HASH) action = (int)bbx_agent_action32(agent_seed, (uint32_t)t_agent, (uint32_t)nP);
     else if (p.agent == BBX_AGENT_FIRST) action = 0;
     else {                                      // degree: first row of minimal deg lcm (buchberger.cpp:171-176)
       uint64_t best = ~0ull;
@@ -744,6 +747,21 @@ static int launch_fast(const BbxParams* p, int blocks, int threads, int envs_per
   f.agent = p->agent; f.auto_reset = p->auto_reset; f.set_budget = p->set_budget; f.pass = p->pass;
   f.obs_every_step = p->obs_every_step; f.obs_fill = p->obs_fill; f.rewards_mode = p->rewards_mode;
   const size_t lds = (size_t)envs_per_block * FLDS_BYTES;
+  static unsigned long long* d_prof = nullptr;
+  if (getenv("BBX_PROF") && !p->trace) {          // diagnostic: per-phase cycle sums, printed by bbx_prof_dump()
+    if (!d_prof) (void)hipMalloc((void**)&d_prof, (size_t)p->B * 8 * sizeof(unsigned long long));
+    f.prof = d_prof;
+    hipLaunchKernelGGL(bbx_fast_prof_kernel, dim3(blocks), dim3(threads), lds, stream, f);
+    (void)hipStreamSynchronize(stream);
+    std::vector<unsigned long long> h((size_t)p->B * 8);
+    (void)hipMemcpy(h.data(), d_prof, h.size() * 8, hipMemcpyDeviceToHost);
+    double s[8] = {0}; for (int e = 0; e < p->B; e++) for (int i = 0; i < 8; i++) s[i] += (double)h[(size_t)e * 8 + i];
+    double tot = 0; for (int i = 0; i < 8; i++) tot += s[i];
+    fprintf(stderr, "[bbx prof] nsteps=%d ticks/step/env:", p->nsteps);
+    for (int i = 0; i < 6; i++) fprintf(stderr, " p%d=%.0f(%.0f%%)", i, s[i] / p->B / (p->nsteps ? p->nsteps : 1), 100.0 * s[i] / tot);
+    fprintf(stderr, "\n");
+    return 0;
+  }
   if (p->trace) hipLaunchKernelGGL((bbx_fast_kernel<true, true>), dim3(blocks), dim3(threads), lds, stream, f);
   else if (p->accounting) hipLaunchKernelGGL((bbx_fast_kernel<false, true>), dim3(blocks), dim3(threads), lds, stream, f);
   else hipLaunchKernelGGL((bbx_fast_kernel<false, false>), dim3(blocks), dim3(threads), lds, stream, f);

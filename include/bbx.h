@@ -79,7 +79,7 @@ int bbx_copy(const bbx_batch* b, bbx_batch** out);
 
 /* ---- LeadMonomialsEnv::seed (buchberger.h:243, wrapped.pyx:28-30): one seed per environment ---- */
 int bbx_seed(bbx_batch* b, const int64_t* seeds);
-/* seeds of the built-in BBX_RANDOM_HASH agent: action = bbx_agent_hash(seed, t) mod rows */
+/* seeds of the built-in BBX_RANDOM_HASH agent: action = bbx_agent_action(seed, t, rows), t = steps taken so far */
 int bbx_seed_agent(bbx_batch* b, const uint32_t* seeds);
 
 /* ---- LeadMonomialsEnv::reset (buchberger.cpp:384-395, wrapped.pyx:18-21) ----------------------
@@ -158,6 +158,7 @@ int bbx_gen_next(bbx_gen* g, int32_t* npolys, int32_t* nterms_total);
 int bbx_gen_get(const bbx_gen* g, int32_t* nterms, int32_t* coefs, int32_t* exps, int32_t* sugars);
 
 uint32_t bbx_agent_hash(uint32_t seed, uint32_t t);
+uint32_t bbx_agent_action(uint32_t seed, uint32_t t, uint32_t rows);   /* (hash * rows) >> 32 */
 const char* bbx_last_error(void);
 const char* bbx_version(void);
 

@@ -1207,7 +1207,7 @@ double bo_bench_random(const char* dist, int k, int nenvs, int nsteps, int seed0
     bo_env_seed(e, seed0 + ei);
     env_reset(e);
     for (int t = 0; t < nsteps; t++) {
-      int action = (int)(agent_hash((uint32_t)(agent_seed0 + ei), (uint32_t)t) % (uint32_t)e->P.n);
+      int action = (int)(((uint64_t)agent_hash((uint32_t)(agent_seed0 + ei), (uint32_t)t) * (uint32_t)e->P.n) >> 32);
       double r = env_step(e, e->P.p[action]);
       int need = e->P.n * 2 * n * k;
       if (need > obs_cap) { obs_cap = need + 256; obs = (int*)realloc(obs, (size_t)obs_cap * sizeof(int)); }

@@ -359,6 +359,12 @@ def load(kind):
     return _cache[kind]
 
 
+def agent_action(seed, t, rows):
+    """Row chosen by the built-in random agent at its step t: multiply-shift range reduction of the counter hash
+    (bbx_agent_action in include/bbx.h; same in oracle/bbx_oracle.c and oracle/ref_driver.cpp)."""
+    return (agent_hash(seed, t) * int(rows)) >> 32
+
+
 def agent_hash(seed, t):
     """The counter-based action hash shared by device, oracle and reference driver."""
     m = (1 << 64) - 1

@@ -281,7 +281,7 @@ void ref_lme_state(void* e, int* out) {
 // Runs `nenvs` independent BuchbergerEnv instances (env e seeded seed0+e), each
 // for `nsteps` steps with auto-reset, choosing the action with the same
 // counter-based hash the device agent uses (bbx_agent_hash in include/bbx.h):
-// action = hash(agent_seed0+e, t) mod |P|.  The lead-monomial observation is
+// action = (hash(agent_seed0+e, t) * |P|) >> 32.  The lead-monomial observation is
 // rebuilt every step like LeadMonomialsEnv::step does.  Returns seconds; writes
 // total steps and total additions (= -sum reward).
 static inline uint32_t agent_hash(uint32_t seed, uint32_t t) {
@@ -302,7 +302,7 @@ double ref_bench_random(const char* dist, int k, int nenvs, int nsteps, int seed
     env.reset();
     for (int t = 0; t < nsteps; t++) {
       int rows = (int)env.state.size() / env.cols;
-      int action = (int)(agent_hash((uint32_t)(agent_seed0 + e), (uint32_t)t) % (uint32_t)rows);
+      int action = (int)(((uint64_t)agent_hash((uint32_t)(agent_seed0 + e), (uint32_t)t) * (uint32_t)rows) >> 32);
       double r = env.step(action);
       steps++;
       adds += (long long)(-r);

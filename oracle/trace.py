@@ -59,7 +59,7 @@ def poly_words(coef, exps):
 def run_trace(env, k, nsteps, policy, agent_seed=0, nobs=None, until_done=False, max_steps=100000):
     """Drive `env` (already seeded) and record a per-step trace.
 
-    policy: 'hash' (action = agent_hash(agent_seed, t) mod |P|), 'degree', 'first'.
+    policy: 'hash' (action = agent_action(agent_seed, t, |P|)), 'degree', 'first'.
     Auto-resets on done unless until_done.  Returns dict of numpy arrays.
     """
     n = env.nvars() if nobs is None else nobs
@@ -75,7 +75,7 @@ def run_trace(env, k, nsteps, policy, agent_seed=0, nobs=None, until_done=False,
             break
         nP = env.nP
         if policy == "hash":
-            a = ffi.agent_hash(agent_seed, t) % nP
+            a = ffi.agent_action(agent_seed, t, nP)
         elif policy == "degree":
             a = degree_action(env)
         elif policy == "first":

@@ -23,5 +23,5 @@ for caps in ({"lds_max_basis": -1}, None):
         print("rollout failed", ex)
     print(env.trace_read(0, 0, 3))
     for t in range(3):
-        a = ffi.agent_hash(5, t) % o.nP
+        a = ffi.agent_action(5, t, o.nP)
         r = o.step(a); print("oracle", a, r, o.nP, o.nG)

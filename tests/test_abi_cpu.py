@@ -67,6 +67,8 @@ def test_agent_hash_matches_oracle_definition(ffi_):
     from oracle import ffi as offi
     for seed, t in ((0, 0), (1, 2), (4095, 255), (0xFFFFFFFF, 0xFFFFFFFF)):
         assert ffi_.lib().bbx_agent_hash(seed, t) == offi.agent_hash(seed, t)
+        for rows in (1, 2, 19, 255):
+            assert ffi_.lib().bbx_agent_action(seed, t, rows) == offi.agent_action(seed, t, rows) < rows
 
 
 def test_no_silent_cpu_fallback(ffi_):

@@ -180,7 +180,7 @@ def test_algorithmic_byte_counter_matches_oracle():
         o = bo.env("3-20-10-weighted"); o.seed(1000 + e); o.reset()
         total = adds = 0
         for t in range(T):
-            r = o.step(ffi.agent_hash(e, t) % o.nP)
+            r = o.step(ffi.agent_action(e, t, o.nP))
             total += o.last_step_bytes() + 4 * o.nP * 2 * 3 * k
             adds += int(-r)
             if o.nP == 0:
@@ -210,7 +210,7 @@ def test_full_size_headline_untraced_vs_oracle():
         o = bo.env("3-20-10-weighted"); o.seed(1000 + e); o.reset()
         adds = total = 0
         for t in range(T):
-            r = o.step(ffi.agent_hash(e, t) % o.nP)
+            r = o.step(ffi.agent_action(e, t, o.nP))
             adds += int(-r)
             total += o.last_step_bytes() + 4 * o.nP * 2 * 3 * k
             if o.nP == 0:

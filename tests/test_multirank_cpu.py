@@ -26,7 +26,7 @@ def _run_shard(rank, world, per_rank, T):
         env.reset()
         adds = 0
         for t in range(T):
-            adds += int(-env.step(ffi.agent_hash(int(pl["agent_seeds"][i]), t) % env.nP))
+            adds += int(-env.step(ffi.agent_action(int(pl["agent_seeds"][i]), t, env.nP)))
             if env.nP == 0:
                 env.reset()
         out[i] = (pl["ids"][i], adds, env.nG)
