@@ -51,6 +51,14 @@ __device__ __forceinline__ uint64_t wave_min64(uint64_t v) {
   return v;
 }
 
+// wave-wide unsigned minimum with DPP row shifts / row broadcasts (no LDS traffic); result is uniform
+__device__ __forceinline__ uint32_t wave_min32(uint32_t x) {
+#define BBX_DPPMIN(ctrl, rmask) { uint32_t y_ = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)x, ctrl, rmask, 0xF, false); x = y_ < x ? y_ : x; }
+  BBX_DPPMIN(0x111, 0xF) BBX_DPPMIN(0x112, 0xF) BBX_DPPMIN(0x114, 0xF) BBX_DPPMIN(0x118, 0xF) BBX_DPPMIN(0x142, 0xA) BBX_DPPMIN(0x143, 0xC)
+#undef BBX_DPPMIN
+  return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+}
+
 // ------------------------------------------------------------------ GF(32003)   polynomials.h:10-26
 __device__ __forceinline__ uint32_t mulmod(uint32_t a, uint32_t b) { return (a * b) % BBX_P; }
 __device__ __forceinline__ uint32_t addmod(uint32_t a, uint32_t b) { uint32_t s = a + b; return s >= BBX_P ? s - BBX_P : s; }
@@ -240,31 +248,56 @@ __device__ bool wave_update(EnvT& e, const BbxLayout& L, int& nG, int& nP, const
       wave_sync();
     }
     nP = w;
-    // (78-81) lcm_i = lcm(LM G[i], LM f), and whether G[i] is coprime to f
+    // (78-81) lcm_i = lcm(LM G[i], LM f); flags: 1 = G[i] coprime to f, 2 = still a candidate, 4 = emits a pair
     for (int i = lane; i < m; i += WAVE) {
       Mono<W> li = e.lm[i];
       e.lcm[i] = m_lcm(li, lmf);
-      e.cp[i] = m_coprime(li, lmf) ? 1 : 0;
+      e.cp[i] = (uint8_t)((m_coprime(li, lmf) ? 1 : 0) | 2);
     }
     wave_sync();
-    // (82-91) The std::map walk keeps exactly the lcms that are minimal under divisibility among the
-    // distinct values (a proper divisor has smaller degree, hence comes earlier in grevlex), and emits
-    // (min index of the bucket, m) unless some index of the bucket is coprime to f.
-    for (int base = 0; base < m; base += WAVE) {
-      int i = base + lane;
-      bool emit = false;
-      if (i < m) {
-        Mono<W> Li = e.lcm[i];
-        bool bad = false;
-        for (int k = 0; k < m; k++) {
-          Mono<W> Lk = e.lcm[k];              // same address in every lane: broadcast read
-          bool eq = m_eq(Lk, Li);
-          bad |= m_divides(Lk, Li) && (!eq || k < i || e.cp[k]);
+    // (82-91) The std::map walk keeps exactly the lcms that are minimal under divisibility among the distinct
+    // values (a proper divisor has smaller degree, hence comes earlier in grevlex).  They are peeled by increasing
+    // degree: every candidate of minimal degree is minimal; its bucket of equal lcms emits (smallest index, m)
+    // unless a member is coprime to f (88-89), and all multiples of it stop being candidates.  Every lane only
+    // ever reads and writes the flags of its own indices (i = lane mod 64), the bucket's lcm travels by readlane.
+    for (;;) {
+      uint32_t dm = 0xFFFFFFFFu;
+      for (int i = lane; i < m; i += WAVE) if (e.cp[i] & 2) { uint32_t d = m_deg(e.lcm[i]); dm = d < dm ? d : dm; }
+      const uint32_t dmin = wave_min32(dm);
+      if (dmin == 0xFFFFFFFFu) break;
+      for (int base = 0; base < m; base += WAVE) {
+        const int i = base + lane;
+        Mono<W> Li = m_zero<W>();
+        bool sv = false;
+        if (i < m) { Li = e.lcm[i]; sv = (e.cp[i] & 2) && m_deg(Li) == dmin; }
+        uint64_t surv = ballot64(sv);
+        while (surv) {
+          const int sl = __builtin_ctzll(surv);
+          Mono<W> Ls;
+#pragma unroll
+          for (int q = 0; q < W; q++) Ls.w[q] = (uint32_t)__builtin_amdgcn_readlane((int)Li.w[q], sl);
+          bool any_cp = false;
+          for (int b2 = 0; b2 < m; b2 += WAVE) {
+            const int j = b2 + lane;
+            bool eq = false;
+            if (j < m) {
+              const Mono<W> Lj = e.lcm[j];
+              const uint8_t fj = e.cp[j];
+              eq = m_eq(Lj, Ls);
+              if (m_divides(Ls, Lj)) e.cp[j] = (uint8_t)(fj & ~2);
+              any_cp |= eq && (fj & 1);
+            }
+            if (b2 == base) surv &= ~ballot64(eq);
+          }
+          if (ballot64(any_cp) == 0 && lane == sl) e.cp[i] |= 4;
         }
-        emit = !bad;
       }
-      uint64_t mask = ballot64(emit);
-      int cnt = __popcll(mask);
+    }
+    for (int base = 0; base < m; base += WAVE) {
+      const int i = base + lane;
+      const bool emit = i < m && (e.cp[i] & 4);
+      const uint64_t mask = ballot64(emit);
+      const int cnt = __popcll(mask);
       if (nP + cnt > (int)L.maxP) { *status = BBX_ST_P_FULL; return false; }
       if (emit) e.pairs[nP + prefix_of(mask, lane)] = (uint32_t)i | ((uint32_t)m << 16);  // (92) ascending i
       nP += cnt;
