@@ -121,6 +121,12 @@ class VecLeadMonomialsEnv:
         _ffi.check(_ffi.lib().bbx_value(self._h, int(idx), strategy.encode(), float(gamma), C.byref(v)))
         return v.value
 
+    def values(self, strategy="degree", gamma=0.99):
+        """value() of every environment at once (float64 [batch])."""
+        out = np.zeros(self.batch, dtype=np.float64)
+        _ffi.check(_ffi.lib().bbx_values(self._h, strategy.encode(), float(gamma), _ffi.ptr(out)))
+        return out
+
     def copy(self):
         h = C.c_void_p()
         _ffi.check(_ffi.lib().bbx_copy(self._h, C.byref(h)))

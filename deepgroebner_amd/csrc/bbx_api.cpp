@@ -17,6 +17,7 @@
 #include "bbx_ideals.h"
 
 extern "C" int bbx_launch_step(const BbxParams* p, int kind, int envs_per_block, hipStream_t stream);
+extern "C" int bbx_launch_clone(const char* src_recs, char* dst_recs, const BbxLayout* L, const int32_t* src, int n, const uint32_t* seeds, hipStream_t stream);
 extern "C" int bbx_launch_gather_hdr(const char* recs, uint32_t rec_bytes, int B, BbxHdr* out, hipStream_t stream);
 extern "C" int bbx_launch_init(char* recs, uint32_t rec_bytes, int B, const uint32_t* agent_seeds, hipStream_t stream);
 extern "C" int bbx_launch_mark_reset(char* recs, uint32_t rec_bytes, int B, const uint8_t* mask, hipStream_t stream);
@@ -97,6 +98,9 @@ struct bbx_batch {
   int32_t* d_obs = nullptr; size_t obs_rows_cap = 0;
   BbxTraceRec* d_trace = nullptr; int trace_cap = 0;
   BbxHdr* d_hdr = nullptr;            // compact header copy (bbx_gather_hdr_kernel)
+  // scratch for value(): cloned records, their headers, source indices, agent seeds, results
+  char* d_vrecs = nullptr; BbxHdr* d_vhdr = nullptr; int32_t* d_vsrc = nullptr; uint32_t* d_vseeds = nullptr; double* d_vvals = nullptr;
+  int vcap = 0;
   // HIP-event timing of the step-kernel launches (bbx_timing)
   bool accounting = true;             // count algorithmic bytes (bbx_accounting)
   bool timing = false;
@@ -339,7 +343,7 @@ int create_common(std::unique_ptr<bbx::IdealGen> proto, int nvars_obs, int elimi
   if (caps) c = *caps;
   if (b->fixed) {
     if (!c.max_basis) c.max_basis = 4096; if (!c.max_pairs) c.max_pairs = 16384;
-    if (!c.arena_terms) c.arena_terms = 1 << 20; if (!c.max_poly_terms) c.max_poly_terms = 8192;
+    if (!c.arena_terms) c.arena_terms = 1 << 20; if (!c.max_poly_terms) c.max_poly_terms = 65536;
   } else if (binomial) {
     if (!c.max_basis) c.max_basis = b->W == 2 ? 512 : 4096; if (!c.max_pairs) c.max_pairs = b->W == 2 ? (elimination == BBX_GEBAUERMOELLER ? 4096 : 32768) : 16384;
     if (!c.arena_terms) c.arena_terms = 2 * c.max_basis + 16; if (!c.max_poly_terms) c.max_poly_terms = 8;
@@ -361,7 +365,7 @@ int create_common(std::unique_ptr<bbx::IdealGen> proto, int nvars_obs, int elimi
     // the hand-tuned kernel covers exactly the reference C++ class's fixed options
     b->fast = b->binom && elimination == BBX_GEBAUERMOELLER && sort_reducers && lg <= 128 && !getenv("BBX_NO_FAST");
   }
-  if (c.max_basis > 65535 || c.max_poly_terms > 65535 || c.max_basis < 2 || c.max_pairs < 2 || c.max_poly_terms < 4 || c.queue_slots < 1)
+  if (c.max_basis > 65535 || c.max_poly_terms > (1 << 22) || c.max_basis < 2 || c.max_pairs < 2 || c.max_poly_terms < 4 || c.queue_slots < 1)
     return fail(BBX_E_ARG, "capacities out of range");
   b->L = b->binom ? make_layout_binom(b->W, c.max_basis, c.max_pairs)
                   : make_layout(b->W, c.max_basis, c.max_pairs, c.arena_terms, c.max_poly_terms);
@@ -448,7 +452,8 @@ void bbx_destroy(bbx_batch* b) {
   if (!b) return;
   (void)hipSetDevice(b->device);
   (void)hipDeviceSynchronize();
-  void* bufs[] = {b->d_recs, b->d_q, b->d_tail, b->d_out, b->d_actions, b->d_mask, b->d_seeds, b->d_obs, b->d_trace, b->d_hdr, b->d_inv};
+  void* bufs[] = {b->d_recs, b->d_q, b->d_tail, b->d_out, b->d_actions, b->d_mask, b->d_seeds, b->d_obs, b->d_trace, b->d_hdr, b->d_inv,
+                  b->d_vrecs, b->d_vhdr, b->d_vsrc, b->d_vseeds, b->d_vvals};
   for (void* p : bufs) (void)hipFree(p);
   delete b;
 }
@@ -627,10 +632,153 @@ int bbx_cols(const bbx_batch* b) { return b ? 2 * b->nvars * b->k : 0; }
 int bbx_nvars(const bbx_batch* b) { return b ? b->nvars : 0; }
 int bbx_batch_size(const bbx_batch* b) { return b ? b->B : 0; }
 
-int bbx_value(bbx_batch* b, int idx, const char* strategy, double gamma, double* out) {
-  (void)b; (void)idx; (void)strategy; (void)gamma; (void)out;
-  return fail(BBX_E_UNSUPPORTED, "bbx_value: device-side value rollouts are not built yet");
+}  // extern "C" (reopened below)
+
+// ---- value(): discounted return of full Buchberger rollouts from clones of the current states ---------------------
+namespace {
+
+bool packed_less(int W, const uint32_t* a, const uint32_t* b) {   // grevlex a < b on packed monomials (device m_gt)
+  const uint64_t ha = (((uint64_t)a[W - 1] << 32) | a[W - 2]) ^ 0x0000FFFFFFFFFFFFull;
+  const uint64_t hb = (((uint64_t)b[W - 1] << 32) | b[W - 2]) ^ 0x0000FFFFFFFFFFFFull;
+  if (ha != hb) return ha < hb;
+  if (W == 4) {
+    const uint64_t la = ~(((uint64_t)a[1] << 32) | a[0]), lb = ~(((uint64_t)b[1] << 32) | b[0]);
+    return la < lb;
+  }
+  return false;
 }
+
+// buchberger() re-sorts its reducers with std::sort (buchberger.cpp:157-158).  That only differs from the
+// environment's own upper_bound order when lead monomials tie, which can only happen among the generators.  For a
+// clone with such a tie the reducer-order arrays are rebuilt on the host with the same std::sort call.
+int resort_reducers_if_tied(bbx_batch* b, char* vrec, const BbxHdr& h) {
+  const int W = b->W, nG = h.nG;
+  if (!b->sort_reducers || nG < 2) return BBX_OK;
+  const int ngen = std::min(nG, b->gens[0]->npolys());
+  std::vector<uint32_t> lm((size_t)nG * W);
+  HIPCHK(hipMemcpy(lm.data(), vrec + b->L.off_lm, (size_t)ngen * W * 4, hipMemcpyDeviceToHost));
+  bool tie = false;
+  for (int i = 0; i < ngen && !tie; i++)
+    for (int j = i + 1; j < ngen; j++)
+      if (!memcmp(&lm[(size_t)i * W], &lm[(size_t)j * W], (size_t)W * 4)) { tie = true; break; }
+  if (!tie) return BBX_OK;
+  HIPCHK(hipMemcpy(lm.data(), vrec + b->L.off_lm, (size_t)nG * W * 4, hipMemcpyDeviceToHost));
+  std::vector<int> ord(nG);
+  for (int i = 0; i < nG; i++) ord[i] = i;
+  std::sort(ord.begin(), ord.end(), [&](int x, int y) { return packed_less(W, &lm[(size_t)x * W], &lm[(size_t)y * W]); });
+  std::vector<uint32_t> slm((size_t)nG * W);
+  for (int r = 0; r < nG; r++) memcpy(&slm[(size_t)r * W], &lm[(size_t)ord[r] * W], (size_t)W * 4);
+  HIPCHK(hipMemcpy(vrec + b->L.off_slm, slm.data(), slm.size() * 4, hipMemcpyHostToDevice));
+  if (b->binom) {
+    std::vector<uint32_t> tm((size_t)nG * W), stm((size_t)nG * W), gi((size_t)nG * 2), si((size_t)nG * 2);
+    HIPCHK(hipMemcpy(tm.data(), vrec + b->L.off_tm, tm.size() * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(gi.data(), vrec + b->L.off_ginfo, gi.size() * 4, hipMemcpyDeviceToHost));
+    for (int r = 0; r < nG; r++) {
+      const int g = ord[r];
+      memcpy(&stm[(size_t)r * W], &tm[(size_t)g * W], (size_t)W * 4);
+      const uint32_t tc = gi[2 * g] >> 16, inv = gi[2 * g + 1] & 0xffffu, sug = gi[2 * g + 1] >> 16;
+      si[2 * r] = tc | (inv << 16); si[2 * r + 1] = sug | ((uint32_t)g << 16);
+    }
+    HIPCHK(hipMemcpy(vrec + b->L.off_stm, stm.data(), stm.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(vrec + b->L.off_sinfo, si.data(), si.size() * 4, hipMemcpyHostToDevice));
+  } else {
+    std::vector<uint16_t> sidx(nG);
+    for (int r = 0; r < nG; r++) sidx[r] = (uint16_t)ord[r];
+    HIPCHK(hipMemcpy(vrec + b->L.off_sidx, sidx.data(), sidx.size() * 2, hipMemcpyHostToDevice));
+  }
+  return BBX_OK;
+}
+
+int agent_of_strategy(const char* s) {   // unknown keys select First: std::map::operator[] default (buchberger.cpp:342-349)
+  if (!strcmp(s, "degree")) return BBX_AGENT_DEGREE;
+  if (!strcmp(s, "normal")) return BBX_AGENT_NORMAL;
+  if (!strcmp(s, "sugar")) return BBX_AGENT_SUGAR;
+  if (!strcmp(s, "random")) return BBX_AGENT_HASH;
+  return BBX_AGENT_FIRST;
+}
+
+// one rollout to completion per entry of src (indices into b); seeds != null re-seeds the clones' random agent
+int value_rollouts(bbx_batch* b, const std::vector<int32_t>& src, int agent, const std::vector<uint32_t>* seeds, double gamma, double* out) {
+  const int n = (int)src.size();
+  if (b->in_flight) { int rc = finish(b, b->last_stream); if (rc) return rc; }
+  if (n > b->vcap) {
+    void* old[] = {b->d_vrecs, b->d_vhdr, b->d_vsrc, b->d_vseeds, b->d_vvals};
+    for (void* q : old) (void)hipFree(q);
+    b->d_vrecs = nullptr; b->d_vhdr = nullptr; b->d_vsrc = nullptr; b->d_vseeds = nullptr; b->d_vvals = nullptr; b->vcap = 0;
+    HIPCHK(hipMalloc((void**)&b->d_vrecs, (size_t)n * b->L.rec_bytes));
+    HIPCHK(hipMalloc((void**)&b->d_vhdr, (size_t)n * sizeof(BbxHdr)));
+    HIPCHK(hipMalloc((void**)&b->d_vsrc, (size_t)n * sizeof(int32_t)));
+    HIPCHK(hipMalloc((void**)&b->d_vseeds, (size_t)n * sizeof(uint32_t)));
+    HIPCHK(hipMalloc((void**)&b->d_vvals, (size_t)n * sizeof(double)));
+    b->vcap = n;
+  }
+  HIPCHK(hipMemcpy(b->d_vsrc, src.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice));
+  if (seeds) HIPCHK(hipMemcpy(b->d_vseeds, seeds->data(), (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice));
+  int lrc = bbx_launch_clone(b->d_recs, b->d_vrecs, &b->L, b->d_vsrc, n, seeds ? b->d_vseeds : nullptr, 0);
+  if (lrc) return fail(BBX_E_DEVICE, "clone launch failed: %s", hipGetErrorString((hipError_t)lrc));
+  std::vector<BbxHdr> vh(n);
+  lrc = bbx_launch_gather_hdr(b->d_vrecs, b->L.rec_bytes, n, b->d_vhdr, 0);
+  if (lrc) return fail(BBX_E_DEVICE, "gather launch failed: %s", hipGetErrorString((hipError_t)lrc));
+  HIPCHK(hipMemcpy(vh.data(), b->d_vhdr, (size_t)n * sizeof(BbxHdr), hipMemcpyDeviceToHost));
+  for (int k = 0; k < n; k++) {
+    if (vh[k].status != BBX_ST_OK) return fail(BBX_E_CAPACITY, "environment %d is in an error state", src[k]);
+    int rc = resort_reducers_if_tied(b, b->d_vrecs + (size_t)k * b->L.rec_bytes, vh[k]);
+    if (rc) return rc;
+  }
+  BbxParams p; fill_params(b, &p);
+  p.recs = b->d_vrecs; p.B = n; p.nsteps = 1 << 30; p.set_budget = 1; p.agent = agent; p.auto_reset = 0;
+  p.value_mode = 1; p.gamma = gamma; p.values = b->d_vvals; p.trace = nullptr; p.accounting = 0;
+  lrc = bbx_launch_step(&p, 0, b->envs_per_block, 0);       // HBM-resident class kernel (no resets, no staging)
+  if (lrc) return fail(BBX_E_DEVICE, "kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
+  lrc = bbx_launch_gather_hdr(b->d_vrecs, b->L.rec_bytes, n, b->d_vhdr, 0);
+  if (lrc) return fail(BBX_E_DEVICE, "gather launch failed: %s", hipGetErrorString((hipError_t)lrc));
+  HIPCHK(hipMemcpy(vh.data(), b->d_vhdr, (size_t)n * sizeof(BbxHdr), hipMemcpyDeviceToHost));
+  for (int k = 0; k < n; k++)
+    if (vh[k].status != BBX_ST_OK || vh[k].nP != 0)
+      return fail(BBX_E_CAPACITY, "value rollout of environment %d did not finish: %s", src[k], status_name(vh[k].status));
+  HIPCHK(hipMemcpy(out, b->d_vvals, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+  return BBX_OK;
+}
+
+int values_for(bbx_batch* b, const std::vector<int32_t>& envs, const char* strategy, double gamma, double* out) {
+  const int n = (int)envs.size();
+  if (!strcmp(strategy, "sample")) {          // best of one Degree and 100 Random rollouts (buchberger.cpp:333-341)
+    int rc = value_rollouts(b, envs, BBX_AGENT_DEGREE, nullptr, gamma, out);
+    if (rc) return rc;
+    std::vector<int32_t> src; std::vector<uint32_t> seeds;
+    for (int e : envs) for (int i = 0; i < 100; i++) { src.push_back(e); seeds.push_back((uint32_t)rand() * 2654435761u + (uint32_t)i); }
+    std::vector<double> r(src.size());
+    rc = value_rollouts(b, src, BBX_AGENT_HASH, &seeds, gamma, r.data());
+    if (rc) return rc;
+    for (int k = 0; k < n; k++) for (int i = 0; i < 100; i++) out[k] = std::max(out[k], r[(size_t)k * 100 + i]);
+    return BBX_OK;
+  }
+  const int agent = agent_of_strategy(strategy);
+  if (agent == BBX_AGENT_HASH) {              // unseeded in the reference (std::random_device): not reproducible there either
+    std::vector<uint32_t> seeds(n);
+    for (auto& s : seeds) s = (uint32_t)rand() * 2654435761u;
+    return value_rollouts(b, envs, agent, &seeds, gamma, out);
+  }
+  return value_rollouts(b, envs, agent, nullptr, gamma, out);
+}
+
+}  // namespace
+
+extern "C" int bbx_value(bbx_batch* b, int idx, const char* strategy, double gamma, double* out) {
+  if (!b || !strategy || !out || idx < 0 || idx >= b->B) return fail(BBX_E_ARG, "bad arguments");
+  HIPCHK(hipSetDevice(b->device));
+  return values_for(b, std::vector<int32_t>{idx}, strategy, gamma, out);
+}
+
+extern "C" int bbx_values(bbx_batch* b, const char* strategy, double gamma, double* out) {
+  if (!b || !strategy || !out) return fail(BBX_E_ARG, "bad arguments");
+  HIPCHK(hipSetDevice(b->device));
+  std::vector<int32_t> envs(b->B);
+  for (int e = 0; e < b->B; e++) envs[e] = e;
+  return values_for(b, envs, strategy, gamma, out);
+}
+
+extern "C" {
 
 int bbx_stats(bbx_batch* b, int64_t* out8) {
   int64_t* out6 = out8;

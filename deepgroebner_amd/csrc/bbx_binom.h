@@ -228,7 +228,8 @@ __device__ __forceinline__ void binom_body(const BbxParams& p, char* smem) {
   int budget = uni(ghdr->budget), rollout_pos = uni(ghdr->rollout_pos);
   int done_last = uni(ghdr->done_last);
   if (status == BBX_ST_STARVED || status == BBX_ST_SPILL) status = BBX_ST_OK;
-  if (p.set_budget) { budget = p.nsteps; rollout_pos = 0; done_last = 0; }
+  double vret = ghdr->vret, vdisc = ghdr->vdisc;
+  if (p.set_budget) { budget = p.nsteps; rollout_pos = 0; done_last = 0; vret = 0.0; vdisc = 1.0; }
   if (p.pass == 1 && !(status == BBX_ST_OK && (need_reset || (budget > 0 && nP > 0)))) return;
 
   BEnv<W> ge = benv_view<W>(grec, p.L);
@@ -264,15 +265,7 @@ __device__ __forceinline__ void binom_body(const BbxParams& p, char* smem) {
     if (p.agent == BBX_AGENT_EXTERNAL) action = p.actions[env];
     else if (p.agent == BBX_AGENT_HASH) action = (int)bbx_agent_action32(agent_seed, (uint32_t)t_agent, (uint32_t)nP);
     else if (p.agent == BBX_AGENT_FIRST) action = 0;
-    else {
-      uint64_t best = ~0ull;
-      for (int r = lane; r < nP; r += WAVE) {
-        uint32_t pr = e.pairs[r];
-        uint64_t key = ((uint64_t)m_deg(m_lcm(e.lm[pr & 0xffffu], e.lm[pr >> 16])) << 32) | (uint32_t)r;
-        best = key < best ? key : best;
-      }
-      action = (int)(uint32_t)wave_min64(best);
-    }
+    else action = select_pair<W>(e, nP, p.agent, [&](int g) { return (int)(e.ginfo[g].y >> 16); });
     action = uni(action);
     if (action < 0 || action >= nP) { status = BBX_ST_BAD_ACTION; break; }
     const uint32_t pr = (uint32_t)uni((int)e.pairs[action]);
@@ -369,6 +362,7 @@ __device__ __forceinline__ void binom_body(const BbxParams& p, char* smem) {
     alg_bytes += bytes;
     const double reward = (p.rewards_mode == BBX_REW_ADDITIONS) ? (-1.0 - (double)nsteps_red) : -1.0;
     last_reward = reward;
+    if (p.value_mode) value_accumulate(vret, vdisc, reward, p.gamma);
     total_steps++; total_adds += 1 + nsteps_red; t_agent++; episode_steps++; steps_done++;
     const bool done = nP == 0;
 
@@ -403,6 +397,8 @@ __device__ __forceinline__ void binom_body(const BbxParams& p, char* smem) {
     h->q_head = q_head; h->t = t_agent; h->episode_steps = episode_steps; h->total_steps = total_steps;
     h->total_additions = total_adds; h->episodes = episodes; h->zero_reductions = zero_red; h->steps_done = steps_done;
     h->budget = budget; h->rollout_pos = rollout_pos; h->done_last = done_last; h->alg_bytes = alg_bytes;
+    h->vret = vret; h->vdisc = vdisc;
+    if (p.value_mode && p.values) p.values[env] = vret;
     if (!handoff) {
       if (p.rewards && (steps_done > 0 || p.pass == 0)) p.rewards[env] = last_reward;
       if (p.dones) p.dones[env] = (uint8_t)((done_last || (nP == 0 && !need_reset)) ? 1 : 0);

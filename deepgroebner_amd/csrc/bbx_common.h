@@ -58,7 +58,8 @@ struct BbxHdr {             // 128 bytes
   int32_t done_last;        // the last executed step ended an episode
   int32_t reserved0;
   int64_t alg_bytes;        // algorithmic bytes moved so far (SURVEY.md 8d formula), for the roofline figure
-  int32_t reserved[10];
+  double vret, vdisc;       // value() rollouts: discounted return so far and the current discount (buchberger.cpp:248-252)
+  int32_t reserved[6];
 };
 
 struct BbxLayout {
@@ -92,7 +93,7 @@ struct BbxTraceRec {        // one per environment per step when tracing (tests 
   uint64_t obs_hash, pairs_hash, newpoly_hash;
 };
 
-enum { BBX_AGENT_EXTERNAL = 0, BBX_AGENT_HASH = 1, BBX_AGENT_DEGREE = 2, BBX_AGENT_FIRST = 3 };
+enum { BBX_AGENT_EXTERNAL = 0, BBX_AGENT_HASH = 1, BBX_AGENT_DEGREE = 2, BBX_AGENT_FIRST = 3, BBX_AGENT_NORMAL = 4, BBX_AGENT_SUGAR = 5 };
 enum { BBX_ELIM_GM = 0, BBX_ELIM_LCM = 1, BBX_ELIM_NONE = 2 };
 enum { BBX_REW_ADDITIONS = 0, BBX_REW_REDUCTIONS = 1 };
 
@@ -116,6 +117,9 @@ struct BbxParams {
   int32_t obs_fill;         // 1: pad rows [nP, obs_rows) with -1
   int32_t obs_every_step;   // 1: materialise the observation after every step (what a policy consumes),
                             // 0: only for the state the caller sees when the launch ends
+  int32_t value_mode;       // 1: accumulate the discounted return of the rollout (value(), buchberger.cpp:332-351)
+  double gamma;
+  double* values;           // [B] discounted return when value_mode
   int32_t accounting;       // 1: count algorithmic bytes per step (BbxHdr.alg_bytes); the lean fast kernel omits it
   int32_t pass;             // 0: primary launch; 1: follow-up launch serving only environments with work left
   const uint16_t* inv_table; // [32003] inverses in GF(32003) (L2-resident), binomial class

@@ -350,6 +350,7 @@ __device__ bool wave_add_poly(Env<W>& e, const BbxLayout& L, int& nG, int& nP, i
                               int elim, int sort_reducers, int* status) {
   const int lane = lane_id();
   if (nG >= (int)L.maxG) { *status = BBX_ST_G_FULL; return false; }
+  if (n > 65535) { *status = BBX_ST_POLY_TOO_LONG; return false; }       // plen[] is 16 bits
   if (arena_used + n > (int)L.arena) { *status = BBX_ST_ARENA_FULL; return false; }
   const int g = nG, off = arena_used;
   for (int t = lane; t < n; t += WAVE) { e.am[off + t] = sm[t]; e.ac[off + t] = sc[t]; }
@@ -459,6 +460,54 @@ __device__ uint64_t wave_poly_hash(const Env<W>& e, int g) {
   return wave_sum64(h);
 }
 
+// ------------------------------------------------------------------ selection strategies (buchberger.cpp:165-198)
+// First index of the pair with the minimal key.  P is always in ascending (j, i) order (new pairs carry the largest
+// j and are appended sorted by i, removals keep the order), so "first minimal row" IS the reference's (key, j, i)
+// tie-break.  Keys: Degree = deg lcm; Normal = lcm in grevlex; Sugar = (sugar of the pair, lcm).
+template <int W> struct SelKey { uint32_t s; Mono<W> m; uint32_t r; };
+template <int W> __device__ __forceinline__ bool sel_less(const SelKey<W>& a, const SelKey<W>& b) {
+  if (a.s != b.s) return a.s < b.s;
+  if (m_gt(b.m, a.m)) return true;
+  if (m_gt(a.m, b.m)) return false;
+  return a.r < b.r;
+}
+template <int W, class EnvT, class SugarFn>
+__device__ int select_pair(const EnvT& e, int nP, int agent, SugarFn sugar_of) {
+  SelKey<W> best; best.s = 0xFFFFFFFFu; best.m = m_zero<W>(); best.r = 0xFFFFFFFFu;
+  for (int r = lane_id(); r < nP; r += WAVE) {
+    const uint32_t pr = e.pairs[r];
+    const int i = pr & 0xffffu, j = pr >> 16;
+    const Mono<W> li = e.lm[i], lj = e.lm[j];
+    const Mono<W> l = m_lcm(li, lj);
+    SelKey<W> c; c.r = (uint32_t)r; c.m = m_zero<W>(); c.s = 0;
+    if (agent == BBX_AGENT_DEGREE) c.s = m_deg(l);
+    else {
+      c.m = l;
+      if (agent == BBX_AGENT_SUGAR) {
+        const uint32_t si = (uint32_t)sugar_of(i) + m_deg(m_div(l, li)), sj = (uint32_t)sugar_of(j) + m_deg(m_div(l, lj));
+        c.s = si > sj ? si : sj;
+      }
+    }
+    if (sel_less<W>(c, best)) best = c;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    SelKey<W> t;
+    t.s = (uint32_t)__shfl_xor((int)best.s, o, WAVE); t.r = (uint32_t)__shfl_xor((int)best.r, o, WAVE);
+#pragma unroll
+    for (int q = 0; q < W; q++) t.m.w[q] = (uint32_t)__shfl_xor((int)best.m.w[q], o, WAVE);
+    if (sel_less<W>(t, best)) best = t;
+  }
+  return (int)best.r;
+}
+// discounted-return bookkeeping of value(): stats.discounted_return += discount * reward; discount *= gamma,
+// in double and without fusing the multiply into the add (the reference runs on x86-64 without FMA)
+__device__ __forceinline__ void value_accumulate(double& vret, double& vdisc, double reward, double gamma) {
+#pragma clang fp contract(off)
+  const double term = vdisc * reward;
+  vret = vret + term;
+  vdisc = vdisc * gamma;
+}
+
 // ------------------------------------------------------------------ the step kernel
 // copy the live prefix of every persistent array between the HBM record and the LDS working copy
 template <int W>
@@ -491,7 +540,8 @@ __device__ __forceinline__ void step_body(const BbxParams& p, char* smem) {
   int budget = uni(ghdr->budget), rollout_pos = uni(ghdr->rollout_pos);
   int done_last = uni(ghdr->done_last);
   if (status == BBX_ST_STARVED || status == BBX_ST_SPILL) status = BBX_ST_OK;   // transient states: try again
-  if (p.set_budget) { budget = p.nsteps; rollout_pos = 0; done_last = 0; }
+  double vret = ghdr->vret, vdisc = ghdr->vdisc;
+  if (p.set_budget) { budget = p.nsteps; rollout_pos = 0; done_last = 0; vret = 0.0; vdisc = 1.0; }
   if (p.pass == 1 && !(status == BBX_ST_OK && (need_reset || (budget > 0 && nP > 0)))) return;  // nothing left to do here
 
   Env<W> ge = env_view<W>(grec, p.L);
@@ -546,15 +596,7 @@ __device__ __forceinline__ void step_body(const BbxParams& p, char* smem) {
     if (p.agent == BBX_AGENT_EXTERNAL) action = p.actions[env];
     else if (p.agent == BBX_AGENT_HASH) action = (int)bbx_agent_action32(agent_seed, (uint32_t)t_agent, (uint32_t)nP);
     else if (p.agent == BBX_AGENT_FIRST) action = 0;
-    else {                                      // degree: first row of minimal deg lcm (buchberger.cpp:171-176)
-      uint64_t best = ~0ull;
-      for (int r = lane; r < nP; r += WAVE) {
-        uint32_t pr = e.pairs[r];
-        uint64_t key = ((uint64_t)m_deg(m_lcm(e.lm[pr & 0xffffu], e.lm[pr >> 16])) << 32) | (uint32_t)r;
-        best = key < best ? key : best;
-      }
-      action = (int)(uint32_t)wave_min64(best);
-    }
+    else action = select_pair<W>(e, nP, p.agent, [&](int g) { return (int)e.psug[g]; });
     action = uni(action);
     if (action < 0 || action >= nP) { status = BBX_ST_BAD_ACTION; break; }
     const uint32_t pr = (uint32_t)uni((int)e.pairs[action]);
@@ -644,6 +686,7 @@ __device__ __forceinline__ void step_body(const BbxParams& p, char* smem) {
     alg_bytes += 4LL * nP * 2 * p.nvars * p.k;      // the observation matrix of the new state
     const double reward = (p.rewards_mode == BBX_REW_ADDITIONS) ? (-1.0 - (double)nsteps_red) : -1.0;  // 328
     last_reward = reward;
+    if (p.value_mode) value_accumulate(vret, vdisc, reward, p.gamma);
     total_steps++; total_adds += 1 + nsteps_red; t_agent++; episode_steps++; steps_done++;
     const bool done = nP == 0;
 
@@ -683,6 +726,8 @@ __device__ __forceinline__ void step_body(const BbxParams& p, char* smem) {
     h->q_head = q_head; h->t = t_agent; h->episode_steps = episode_steps; h->total_steps = total_steps;
     h->total_additions = total_adds; h->episodes = episodes; h->zero_reductions = zero_red; h->steps_done = steps_done;
     h->budget = budget; h->rollout_pos = rollout_pos; h->done_last = done_last; h->alg_bytes = alg_bytes;
+    h->vret = vret; h->vdisc = vdisc;
+    if (p.value_mode && p.values) p.values[env] = vret;
     if (!handoff) {
       if (p.rewards && (steps_done > 0 || p.pass == 0)) p.rewards[env] = last_reward;
       if (p.dones) p.dones[env] = (uint8_t)((done_last || (nP == 0 && !need_reset)) ? 1 : 0);
@@ -730,6 +775,30 @@ extern "C" int bbx_launch_init(char* recs, uint32_t rec_bytes, int B, const uint
 }
 extern "C" int bbx_launch_mark_reset(char* recs, uint32_t rec_bytes, int B, const uint8_t* mask, hipStream_t stream) {
   hipLaunchKernelGGL(bbx_mark_reset_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, recs, rec_bytes, B, mask);
+  return (int)hipGetLastError();
+}
+
+// value(): clone environment src[k] of one record array into slot k of another (live prefixes only), optionally
+// re-seeding the built-in random agent of the clone
+template <int W>
+__global__ void bbx_clone_kernel(const char* src_recs, char* dst_recs, BbxLayout L, const int32_t* src, int n, const uint32_t* seeds) {
+  const int k = blockIdx.x * (blockDim.x / WAVE) + (int)(threadIdx.x / WAVE);
+  if (k >= n) return;
+  char* s = const_cast<char*>(src_recs) + (size_t)src[k] * L.rec_bytes;
+  char* d = dst_recs + (size_t)k * L.rec_bytes;
+  BbxHdr h = *(const BbxHdr*)s;
+  if (L.kind == 1) bstage_copy<W>(benv_view<W>(d, L), benv_view<W>(s, L), h.nG, h.nP);
+  else stage_copy<W>(env_view<W>(d, L), env_view<W>(s, L), h.nG, h.nP, h.arena_used);
+  if (lane_id() == 0) {
+    h.need_reset = 0; h.budget = 0; h.rollout_pos = 0; h.t = 0;
+    if (seeds) h.agent_seed = seeds[k];
+    *(BbxHdr*)d = h;
+  }
+}
+extern "C" int bbx_launch_clone(const char* src_recs, char* dst_recs, const BbxLayout* L, const int32_t* src, int n, const uint32_t* seeds, hipStream_t stream) {
+  const int blocks = (n + 3) / 4;
+  if (L->W == 2) hipLaunchKernelGGL((bbx_clone_kernel<2>), dim3(blocks), dim3(256), 0, stream, src_recs, dst_recs, *L, src, n, seeds);
+  else hipLaunchKernelGGL((bbx_clone_kernel<4>), dim3(blocks), dim3(256), 0, stream, src_recs, dst_recs, *L, src, n, seeds);
   return (int)hipGetLastError();
 }
 

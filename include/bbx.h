@@ -44,7 +44,7 @@ typedef struct bbx_caps {
   int32_t max_basis;      /* |G|  (<= 65535) */
   int32_t max_pairs;      /* |P| */
   int32_t arena_terms;    /* total terms of all basis polynomials */
-  int32_t max_poly_terms; /* longest intermediate polynomial during spoly/reduce (<= 65535) */
+  int32_t max_poly_terms; /* longest intermediate polynomial during spoly/reduce; basis elements hold <= 65535 terms */
   int32_t queue_slots;    /* pre-generated ideals buffered per environment for device-side resets */
   int32_t lds_max_basis;  /* |G| up to which a small (3-variable binomial) environment is kept LDS-resident
                              for a whole launch; 0 = default (128), negative = never */
@@ -108,6 +108,8 @@ int bbx_batch_size(const bbx_batch* b);
  * discounted return of a full Buchberger rollout from environment idx's current state.
  * Unknown strategies select First, as the reference's std::map lookup does. */
 int bbx_value(bbx_batch* b, int idx, const char* strategy, double gamma, double* out);
+/* the same for every environment of the batch at once: out[batch] */
+int bbx_values(bbx_batch* b, const char* strategy, double gamma, double* out);
 
 /* ---- same calls on caller-owned DEVICE buffers (e.g. torch tensors), asynchronous on `stream` ----
  * (hipStream_t passed as void*; NULL = the default stream).  obs may be NULL. */

@@ -221,3 +221,46 @@ def test_full_size_headline_untraced_vs_oracle():
             basis, pairs, order = env.state(e)
             want = _state_words(o.basis(), o.pairs(), o.reducer_order())
             assert np.array_equal(_state_words(basis, pairs, order), want), e
+
+
+def test_value_matches_reference_known_answers():
+    """env.value(strategy, gamma) (buchberger.cpp:332-351): device rollouts from a clone, discounted return in double.
+    Golden answers recorded from the compiled reference (tests/golden/values.json), compared with ==; unknown
+    strategy names select First like the reference's std::map lookup ('env' is what train.py actually passes)."""
+    from deepgroebner_amd import CLeadMonomialsEnv
+    vals = meta()["values"]
+    envs = {}
+    for key in sorted(vals):
+        parts = key.split("|")
+        dist, seed, t, strat = parts[0], int(parts[1]), int(parts[2]), parts[3]
+        gamma = 0.9 if len(parts) == 5 else 0.99
+        ek = (dist, seed)
+        if ek not in envs:
+            env = CLeadMonomialsEnv(dist, k=1)
+            env.seed(seed)
+            envs[ek] = [env, env.reset(), 0]
+        env, state, at = envs[ek]
+        while at < t:                                   # the walk oracle/make_golden.py did
+            state, _, _, _ = env.step(ffi.agent_hash(seed, at) % len(state))
+            at += 1
+        envs[ek][1], envs[ek][2] = state, at
+        assert env.value(strat, gamma) == vals[key], key
+
+
+def test_values_batch_and_state_untouched():
+    from deepgroebner_amd import VecLeadMonomialsEnv
+    bo = ffi.load("bo")
+    B = 6
+    env = VecLeadMonomialsEnv("3-20-10-weighted", batch=B, k=2)
+    env.seed(np.arange(B) + 50); obs0 = env.reset()
+    want = []
+    for e in range(B):
+        o = bo.env("3-20-10-weighted"); o.seed(50 + e); o.reset()
+        want.append([o.value(s, 0.99) for s in ("degree", "normal", "sugar", "first")])
+    for c, s in enumerate(("degree", "normal", "sugar", "first")):
+        got = env.values(s, 0.99)
+        assert got.tolist() == [w[c] for w in want], s
+    obs1 = env.observations()
+    assert all(np.array_equal(a, b) for a, b in zip(obs0, obs1))      # value() works on clones
+    v = env.value(2, "sample", 0.99)
+    assert v >= want[2][0]                                             # best of degree + 100 random rollouts
