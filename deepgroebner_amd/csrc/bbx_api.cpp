@@ -343,7 +343,12 @@ int create_common(std::unique_ptr<bbx::IdealGen> proto, int nvars_obs, int elimi
   if (caps) c = *caps;
   if (b->fixed) {
     if (!c.max_basis) c.max_basis = 4096; if (!c.max_pairs) c.max_pairs = 16384;
-    if (!c.arena_terms) c.arena_terms = 1 << 20; if (!c.max_poly_terms) c.max_poly_terms = 65536;
+    if (!c.max_poly_terms) c.max_poly_terms = 65536;
+    if (!c.arena_terms) {   // long polynomials (cyclic-7: ~2000 terms per element after a few hundred steps): as much
+                            // arena as a 48 GiB budget for the whole batch allows, between 2^18 and 2^22 terms
+      const long long per_env = (48LL << 30) / batch / 18;
+      c.arena_terms = (int)std::max(1LL << 18, std::min(1LL << 22, per_env));
+    }
   } else if (binomial) {
     if (!c.max_basis) c.max_basis = b->W == 2 ? 512 : 4096; if (!c.max_pairs) c.max_pairs = b->W == 2 ? (elimination == BBX_GEBAUERMOELLER ? 4096 : 32768) : 16384;
     if (!c.arena_terms) c.arena_terms = 2 * c.max_basis + 16; if (!c.max_poly_terms) c.max_poly_terms = 8;
