@@ -112,6 +112,7 @@ struct bbx_batch {
   hipStream_t last_stream = 0;
   bool in_flight = false;
   int staged = 0, fast = 0, envs_per_block = 4;
+  int wide = 0;                       // > 0: waves per environment of the wide (one workgroup per environment) class
 };
 
 namespace {
@@ -238,6 +239,7 @@ int enqueue(bbx_batch* b, const BbxParams& p0, bool resume, hipStream_t stream) 
   BbxParams p = p0;
   int kinds[2]; int nk = 0;
   if (p.nsteps == 0 && !resume) kinds[nk++] = 2;
+  else if (b->wide) kinds[nk++] = 4;
   else { if (b->staged) kinds[nk++] = b->fast ? 3 : 1; kinds[nk++] = 0; }
   for (int i = 0; i < nk; i++) {
     if (resume) { p.set_budget = 0; p.pass = 1; }
@@ -248,7 +250,7 @@ int enqueue(bbx_batch* b, const BbxParams& p0, bool resume, hipStream_t stream) 
       HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
       HIPCHK(hipEventRecord(e0, stream));
     }
-    int lrc = bbx_launch_step(&p, kinds[i], b->envs_per_block, stream);
+    int lrc = bbx_launch_step(&p, kinds[i], kinds[i] == 4 ? b->wide : b->envs_per_block, stream);
     if (lrc) return fail(BBX_E_DEVICE, "kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
     if (timed) { HIPCHK(hipEventRecord(e1, stream)); b->ev_open.push_back({e0, e1}); }
   }
@@ -358,6 +360,8 @@ int create_common(std::unique_ptr<bbx::IdealGen> proto, int nvars_obs, int elimi
   }
   if (!c.queue_slots) c.queue_slots = 8;
   b->binom = binomial && !c.general_class && !getenv("BBX_NO_BINOM");
+  // long-polynomial environments (fixed ideals such as cyclic-n) in small batches: one workgroup per environment
+  if (b->fixed && !getenv("BBX_NO_WIDE")) b->wide = c.wide_waves > 0 ? std::min(8, c.wide_waves) : (c.wide_waves < 0 ? 0 : (batch <= 2048 ? 8 : 0));
   // LDS-resident class: small binomial environments work out of LDS for the whole launch; anything that
   // outgrows it continues in the HBM-resident pass of the same launch sequence
   b->staged = 0;
@@ -472,7 +476,7 @@ int bbx_copy(const bbx_batch* s, bbx_batch** out) {
   b->elim = s->elim; b->rewards = s->rewards; b->sort_input = s->sort_input; b->sort_reducers = s->sort_reducers;
   b->fixed = s->fixed; b->binom = s->binom; b->L = s->L; b->LL = s->LL; b->slot_words = s->slot_words; b->nslots = s->nslots;
   b->h_q = s->h_q; b->h_tail = s->h_tail; b->h_head = s->h_head; b->q_dirty = true;
-  b->accounting = s->accounting; b->staged = s->staged; b->fast = s->fast; b->envs_per_block = s->envs_per_block;
+  b->wide = s->wide; b->accounting = s->accounting; b->staged = s->staged; b->fast = s->fast; b->envs_per_block = s->envs_per_block;
   for (auto& g : s->gens) b->gens.push_back(g->clone());
   const int batch = s->B;
   HIPCHK(hipMalloc((void**)&b->d_recs, (size_t)batch * b->L.rec_bytes));

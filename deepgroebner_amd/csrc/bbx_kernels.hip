@@ -185,10 +185,12 @@ template <int W> struct PView {
 // would exceed ocap.
 template <int W>
 __device__ int wave_merge(const PView<W>& A, const PView<W>& B, Mono<W>* tm, uint16_t* tc,
-                          Mono<W>* om, uint16_t* oc, int ocap) {
+                          Mono<W>* om, uint16_t* oc, int ocap, unsigned long long* prof = nullptr) {
   const int lane = lane_id();
+  unsigned long long t0_ = prof ? __builtin_amdgcn_s_memtime() : 0;
   const int na = A.n, nb = B.n, total = na + nb;
-  // pass 1: every term finds its slot in the virtual merged sequence
+  // pass 1: every term finds its slot in the virtual merged sequence (short polynomials only: long ones take
+  // wave_merge_tiled below)
   for (int x = lane; x < na; x += WAVE) {
     Mono<W> a = A.mono(x);
     int lo = 0, hi = nb;                       // #B terms strictly greater than a
@@ -205,6 +207,7 @@ __device__ int wave_merge(const PView<W>& A, const PView<W>& B, Mono<W>* tm, uin
     tm[y + lo] = b; tc[y + lo] = dup ? (uint16_t)0 : (uint16_t)B.coef(y);
   }
   wave_sync();
+  if (prof) { unsigned long long t1_ = __builtin_amdgcn_s_memtime(); prof[0] += t1_ - t0_; t0_ = t1_; }
   // pass 2: squeeze the holes out
   int nout = 0;
   for (int base = 0; base < total; base += WAVE) {
@@ -218,7 +221,213 @@ __device__ int wave_merge(const PView<W>& A, const PView<W>& B, Mono<W>* tm, uin
     nout += __popcll(mask);
   }
   wave_sync();
+  if (prof) { unsigned long long t1_ = __builtin_amdgcn_s_memtime(); prof[1] += t1_ - t0_; }
   return nout > ocap ? -1 : nout;
+}
+
+// ------------------------------------------------------------------ long polynomials: merge-path tiles through LDS
+// The rank-by-binary-search merge above gathers 16-byte terms at random from HBM/L2, one cache line per probe; for the
+// long polynomials of cyclic-n (hundreds to thousands of terms) that line traffic is the whole cost (profiles/).
+// Here the virtual merged sequence is cut into tiles of MT positions along merge-path diagonals (all tile boundaries
+// are searched at once, one per lane), each tile's two contiguous input ranges are streamed into LDS with coalesced
+// loads, ranks are computed against LDS, holes (cancelled or combined terms) are squeezed out with ballots and the
+// tile is appended to the output — no staging pass through memory.
+constexpr int MT = 256;                                   // virtual positions per tile
+template <int W> __host__ __device__ constexpr int merge_lds_bytes() { return 2 * (MT + 8) * (4 * W + 2); }
+
+// merge-path partition: lane l returns (i, j), i + j = d = (t0 + l) * MT (clamped), such that A[0..i) and B[0..j) are
+// exactly the first d terms of the merge (ties: the A term first); an equal pair is never split across the boundary
+template <int W>
+__device__ __forceinline__ void merge_partition(const PView<W>& A, const PView<W>& B, int t0, int& bi, int& bj) {
+  const int na = A.n, nb = B.n, total = na + nb;
+  int d = (t0 + lane_id()) * MT; d = d < total ? d : total;
+  int lo = d - nb > 0 ? d - nb : 0, hi = d < na ? d : na;
+  while (__any(lo < hi)) {
+    const bool act = lo < hi;
+    const int mid = (lo + hi) >> 1;
+    const Mono<W> am = A.mono(act ? mid : 0), bm = B.mono(act ? d - 1 - mid : 0);   // na, nb >= 1
+    if (act) { if (!m_gt(bm, am)) lo = mid + 1; else hi = mid; }
+  }
+  bi = lo; bj = d - lo;
+  const bool chk = bi > 0 && bj < nb;
+  const Mono<W> am = A.mono(chk ? bi - 1 : 0), bm = B.mono(chk ? bj : 0);
+  if (chk && m_eq(am, bm)) bj++;
+}
+
+// one tile: ranges A[i0..i1) and B[j0..j1) are streamed into LDS (coalesced), ranked against each other there, merged
+// with equal monomials combined and zero sums dropped, and written densely to (dm, dc).  Returns the number written
+// (<= MT); nothing beyond `cap` terms is stored.
+template <int W>
+__device__ int merge_tile(const PView<W>& A, const PView<W>& B, int i0, int j0, int i1, int j1, char* lds,
+                          Mono<W>* dm, uint16_t* dc, int cap) {
+  const int lane = lane_id();
+  Mono<W>* Lm = (Mono<W>*)lds;                             // tile terms: A range then B range
+  Mono<W>* Tm = Lm + (MT + 8);                             // the tile in merged order, with holes
+  uint16_t* Lc = (uint16_t*)(Tm + (MT + 8));
+  uint16_t* Tc = Lc + (MT + 8);
+  const int nat = i1 - i0, nbt = j1 - j0, nt = nat + nbt;  // nt <= MT + 1
+  constexpr int MU = (MT + 8 + WAVE - 1) / WAVE;           // terms per lane
+  Mono<W> mine[MU]; uint32_t mc[MU]; int lo2[MU];
+#pragma unroll
+  for (int u = 0; u < MU; u++) {                           // all loads issued, then consumed
+    const int q = lane + u * WAVE;
+    const bool isa = q < nat;
+    const int src = q < nt ? (isa ? i0 + q : j0 + q - nat) : 0;
+    const Mono<W> ma = A.m[isa ? src : 0], mb = B.m[isa ? 0 : src];
+    const uint32_t ca = A.c[isa ? src : 0], cb = B.c[isa ? 0 : src];
+    mine[u] = isa ? m_mul(ma, A.shift) : m_mul(mb, B.shift);
+    mc[u] = isa ? mulmod(ca, A.scale) : mulmod(cb, B.scale);
+    lo2[u] = 0;
+  }
+#pragma unroll
+  for (int u = 0; u < MU; u++) { const int q = lane + u * WAVE; if (q < nt) { Lm[q] = mine[u]; Lc[q] = (uint16_t)mc[u]; } }
+  wave_sync();
+  int top = 1; { const int mx = nat > nbt ? nat : nbt; while (top * 2 <= mx) top *= 2; }
+  for (int step = top; step > 0; step >>= 1) {             // rank of every term in the OTHER range, lockstep
+#pragma unroll
+    for (int u = 0; u < MU; u++) {
+      const int q = lane + u * WAVE;
+      const bool isa = q < nat;
+      const int lim = isa ? nbt : nat, off = isa ? nat : 0;
+      const int idx = lo2[u] + step;
+      const bool ok = q < nt && idx <= lim;
+      const Mono<W> pm = Lm[ok ? off + idx - 1 : 0];
+      // A term: count B terms strictly greater;  B term: count A terms greater or equal
+      const bool adv = isa ? m_gt(pm, mine[u]) : !m_gt(mine[u], pm);
+      lo2[u] = (ok && adv) ? idx : lo2[u];
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < MU; u++) {
+    const int q = lane + u * WAVE;
+    if (q < nt) {
+      uint32_t c = mc[u];
+      int pos;
+      if (q < nat) {
+        pos = q + lo2[u];
+        if (lo2[u] < nbt && m_eq(Lm[nat + lo2[u]], mine[u])) c = addmod(c, Lc[nat + lo2[u]]);
+      } else {
+        pos = (q - nat) + lo2[u];
+        if (lo2[u] > 0 && m_eq(Lm[lo2[u] - 1], mine[u])) c = 0;   // combined into the equal A term
+      }
+      Tm[pos] = mine[u]; Tc[pos] = (uint16_t)c;                    // c == 0 marks a hole
+    }
+  }
+  wave_sync();
+  int cnt = 0;
+  for (int base = 0; base < nt; base += WAVE) {            // squeeze the holes out
+    const int idx = base + lane;
+    const uint32_t c = idx < nt ? Tc[idx] : 0u;
+    const uint64_t mask = ballot64(c != 0);
+    if (c != 0) {
+      const int o = cnt + prefix_of(mask, lane);
+      if (o < cap) { dm[o] = Tm[idx]; dc[o] = (uint16_t)c; }
+    }
+    cnt += __popcll(mask);
+  }
+  wave_sync();
+  return cnt;
+}
+
+// single-wave driver: tiles in order, appended directly to the output
+template <int W>
+__device__ int wave_merge_tiled(const PView<W>& A, const PView<W>& B, char* lds, Mono<W>* om, uint16_t* oc, int ocap) {
+  const int total = A.n + B.n;
+  const int ntiles = (total + MT - 1) / MT;
+  int nout = 0;
+  for (int t0 = 0; t0 < ntiles; t0 += 63) {               // 64 boundaries -> 63 tiles per batch
+    int bi, bj;
+    merge_partition<W>(A, B, t0, bi, bj);
+    const int batch = ntiles - t0 < 63 ? ntiles - t0 : 63;
+    for (int tt = 0; tt < batch; tt++) {
+      const int i0 = __builtin_amdgcn_readlane(bi, tt), j0 = __builtin_amdgcn_readlane(bj, tt);
+      const int i1 = __builtin_amdgcn_readlane(bi, tt + 1), j1 = __builtin_amdgcn_readlane(bj, tt + 1);
+      const int room = ocap - nout > 0 ? ocap - nout : 0;
+      nout += merge_tile<W>(A, B, i0, j0, i1, j1, lds, om + (nout < ocap ? nout : 0), oc + (nout < ocap ? nout : 0), room);
+    }
+  }
+  return nout > ocap ? -1 : nout;
+}
+
+// ------------------------------------------------------------------ cooperative merge: one workgroup per environment
+// Long-polynomial environments (cyclic-n) run few in number (BASELINE: 512), so one wave each leaves most of the chip
+// idle while the merges of one reduction round are embarrassingly parallel across tiles.  In the wide kernel wave 0
+// of a workgroup (the leader) runs the ordinary step code; the other waves park at a workgroup barrier and are woken
+// for every long merge: tiles are dealt round-robin to all waves, each wave squeezes its tiles into the staging
+// buffer, then (second barrier) copies them to their final offsets, then (third barrier) the leader goes on alone.
+constexpr int COOP_MAXT = 510;                             // tiles per cooperative merge (130k terms at MT = 256)
+struct CoopCmd {
+  int cmd;                                                 // 1 = merge, 2 = exit
+  int ntiles, ocap, overflow;
+  int na, nb;
+  uint32_t ascale, bscale;
+  uint32_t ashift[4], bshift[4];
+  const void *am, *ac, *bm, *bc;
+  void *om, *oc, *tm, *tc;
+  int bi[COOP_MAXT + 2], bj[COOP_MAXT + 2], cnt[COOP_MAXT + 2];
+};
+constexpr int coop_cmd_bytes() { return (int)((sizeof(CoopCmd) + 255) / 256 * 256); }
+
+template <int W>
+__device__ void coop_work(CoopCmd* cc, char* lds_tile, int wave, int nwaves) {
+  PView<W> A, B;
+  A.m = (const Mono<W>*)cc->am; A.c = (const uint16_t*)cc->ac; A.n = cc->na; A.scale = cc->ascale;
+  B.m = (const Mono<W>*)cc->bm; B.c = (const uint16_t*)cc->bc; B.n = cc->nb; B.scale = cc->bscale;
+#pragma unroll
+  for (int q = 0; q < W; q++) { A.shift.w[q] = cc->ashift[q]; B.shift.w[q] = cc->bshift[q]; }
+  const int ntiles = cc->ntiles;
+  Mono<W>* tm = (Mono<W>*)cc->tm; uint16_t* tc = (uint16_t*)cc->tc;
+  for (int t = wave; t < ntiles; t += nwaves) {            // phase 1: my tiles, squeezed, into the staging buffer
+    const int c = merge_tile<W>(A, B, cc->bi[t], cc->bj[t], cc->bi[t + 1], cc->bj[t + 1], lds_tile, tm + (size_t)t * MT, tc + (size_t)t * MT, MT);
+    if (lane_id() == 0) cc->cnt[t] = c;
+  }
+  __syncthreads();
+  Mono<W>* om = (Mono<W>*)cc->om; uint16_t* oc = (uint16_t*)cc->oc;
+  for (int t = wave; t < ntiles; t += nwaves) {            // phase 2: to the final offsets
+    int off = 0;
+    for (int s = lane_id(); s < t; s += WAVE) off += cc->cnt[s];
+    for (int o = 32; o > 0; o >>= 1) off += __shfl_xor(off, o, WAVE);
+    const int c = cc->cnt[t];
+    if (off + c > cc->ocap) { if (lane_id() == 0) cc->overflow = 1; continue; }
+    for (int q = lane_id(); q < c; q += WAVE) { om[off + q] = tm[(size_t)t * MT + q]; oc[off + q] = tc[(size_t)t * MT + q]; }
+  }
+  __syncthreads();
+}
+
+// leader side; all helper waves are parked at the first barrier of coop_helper_loop
+template <int W>
+__device__ int coop_merge(const PView<W>& A, const PView<W>& B, CoopCmd* cc, char* lds_tile, int nwaves,
+                          Mono<W>* tm, uint16_t* tc, Mono<W>* om, uint16_t* oc, int ocap) {
+  const int lane = lane_id();
+  const int total = A.n + B.n;
+  const int ntiles = (total + MT - 1) / MT;
+  for (int t0 = 0; t0 <= ntiles; t0 += 64) {               // every boundary 0..ntiles
+    int bi, bj;
+    merge_partition<W>(A, B, t0, bi, bj);
+    if (t0 + lane <= ntiles) { cc->bi[t0 + lane] = bi; cc->bj[t0 + lane] = bj; }
+  }
+  if (lane == 0) {
+    cc->cmd = 1; cc->ntiles = ntiles; cc->ocap = ocap; cc->overflow = 0; cc->na = A.n; cc->nb = B.n;
+    cc->ascale = A.scale; cc->bscale = B.scale;
+    for (int q = 0; q < W; q++) { cc->ashift[q] = A.shift.w[q]; cc->bshift[q] = B.shift.w[q]; }
+    cc->am = A.m; cc->ac = A.c; cc->bm = B.m; cc->bc = B.c; cc->om = om; cc->oc = oc; cc->tm = tm; cc->tc = tc;
+  }
+  __syncthreads();                                         // barrier 1: wake the helpers
+  coop_work<W>(cc, lds_tile, 0, nwaves);                   // barriers 2 and 3 inside
+  int nout = 0;
+  for (int s = lane; s < ntiles; s += WAVE) nout += cc->cnt[s];
+  for (int o = 32; o > 0; o >>= 1) nout += __shfl_xor(nout, o, WAVE);
+  nout = uni(nout);
+  return (cc->overflow || nout > ocap) ? -1 : nout;
+}
+
+template <int W>
+__device__ void coop_helper_loop(CoopCmd* cc, char* lds_tile, int wave, int nwaves) {
+  for (;;) {
+    __syncthreads();                                       // barrier 1: wait for a command
+    if (cc->cmd == 2) break;
+    coop_work<W>(cc, lds_tile, wave, nwaves);              // barriers 2 and 3 inside
+  }
 }
 
 // ------------------------------------------------------------------ update()   buchberger.cpp:52-99
@@ -521,11 +730,16 @@ __device__ void stage_copy(const Env<W>& dst, const Env<W>& src, int nG, int nP,
   for (int i = lane; i < nT; i += WAVE) { dst.am[i] = src.am[i]; dst.ac[i] = src.ac[i]; }
 }
 
-template <int W, bool STAGED, bool TRACE>
-__device__ __forceinline__ void step_body(const BbxParams& p, char* smem) {
+template <int W, bool STAGED, bool TRACE, bool PROF = false>
+__device__ __forceinline__ void step_body(const BbxParams& p, char* smem, unsigned long long* prof_out = nullptr,
+                                          CoopCmd* coop = nullptr, int coop_waves = 0) {
   const int lane = lane_id();
-  const int wave_in_block = uni((int)(threadIdx.x / WAVE));   // provably wave-uniform: record addresses live in SGPRs
-  const int env = blockIdx.x * (blockDim.x / WAVE) + wave_in_block;
+  unsigned long long ps[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // diagnostic build: cycles per phase
+  unsigned long long pl = PROF ? __builtin_amdgcn_s_memtime() : 0;
+#define GSTAMP(slot) do { if (PROF) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); ps[slot] += t_ - pl; pl = t_; } } while (0)
+  // wide kernel (coop != null): one workgroup per environment, this is its leader wave
+  const int wave_in_block = coop ? 0 : uni((int)(threadIdx.x / WAVE));   // provably wave-uniform: record addresses live in SGPRs
+  const int env = coop ? (int)blockIdx.x : (int)(blockIdx.x * (blockDim.x / WAVE) + wave_in_block);
   if (env >= p.B) return;                       // whole wave exits together
   char* grec = p.recs + (size_t)env * p.L.rec_bytes;
   BbxHdr* ghdr = (BbxHdr*)grec;
@@ -562,6 +776,8 @@ __device__ __forceinline__ void step_body(const BbxParams& p, char* smem) {
   int steps_done = 0;
   double last_reward = 0.0;
   const bool tracing = TRACE && p.trace != nullptr;   // hashing code exists only in the TRACE instantiations
+  // per-wave LDS tile scratch of the merge-path merge (HBM-resident class only; the launcher provides it)
+  char* mlds = (!STAGED && smem != nullptr) ? smem + (coop ? (size_t)coop_cmd_bytes() : (size_t)wave_in_block * merge_lds_bytes<W>()) : nullptr;
 
   // scratch polynomials
   const int maxT = (int)L.maxT;
@@ -628,8 +844,12 @@ __device__ __forceinline__ void step_body(const BbxParams& p, char* smem) {
       hsug = uni(si > sj ? si : sj);
       if (hsug > 65535) { status = BBX_ST_DEG_OVERFLOW; break; }
       if (A.n + Bv.n > 2 * maxT) { status = BBX_ST_POLY_TOO_LONG; break; }
-      hn = wave_merge<W>(A, Bv, tm, tc, hm, hc, maxT);
+      GSTAMP(0);                                   // 0: loop top, agent, pair removal
+      const bool big = mlds && A.n > 0 && Bv.n > 0 && A.n + Bv.n > 64;
+      if (big && coop && A.n + Bv.n > 2 * MT && A.n + Bv.n <= COOP_MAXT * MT && A.n + Bv.n + MT <= 2 * maxT) hn = coop_merge<W>(A, Bv, coop, mlds, coop_waves, tm, tc, hm, hc, maxT);
+      else hn = big ? wave_merge_tiled<W>(A, Bv, mlds, hm, hc, maxT) : wave_merge<W>(A, Bv, tm, tc, hm, hc, maxT);
       if (hn < 0) { status = BBX_ST_POLY_TOO_LONG; break; }
+      GSTAMP(1);                                   // 1: S-polynomial merge
       alg_bytes += 12LL * (A.n + Bv.n + 2 + hn);   // both inputs read, S-polynomial written
     }
 
@@ -645,6 +865,7 @@ __device__ __forceinline__ void step_body(const BbxParams& p, char* smem) {
         uint64_t mask = ballot64(d);
         if (mask) { found = base + __builtin_ctzll(mask); break; }
       }
+      GSTAMP(2);                                  // 2: divisor scans
       if (found >= 0) {                         // h <- h - (LT h / LT f) f     (34-36)
         const int g = uni((int)e.sidx[found]);
         const uint32_t c = mulmod((uint32_t)uni((int)hc[hoff]), (uint32_t)uni((int)e.pinv[g]));
@@ -658,8 +879,13 @@ __device__ __forceinline__ void step_body(const BbxParams& p, char* smem) {
         if (hsug > 65535) { status = BBX_ST_DEG_OVERFLOW; overflow = true; break; }
         if (A.n + Bv.n > 2 * maxT) { status = BBX_ST_POLY_TOO_LONG; overflow = true; break; }
         Mono<W>* nm = (hm == hm0) ? hm1 : hm0; uint16_t* nc = (hc == hc0) ? hc1 : hc0;
-        int nn = wave_merge<W>(A, Bv, tm, tc, nm, nc, maxT);
+        GSTAMP(3);                                // 3: reducer fetch / setup
+        const bool big = mlds && A.n > 0 && Bv.n > 0 && A.n + Bv.n > 64;
+        int nn;
+        if (big && coop && A.n + Bv.n > 2 * MT && A.n + Bv.n <= COOP_MAXT * MT && A.n + Bv.n + MT <= 2 * maxT) nn = coop_merge<W>(A, Bv, coop, mlds, coop_waves, tm, tc, nm, nc, maxT);
+        else nn = big ? wave_merge_tiled<W>(A, Bv, mlds, nm, nc, maxT) : wave_merge<W>(A, Bv, tm, tc, nm, nc, maxT, PROF ? &ps[6] : nullptr);
         if (nn < 0) { status = BBX_ST_POLY_TOO_LONG; overflow = true; break; }
+        GSTAMP(4);                                // 4: reduction merges (6/7: their pass 1 / pass 2)
         alg_bytes += 8LL * (found + 1) + 12LL * (Bv.n + 1) + 12LL * (A.n + 1 + nn);
         hm = nm; hc = nc; hn = nn; hoff = 0;
         nsteps_red++;
@@ -671,6 +897,7 @@ __device__ __forceinline__ void step_body(const BbxParams& p, char* smem) {
         int d = uni((int)m_deg(lmh));
         rsug = d > rsug ? d : rsug;
         rn++; hoff++;
+        GSTAMP(5);                                // 5: tail moves
       }
     }
     if (overflow) break;
@@ -711,6 +938,7 @@ __device__ __forceinline__ void step_body(const BbxParams& p, char* smem) {
     }
   }
 
+  if (PROF && prof_out && lane == 0) for (int i = 0; i < 10; i++) prof_out[(size_t)env * 10 + i] = ps[i];
   // an environment that must continue in the follow-up pass reports nothing yet
   const bool handoff = status == BBX_ST_SPILL;
   // ---- observation of the state the caller sees next ------------------------------------------
@@ -746,6 +974,27 @@ __global__ __launch_bounds__(256) void bbx_step_kernel(BbxParams p) {
 template <int W>
 __global__ __launch_bounds__(256) void bbx_aux_kernel(BbxParams p) {
   step_body<W, false, false>(p, nullptr);
+}
+// wide class: one workgroup of NW waves per environment (long polynomials, few environments); LDS =
+// [CoopCmd][NW x merge tile scratch]
+template <int W, bool TRACE>
+__global__ __launch_bounds__(512) void bbx_wide_kernel(BbxParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  CoopCmd* cc = (CoopCmd*)smem;
+  const int wave = uni((int)(threadIdx.x / WAVE)), nwaves = (int)(blockDim.x / WAVE);
+  if (wave == 0) {
+    step_body<W, false, TRACE>(p, smem, nullptr, cc, nwaves);
+    if (lane_id() == 0) cc->cmd = 2;
+    __syncthreads();                                       // release the helpers for good
+  } else {
+    coop_helper_loop<W>(cc, smem + coop_cmd_bytes() + (size_t)wave * merge_lds_bytes<W>(), wave, nwaves);
+  }
+}
+// diagnostic build with s_memtime stamps (BBX_PROF=1), never used for reported numbers
+template <int W>
+__global__ __launch_bounds__(256) void bbx_step_prof_kernel(BbxParams p, unsigned long long* prof) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  step_body<W, false, false, true>(p, smem, prof);
 }
 
 #include "bbx_binom.h"
@@ -833,8 +1082,31 @@ static int launch_w(const BbxParams* p, int kind, int blocks, int threads, size_
     else { if (trace) BBX_LAUNCH((bbx_step_kernel<W, true, true>)); else BBX_LAUNCH((bbx_step_kernel<W, true, false>)); }
     return 0;
   }
+  if (!binom && !trace && getenv("BBX_PROF")) {
+    static unsigned long long* d_prof = nullptr;
+    if (!d_prof) (void)hipMalloc((void**)&d_prof, (size_t)p->B * 10 * sizeof(unsigned long long));
+    lds = (size_t)(threads / WAVE) * merge_lds_bytes<W>();
+    (void)hipFuncSetAttribute((const void*)bbx_step_prof_kernel<W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((bbx_step_prof_kernel<W>), dim3(blocks), dim3(threads), lds, stream, *p, d_prof);
+    (void)hipStreamSynchronize(stream);
+    std::vector<unsigned long long> h((size_t)p->B * 10);
+    (void)hipMemcpy(h.data(), d_prof, h.size() * 8, hipMemcpyDeviceToHost);
+    double s[10] = {0}, tot = 0;
+    for (int e = 0; e < p->B; e++) for (int i = 0; i < 10; i++) s[i] += (double)h[(size_t)e * 10 + i];
+    for (int i = 0; i < 6; i++) tot += s[i];
+    fprintf(stderr, "[bbx prof general] nsteps=%d kcycles/env:", p->nsteps);
+    for (int i = 0; i < 10; i++) fprintf(stderr, " p%d=%.0f(%.0f%%)", i, s[i] / p->B / 1e3, 100.0 * s[i] / tot);
+    fprintf(stderr, "\n");
+    return 0;
+  }
   if (binom) { if (trace) BBX_LAUNCH((bbx_binom_kernel<W, false, true>)); else BBX_LAUNCH((bbx_binom_kernel<W, false, false>)); }
-  else { if (trace) BBX_LAUNCH((bbx_step_kernel<W, false, true>)); else BBX_LAUNCH((bbx_step_kernel<W, false, false>)); }
+  else {
+    lds = (size_t)(threads / WAVE) * merge_lds_bytes<W>();          // merge-path tile scratch, one per wave
+    const void* fn = trace ? (const void*)bbx_step_kernel<W, false, true> : (const void*)bbx_step_kernel<W, false, false>;
+    hipError_t err = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (err != hipSuccess) return (int)err;
+    if (trace) BBX_LAUNCH((bbx_step_kernel<W, false, true>)); else BBX_LAUNCH((bbx_step_kernel<W, false, false>));
+  }
   return 0;
 }
 // kind 3: the hand-tuned LDS/register-resident kernel (bbx_fast.h) for W == 2 binomial, GM, sorted reducers
@@ -873,6 +1145,20 @@ extern "C" int bbx_launch_step(const BbxParams* p, int kind, int envs_per_block,
   const int threads = envs_per_block * WAVE;
   const int blocks = (p->B + envs_per_block - 1) / envs_per_block;
   if (kind == 3) { launch_fast(p, blocks, threads, envs_per_block, stream); return (int)hipGetLastError(); }
+  if (kind == 4) {                                         // wide: envs_per_block is the number of waves per environment
+    const int nw = envs_per_block;
+    const size_t wl = (size_t)coop_cmd_bytes() + (size_t)nw * (p->L.W == 2 ? merge_lds_bytes<2>() : merge_lds_bytes<4>());
+    const bool tr = p->trace != nullptr;
+    const void* fn = p->L.W == 2 ? (tr ? (const void*)bbx_wide_kernel<2, true> : (const void*)bbx_wide_kernel<2, false>)
+                                 : (tr ? (const void*)bbx_wide_kernel<4, true> : (const void*)bbx_wide_kernel<4, false>);
+    hipError_t err = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl);
+    if (err != hipSuccess) return (int)err;
+    if (p->L.W == 2) { if (tr) hipLaunchKernelGGL((bbx_wide_kernel<2, true>), dim3(p->B), dim3(nw * WAVE), wl, stream, *p);
+                       else hipLaunchKernelGGL((bbx_wide_kernel<2, false>), dim3(p->B), dim3(nw * WAVE), wl, stream, *p); }
+    else { if (tr) hipLaunchKernelGGL((bbx_wide_kernel<4, true>), dim3(p->B), dim3(nw * WAVE), wl, stream, *p);
+           else hipLaunchKernelGGL((bbx_wide_kernel<4, false>), dim3(p->B), dim3(nw * WAVE), wl, stream, *p); }
+    return (int)hipGetLastError();
+  }
   const size_t lds = kind == 1 ? (size_t)envs_per_block * p->LL.rec_bytes : 0;
   int rc = p->L.W == 2 ? launch_w<2>(p, kind, blocks, threads, lds, stream) : launch_w<4>(p, kind, blocks, threads, lds, stream);
   if (rc) return rc;

@@ -48,6 +48,8 @@ typedef struct bbx_caps {
   int32_t queue_slots;    /* pre-generated ideals buffered per environment for device-side resets */
   int32_t lds_max_basis;  /* |G| up to which a small (3-variable binomial) environment is kept LDS-resident
                              for a whole launch; 0 = default (128), negative = never */
+  int32_t wide_waves;     /* fixed ideals (long polynomials): waves of the workgroup that serves ONE environment;
+                             0 = default (8 when batch <= 2048, else one wave per environment), negative = never */
   int32_t general_class;  /* non-zero: never use the binomial kernel class (term arena + general merges even for
                              binomial ideals); for testing the general path on the same inputs */
 } bbx_caps;

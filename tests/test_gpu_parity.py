@@ -335,3 +335,29 @@ def test_rollout_device_with_torch_buffers():
         assert float(rew[e]) == r and bool(done[e]) == d and int(rows[e]) == o.nP
         got = obs[e].cpu().numpy()
         assert np.array_equal(got[:o.nP], o.obs(k)) and (got[o.nP:] == -1).all()
+
+
+@pytest.mark.parametrize("wide", [0, -1, 3])
+def test_long_polynomials_cyclic7_all_merge_paths(wide):
+    """cyclic-7 far enough into an episode that polynomials have hundreds to thousands of terms: exercises the
+    merge-path tiled merge (one wave) and the cooperative workgroup merge (wide kernel, leader + helper waves)
+    against the oracle: per-step rewards via counters, and the complete final state."""
+    from deepgroebner_amd import VecLeadMonomialsEnv
+    bo = ffi.load("bo")
+    B, T, k = 3, 110, 2
+    env = VecLeadMonomialsEnv("cyclic-7", batch=B, k=k, caps={"wide_waves": wide, "arena_terms": 1 << 19})
+    env.seed_agent(np.arange(B) + 40); env.reset()
+    env.rollout("random", T, auto_reset=False)
+    st = env.stats()
+    for e in range(B):
+        o = bo.env("cyclic-7"); o.reset()
+        adds = 0
+        for t in range(T):
+            if o.nP == 0:
+                break
+            adds += int(-o.step(ffi.agent_action(40 + e, t, o.nP)))
+        assert st[e, 1] == adds and st[e, 7] == o.nG and int(env.rows[e]) == o.nP
+        basis, pairs, order = env.state(e)
+        assert max(len(c) for c, _ in basis) > 600                     # long enough to take the cooperative path
+        want = _state_words(o.basis(), o.pairs(), o.reducer_order())
+        assert np.array_equal(_state_words(basis, pairs, order), want), e
