@@ -1,5 +1,5 @@
 """deepgroebner_amd — MI355X-native BuchbergerEnv step path (drop-in for deepgroebner's
 LeadMonomialsEnv / CLeadMonomialsEnv and its ideal generators)."""
-from .buchberger import CLeadMonomialsEnv, LeadMonomialsEnv, VecLeadMonomialsEnv  # noqa: F401
+from .buchberger import CLeadMonomialsEnv, LeadMonomialsEnv, VecLeadMonomialsEnv, strategy_stats  # noqa: F401
 from .ideals import (FixedIdealGenerator, RandomBinomialIdealGenerator, RandomIdealGenerator,  # noqa: F401
                      basis, cyclic, degree_distribution, parse_ideal_dist)

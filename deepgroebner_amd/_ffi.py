@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(HERE, "libbbx.so")
 
 BBX_GEBAUERMOELLER, BBX_LCM, BBX_NONE = 0, 1, 2
 BBX_ADDITIONS, BBX_REDUCTIONS = 0, 1
-AGENTS = {"external": 0, "random": 1, "degree": 2, "first": 3}
+AGENTS = {"external": 0, "random": 1, "degree": 2, "first": 3, "normal": 4, "sugar": 5}
 ELIMINATION = {"gebauermoeller": 0, "lcm": 1, "none": 2}
 REWARDS = {"additions": 0, "reductions": 1}
 
@@ -45,6 +45,7 @@ _i32p = C.POINTER(C.c_int32)
 SIGNATURES = {
     "bbx_create": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Caps), C.POINTER(_vp)]),
     "bbx_create_fixed": (C.c_int, [C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Caps), C.POINTER(_vp)]),
+    "bbx_create_ideals": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Caps), C.POINTER(_vp)]),
     "bbx_destroy": (None, [_vp]),
     "bbx_copy": (C.c_int, [_vp, C.POINTER(_vp)]),
     "bbx_seed": (C.c_int, [_vp, _vp]),

@@ -39,7 +39,23 @@ class VecLeadMonomialsEnv:
         self._h = C.c_void_p()
         self.batch, self.k = int(batch), int(k)
         el, rw = _ffi.ELIMINATION[elimination], _ffi.REWARDS[rewards]
-        if isinstance(ideal_dist, FixedIdealGenerator):
+        if isinstance(ideal_dist, (list, tuple)):             # a list of ideals: environment e gets ideals e, e+batch, ...
+            ideals = [[[(int(c), tuple(int(x) for x in e)) for c, e in f] for f in F] for F in ideal_dist]
+            npolys = np.array([len(F) for F in ideals], dtype=np.int32)
+            nterms = np.array([len(f) for F in ideals for f in F], dtype=np.int32)
+            coefs = np.array([c for F in ideals for f in F for c, _ in f], dtype=np.int32)
+            exps = np.zeros((len(coefs), NV), dtype=np.int32)
+            r = 0
+            for F in ideals:
+                for f in F:
+                    for _, e in f:
+                        exps[r, :len(e)] = e
+                        r += 1
+            nv = max(len(e) for F in ideals for f in F for _, e in f)
+            _ffi.check(L.bbx_create_ideals(len(ideals), _ffi.ptr(npolys), _ffi.ptr(nterms), _ffi.ptr(coefs), _ffi.ptr(exps), nv, el, rw,
+                                           int(sort_input), int(sort_reducers), self.k, self.batch, int(device),
+                                           _caps(caps), C.byref(self._h)))
+        elif isinstance(ideal_dist, FixedIdealGenerator):
             F = ideal_dist.F
             nterms = np.array([len(f) for f in F], dtype=np.int32)
             coefs = np.array([c for f in F for c, _ in f], dtype=np.int32)
@@ -231,3 +247,16 @@ class LeadMonomialsEnv(CLeadMonomialsEnv):
 
     def value(self, gamma=0.99):
         return self._vec.value(0, "degree", gamma)
+
+
+def strategy_stats(ideals, strategy="degree", elimination="gebauermoeller", sort_reducers=True, device=0, caps=None):
+    """Full Buchberger runs of one selection strategy over a list of ideals, all at once on the GPU: the columns
+    scripts/make_strat.cpp:44-70 of the reference writes per ideal.  Returns int64 [len(ideals), 3] =
+    (ZeroReductions, NonzeroReductions, PolynomialAdditions)."""
+    env = VecLeadMonomialsEnv(list(ideals), batch=len(ideals), elimination=elimination, sort_reducers=sort_reducers,
+                              k=1, device=device, caps=caps)
+    env.reset()
+    if int(env.rows.max()) > 0:
+        env.rollout(strategy, 1 << 30, auto_reset=False)
+    st = env.stats()
+    return np.stack([st[:, 3], st[:, 0] - st[:, 3], st[:, 1]], axis=1)

@@ -240,7 +240,10 @@ int enqueue(bbx_batch* b, const BbxParams& p0, bool resume, hipStream_t stream) 
   int kinds[2]; int nk = 0;
   if (p.nsteps == 0 && !resume) kinds[nk++] = 2;
   else if (b->wide) kinds[nk++] = 4;
-  else { if (b->staged) kinds[nk++] = b->fast ? 3 : 1; kinds[nk++] = 0; }
+  else {   // the hand-tuned kernel knows the external / random / degree / first agents; the others take the class kernel
+    if (b->staged) kinds[nk++] = (b->fast && p.agent <= BBX_AGENT_FIRST) ? 3 : 1;
+    kinds[nk++] = 0;
+  }
   for (int i = 0; i < nk; i++) {
     if (resume) { p.set_budget = 0; p.pass = 1; }
     else if (i > 0) { p.set_budget = 0; p.pass = 1; }
@@ -313,7 +316,8 @@ int copy_out(bbx_batch* b, double* rewards, uint8_t* dones, int32_t* rows) {
 }
 
 int create_common(std::unique_ptr<bbx::IdealGen> proto, int nvars_obs, int elimination, int rewards, int sort_input,
-                  int sort_reducers, int k, int batch, int device, const bbx_caps* caps, bbx_batch** out) {
+                  int sort_reducers, int k, int batch, int device, const bbx_caps* caps, bbx_batch** out,
+                  const std::shared_ptr<const std::vector<bbx::HIdeal>>& list = nullptr) {
   if (!out) return fail(BBX_E_ARG, "out is null");
   *out = nullptr;
   if (batch < 1 || k < 1) return fail(BBX_E_ARG, "batch and k must be positive");
@@ -335,15 +339,16 @@ int create_common(std::unique_ptr<bbx::IdealGen> proto, int nvars_obs, int elimi
     bbx::HIdeal F; std::string err;
     if (!probe->next(F, &err)) return fail(BBX_E_GENERATOR, "%s", err.c_str());
     for (auto& f : F) for (auto& t : f.t) for (int v = 0; v < bbx::kN; v++) if (t.e[v]) maxvar = std::max(maxvar, v + 1);
-    if (!b->fixed) maxvar = std::max(maxvar, proto->nvars());
+    if (list) for (auto& I : *list) for (auto& f : I) for (auto& t : f.t) for (int v = 0; v < bbx::kN; v++) if (t.e[v]) maxvar = std::max(maxvar, v + 1);
+    if (!b->fixed && !list) maxvar = std::max(maxvar, proto->nvars());
   }
   if (maxvar > 7) return fail(BBX_E_UNSUPPORTED, "8-variable rings are not supported by the device monomial format (7 exponents + degree)");
   if (b->nvars > 7) return fail(BBX_E_UNSUPPORTED, "observation width of %d variables is not supported", b->nvars);
   b->W = maxvar <= 3 ? 2 : 4;
-  const bool binomial = !b->fixed && proto->max_terms_hint() == 2;
+  const bool binomial = !b->fixed && !list && proto->max_terms_hint() == 2;
   bbx_caps c{};
   if (caps) c = *caps;
-  if (b->fixed) {
+  if (b->fixed || list) {
     if (!c.max_basis) c.max_basis = 4096; if (!c.max_pairs) c.max_pairs = 16384;
     if (!c.max_poly_terms) c.max_poly_terms = 65536;
     if (!c.arena_terms) {   // long polynomials (cyclic-7: ~2000 terms per element after a few hundred steps): as much
@@ -361,7 +366,7 @@ int create_common(std::unique_ptr<bbx::IdealGen> proto, int nvars_obs, int elimi
   if (!c.queue_slots) c.queue_slots = 8;
   b->binom = binomial && !c.general_class && !getenv("BBX_NO_BINOM");
   // long-polynomial environments (fixed ideals such as cyclic-n) in small batches: one workgroup per environment
-  if (b->fixed && !getenv("BBX_NO_WIDE")) b->wide = c.wide_waves > 0 ? std::min(8, c.wide_waves) : (c.wide_waves < 0 ? 0 : (batch <= 2048 ? 8 : 0));
+  if ((b->fixed || list) && !getenv("BBX_NO_WIDE")) b->wide = c.wide_waves > 0 ? std::min(8, c.wide_waves) : (c.wide_waves < 0 ? 0 : (batch <= 2048 ? 8 : 0));
   // LDS-resident class: small binomial environments work out of LDS for the whole launch; anything that
   // outgrows it continues in the HBM-resident pass of the same launch sequence
   b->staged = 0;
@@ -384,7 +389,10 @@ int create_common(std::unique_ptr<bbx::IdealGen> proto, int nvars_obs, int elimi
 
   if (b->fixed) b->gens.push_back(std::move(proto));
   else {
-    for (int e = 0; e < batch; e++) { b->gens.push_back(proto->clone()); b->gens.back()->seed(5489 + e); }
+    for (int e = 0; e < batch; e++) {
+      if (list) b->gens.push_back(bbx::make_list(list, e, batch, proto->nvars()));   // environment e: ideals e, e+B, ...
+      else { b->gens.push_back(proto->clone()); b->gens.back()->seed(5489 + e); }
+    }
   }
   const size_t qwords = b->fixed ? b->slot_words : (size_t)batch * b->nslots * b->slot_words;
   b->h_q.assign(qwords, 0u);
@@ -455,6 +463,32 @@ int bbx_create_fixed(int npolys, const int32_t* nterms, const int32_t* coefs, co
     F.push_back(bbx::poly_from_terms(ts));
   }
   return create_common(bbx::make_fixed(F), nvars_obs, elimination, rewards, sort_input, sort_reducers, k, batch, device, caps, out);
+}
+
+int bbx_create_ideals(int nideals, const int32_t* npolys, const int32_t* nterms, const int32_t* coefs, const int32_t* exps,
+                      int nvars_obs, int elimination, int rewards, int sort_input, int sort_reducers,
+                      int k, int batch, int device, const bbx_caps* caps, bbx_batch** out) {
+  if (nideals < 1 || !npolys || !nterms || !coefs || !exps || nvars_obs < 1) return fail(BBX_E_ARG, "bad ideal list");
+  auto list = std::make_shared<std::vector<bbx::HIdeal>>();
+  size_t pi = 0, at = 0;
+  for (int i = 0; i < nideals; i++) {
+    bbx::HIdeal F;
+    for (int p = 0; p < npolys[i]; p++, pi++) {
+      std::vector<bbx::HTerm> ts;
+      for (int t = 0; t < nterms[pi]; t++, at++) {
+        bbx::HTerm h; h.c = bbx::coef_norm(coefs[at]); h.deg = 0;
+        for (int v = 0; v < bbx::kN; v++) { h.e[v] = exps[at * bbx::kN + v]; h.deg += h.e[v]; }
+        ts.push_back(h);
+      }
+      if (ts.empty()) return fail(BBX_E_ARG, "zero polynomial among the generators");
+      F.push_back(bbx::poly_from_terms(ts));
+    }
+    if (F.empty()) return fail(BBX_E_ARG, "empty ideal in the list");
+    list->push_back(F);
+  }
+  std::shared_ptr<const std::vector<bbx::HIdeal>> clist = list;
+  return create_common(bbx::make_list(clist, 0, 1, nvars_obs), nvars_obs, elimination, rewards, sort_input, sort_reducers,
+                       k, batch, device, caps, out, clist);
 }
 
 void bbx_destroy(bbx_batch* b) {
@@ -551,7 +585,7 @@ int bbx_step(bbx_batch* b, const int32_t* actions, double* rewards, uint8_t* don
 }
 
 int bbx_rollout(bbx_batch* b, int agent, int nsteps, int auto_reset, double* rewards, uint8_t* dones, int32_t* rows) {
-  if (!b || nsteps < 0 || agent < BBX_RANDOM_HASH || agent > BBX_FIRST) return fail(BBX_E_ARG, "bad rollout arguments");
+  if (!b || nsteps < 0 || agent < BBX_RANDOM_HASH || agent > BBX_SUGAR) return fail(BBX_E_ARG, "bad rollout arguments");
   HIPCHK(hipSetDevice(b->device));
   if (b->d_trace && nsteps > b->trace_cap) return fail(BBX_E_ARG, "rollout of %d steps exceeds the trace capacity %d", nsteps, b->trace_cap);
   BbxParams p; fill_params(b, &p);
@@ -576,7 +610,7 @@ int bbx_step_device(bbx_batch* b, const int32_t* d_actions, double* d_rewards, u
 
 int bbx_rollout_device(bbx_batch* b, int agent, int nsteps, int auto_reset, double* d_rewards, uint8_t* d_dones,
                        int32_t* d_rows, int32_t* d_obs, int obs_rows, int obs_fill, int obs_every_step, void* stream) {
-  if (!b || nsteps < 0 || agent < BBX_RANDOM_HASH || agent > BBX_FIRST) return fail(BBX_E_ARG, "bad rollout arguments");
+  if (!b || nsteps < 0 || agent < BBX_RANDOM_HASH || agent > BBX_SUGAR) return fail(BBX_E_ARG, "bad rollout arguments");
   HIPCHK(hipSetDevice(b->device));
   BbxParams p; fill_params(b, &p);
   p.obs_every_step = obs_every_step ? 1 : 0;

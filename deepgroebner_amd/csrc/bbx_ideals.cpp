@@ -192,6 +192,29 @@ class FixedGen : public IdealGen {
   int n_;
 };
 
+class ListGen : public IdealGen {
+ public:
+  ListGen(std::shared_ptr<const std::vector<HIdeal>> ideals, int first, int stride, int nvars)
+      : ideals_(std::move(ideals)), at_(first), stride_(stride), n_(nvars) {
+    maxt_ = 1; maxp_ = 1;
+    for (auto& F : *ideals_) { maxp_ = std::max(maxp_, (int)F.size()); for (auto& f : F) maxt_ = std::max(maxt_, (int)f.t.size()); }
+  }
+  bool next(HIdeal& out, std::string*) override {
+    const size_t n = ideals_->size();
+    out = (*ideals_)[(size_t)at_ % n];
+    at_ = (int)(((size_t)at_ + (size_t)stride_) % (n * (size_t)std::max(stride_, 1)));
+    return true;
+  }
+  int nvars() const override { return n_; }
+  std::unique_ptr<IdealGen> clone() const override { return std::make_unique<ListGen>(*this); }
+  int max_terms_hint() const override { return maxt_; }
+  int npolys() const override { return maxp_; }
+  void set_first(int first) { at_ = first; }
+ private:
+  std::shared_ptr<const std::vector<HIdeal>> ideals_;
+  int at_, stride_, n_, maxt_, maxp_;
+};
+
 class RandomBase : public IdealGen {
  public:
   RandomBase(int n, int d, int s, DistType dist, bool constants, bool homogeneous)
@@ -284,6 +307,9 @@ class RandomGen : public RandomBase {     // ideals.cpp:203-231
 }  // namespace
 
 std::unique_ptr<IdealGen> make_fixed(const HIdeal& F) { return std::make_unique<FixedGen>(F); }
+std::unique_ptr<IdealGen> make_list(std::shared_ptr<const std::vector<HIdeal>> ideals, int first, int stride, int nvars) {
+  return std::make_unique<ListGen>(std::move(ideals), first, stride, nvars);
+}
 
 std::unique_ptr<IdealGen> parse_ideal_dist(const std::string& ideal_dist, std::string* err) {
   std::vector<std::string> a;

@@ -50,6 +50,8 @@ std::vector<HPoly> cyclic(int n);                         // ideals.cpp:16-36
 std::vector<std::array<int, kN>> basis(int n, int d);     // ideals.cpp:39-64
 std::vector<double> degree_probabilities(int n, int d, DistType dist, bool constants);
 std::unique_ptr<IdealGen> make_fixed(const HIdeal& F);
+// a generator that walks a shared list of ideals: first, first + stride, ... (wrapping around)
+std::unique_ptr<IdealGen> make_list(std::shared_ptr<const std::vector<HIdeal>> ideals, int first, int stride, int nvars);
 std::unique_ptr<IdealGen> parse_ideal_dist(const std::string& dist, std::string* err);  // ideals.cpp:103-143
 
 }  // namespace bbx

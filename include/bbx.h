@@ -37,7 +37,7 @@ enum bbx_status {
 enum { BBX_GEBAUERMOELLER = 0, BBX_LCM = 1, BBX_NONE = 2 };
 enum { BBX_ADDITIONS = 0, BBX_REDUCTIONS = 1 };
 /* built-in device-side agents for bbx_rollout (0 = actions supplied by the caller) */
-enum { BBX_EXTERNAL = 0, BBX_RANDOM_HASH = 1, BBX_DEGREE = 2, BBX_FIRST = 3 };
+enum { BBX_EXTERNAL = 0, BBX_RANDOM_HASH = 1, BBX_DEGREE = 2, BBX_FIRST = 3, BBX_NORMAL = 4, BBX_SUGAR = 5 };
 
 /* Per-environment capacities; 0 picks a default suited to the distribution. */
 typedef struct bbx_caps {
@@ -74,6 +74,13 @@ int bbx_create(const char* ideal_dist, int elimination, int rewards, int sort_in
 int bbx_create_fixed(int npolys, const int32_t* nterms, const int32_t* coefs, const int32_t* exps, int nvars_obs,
                      int elimination, int rewards, int sort_input, int sort_reducers,
                      int k, int batch, int device, const bbx_caps* caps, bbx_batch** out);
+/* A list of ideals instead of one (what scripts/make_strat.cpp:12-72 iterates over): environment e is reset to ideals
+ * e, e + batch, e + 2*batch, ... (wrapping around).  npolys[nideals]; nterms per polynomial, coefs, exps concatenated.
+ * Together with bbx_rollout(agent, huge nsteps, auto_reset = 0) and bbx_stats this yields the reference's
+ * ZeroReductions / NonzeroReductions / PolynomialAdditions columns per ideal and strategy. */
+int bbx_create_ideals(int nideals, const int32_t* npolys, const int32_t* nterms, const int32_t* coefs, const int32_t* exps,
+                      int nvars_obs, int elimination, int rewards, int sort_input, int sort_reducers,
+                      int k, int batch, int device, const bbx_caps* caps, bbx_batch** out);
 void bbx_destroy(bbx_batch* b);
 /* LeadMonomialsEnv copy constructor (buchberger.pxd:11, wrapped.pyx:35-38): deep clone incl. the
  * generators' RNG state. */

@@ -361,3 +361,28 @@ def test_long_polynomials_cyclic7_all_merge_paths(wide):
         assert max(len(c) for c, _ in basis) > 600                     # long enough to take the cooperative path
         want = _state_words(o.basis(), o.pairs(), o.reducer_order())
         assert np.array_equal(_state_words(basis, pairs, order), want), e
+
+
+def test_strategy_stats_like_make_strat():
+    """scripts/make_strat.cpp of the reference: full Buchberger per ideal and strategy -> ZeroReductions,
+    NonzeroReductions, PolynomialAdditions.  A mixed list of ideals (random binomial, random dense, cyclic) in one
+    batch against the oracle's buchberger() statistics, plus the cyclic known answers of SURVEY 8c."""
+    from deepgroebner_amd import strategy_stats
+    bo = ffi.load("bo")
+    ideals = []
+    for dist, seed in (("3-20-10-weighted", 3), ("3-6-5-0.5-uniform", 4), ("4-5-4-weighted", 5), ("3-20-10-uniform", 6)):
+        g = bo.generator(dist); g.seed(seed)
+        ideals += [g.next() for _ in range(3)]
+    ideals += [bo.cyclic(4), bo.cyclic(5)]
+    trim = [[[(c, e[:5]) for c, e in f] for f in F] for F in ideals]
+    for strategy in ("degree", "normal", "sugar", "first"):
+        if strategy == "first":
+            sub = trim[:-1]                                   # First explodes on cyclic-5
+        else:
+            sub = trim
+        got = strategy_stats(sub, strategy)
+        for n, F in enumerate(sub):
+            _, st = bo.buchberger(F, selection=strategy, want_basis=False)
+            assert got[n].tolist() == [st["zero_reductions"], st["nonzero_reductions"], st["polynomial_additions"]], (strategy, n)
+    got = strategy_stats([trim[-1]], "degree")
+    assert got[0].tolist() == [69, 41, 1442]                  # cyclic-5, Degree (SURVEY 8c)
