@@ -112,9 +112,11 @@ class VecLeadMonomialsEnv:
         _ffi.check(_ffi.lib().bbx_reset(self._h, _ffi.ptr(m), _ffi.ptr(self.rows)))
         return self.observations()
 
-    def step(self, actions):
+    def step(self, actions, auto_reset=False):
+        """auto_reset=True: finished environments start their next episode inside the same call (VecEnv style)."""
         a = np.ascontiguousarray(np.broadcast_to(np.asarray(actions, dtype=np.int32), (self.batch,)))
-        _ffi.check(_ffi.lib().bbx_step(self._h, _ffi.ptr(a), _ffi.ptr(self._rewards), _ffi.ptr(self._dones), _ffi.ptr(self.rows)))
+        fn = _ffi.lib().bbx_step_autoreset if auto_reset else _ffi.lib().bbx_step
+        _ffi.check(fn(self._h, _ffi.ptr(a), _ffi.ptr(self._rewards), _ffi.ptr(self._dones), _ffi.ptr(self.rows)))
         return self.observations(), self._rewards.copy(), self._dones.astype(bool), [{} for _ in range(self.batch)]
 
     def rollout(self, agent="random", nsteps=1, auto_reset=True):

@@ -18,6 +18,7 @@
 
 extern "C" int bbx_launch_step(const BbxParams* p, int kind, int envs_per_block, hipStream_t stream);
 extern "C" int bbx_launch_clone(const char* src_recs, char* dst_recs, const BbxLayout* L, const int32_t* src, int n, const uint32_t* seeds, hipStream_t stream);
+extern "C" int bbx_launch_gather_lite(const char* recs, uint32_t rec_bytes, int B, void* out, hipStream_t stream);
 extern "C" int bbx_launch_gather_hdr(const char* recs, uint32_t rec_bytes, int B, BbxHdr* out, hipStream_t stream);
 extern "C" int bbx_launch_init(char* recs, uint32_t rec_bytes, int B, const uint32_t* agent_seeds, hipStream_t stream);
 extern "C" int bbx_launch_mark_reset(char* recs, uint32_t rec_bytes, int B, const uint8_t* mask, hipStream_t stream);
@@ -87,6 +88,7 @@ struct bbx_batch {
   std::vector<uint32_t> h_q;          // host mirror of the ideal queue
   std::vector<int32_t> h_tail, h_head;
   std::vector<BbxHdr> h_hdr;
+  std::vector<int32_t> h_lite;        // per environment {status, q_head, budget, nP}: what is polled after every launch
   bool q_dirty = true;
   std::vector<uint8_t> q_dirty_env;
   // device
@@ -271,20 +273,34 @@ int collect_events(bbx_batch* b) {
   return BBX_OK;
 }
 
+int read_lite(bbx_batch* b, hipStream_t stream) {
+  b->h_lite.resize((size_t)b->B * 4);
+  int lrc = bbx_launch_gather_lite(b->d_recs, b->L.rec_bytes, b->B, b->d_hdr, stream);   // d_hdr doubles as the compact buffer
+  if (lrc) return fail(BBX_E_DEVICE, "gather launch failed: %s", hipGetErrorString((hipError_t)lrc));
+  HIPCHK(hipMemcpyAsync(b->h_lite.data(), b->d_hdr, (size_t)b->B * 16, hipMemcpyDeviceToHost, stream));
+  HIPCHK(hipStreamSynchronize(stream));
+  for (int e = 0; e < b->B; e++) b->h_head[e] = b->h_lite[(size_t)e * 4 + 1];
+  return BBX_OK;
+}
+
 // wait for the launch in flight; serve environments that ran out of queued ideals; surface errors
 int finish(bbx_batch* b, hipStream_t stream) {
   for (int round = 0;; round++) {
-    int rc = read_headers(b, stream);
+    int rc = read_lite(b, stream);
     if (rc) return rc;
     rc = collect_events(b);
     if (rc) return rc;
     bool again = false;
     for (int e = 0; e < b->B; e++) {
-      int st = b->h_hdr[e].status;
+      int st = b->h_lite[(size_t)e * 4];
       if (st == BBX_ST_STARVED || st == BBX_ST_SPILL) again = true;
       else if (st == BBX_ST_BAD_ACTION) return fail(BBX_E_ACTION, "environment %d: %s", e, status_name(st));
-      else if (st != BBX_ST_OK) return fail(BBX_E_CAPACITY, "environment %d: %s (|G|=%d |P|=%d terms=%d)", e, status_name(st),
-                                            b->h_hdr[e].nG, b->h_hdr[e].nP, b->h_hdr[e].arena_used);
+      else if (st != BBX_ST_OK) {
+        rc = read_headers(b, stream);
+        if (rc) return rc;
+        return fail(BBX_E_CAPACITY, "environment %d: %s (|G|=%d |P|=%d terms=%d)", e, status_name(st),
+                    b->h_hdr[e].nG, b->h_hdr[e].nP, b->h_hdr[e].arena_used);
+      }
     }
     if (!again) break;
     if (round > 100000) return fail(BBX_E_GENERATOR, "ideal queue starvation did not resolve");
@@ -566,22 +582,29 @@ int bbx_reset(bbx_batch* b, const uint8_t* mask, int32_t* rows) {
   if (rc) return rc;
   rc = finish(b, 0);
   if (rc) return rc;
-  if (rows) for (int e = 0; e < b->B; e++) rows[e] = b->h_hdr[e].nP;
+  if (rows) for (int e = 0; e < b->B; e++) rows[e] = b->h_lite[(size_t)e * 4 + 3];
   return BBX_OK;
 }
 
-int bbx_step(bbx_batch* b, const int32_t* actions, double* rewards, uint8_t* dones, int32_t* rows) {
+static int step_host(bbx_batch* b, const int32_t* actions, double* rewards, uint8_t* dones, int32_t* rows, int auto_reset) {
   if (!b || !actions) return fail(BBX_E_ARG, "null argument");
   HIPCHK(hipSetDevice(b->device));
   HIPCHK(hipMemcpy(b->d_actions, actions, (size_t)b->B * sizeof(int32_t), hipMemcpyHostToDevice));
   BbxParams p; fill_params(b, &p);
-  p.nsteps = 1; p.set_budget = 1; p.agent = BBX_AGENT_EXTERNAL; p.auto_reset = 0; p.actions = b->d_actions;
+  p.nsteps = 1; p.set_budget = 1; p.agent = BBX_AGENT_EXTERNAL; p.auto_reset = auto_reset; p.actions = b->d_actions;
   p.rewards = b->d_rewards; p.dones = b->d_dones; p.rows = b->d_rows;
   int rc = launch(b, p, 0);
   if (rc) return rc;
   rc = finish(b, 0);
   if (rc) return rc;
   return copy_out(b, rewards, dones, rows);
+}
+
+int bbx_step(bbx_batch* b, const int32_t* actions, double* rewards, uint8_t* dones, int32_t* rows) {
+  return step_host(b, actions, rewards, dones, rows, 0);
+}
+int bbx_step_autoreset(bbx_batch* b, const int32_t* actions, double* rewards, uint8_t* dones, int32_t* rows) {
+  return step_host(b, actions, rewards, dones, rows, 1);
 }
 
 int bbx_rollout(bbx_batch* b, int agent, int nsteps, int auto_reset, double* rewards, uint8_t* dones, int32_t* rows) {

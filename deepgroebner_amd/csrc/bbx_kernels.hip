@@ -1057,6 +1057,17 @@ __global__ void bbx_gather_hdr_kernel(const char* recs, uint32_t rec_bytes, int 
   if (env >= B) return;
   out[env] = *(const BbxHdr*)(recs + (size_t)env * rec_bytes);
 }
+// the four header words the host polls after every launch
+__global__ void bbx_gather_lite_kernel(const char* recs, uint32_t rec_bytes, int B, int4* out) {
+  int env = blockIdx.x * blockDim.x + threadIdx.x;
+  if (env >= B) return;
+  const BbxHdr* h = (const BbxHdr*)(recs + (size_t)env * rec_bytes);
+  out[env] = make_int4(h->status, h->q_head, h->budget, h->nP);
+}
+extern "C" int bbx_launch_gather_lite(const char* recs, uint32_t rec_bytes, int B, void* out, hipStream_t stream) {
+  hipLaunchKernelGGL(bbx_gather_lite_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, recs, rec_bytes, B, (int4*)out);
+  return (int)hipGetLastError();
+}
 extern "C" int bbx_launch_gather_hdr(const char* recs, uint32_t rec_bytes, int B, BbxHdr* out, hipStream_t stream) {
   hipLaunchKernelGGL(bbx_gather_hdr_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, recs, rec_bytes, B, out);
   return (int)hipGetLastError();

@@ -100,6 +100,10 @@ int bbx_reset(bbx_batch* b, const uint8_t* mask, int32_t* rows);
  * left untouched (reward 0).  rewards/dones/rows may be NULL. */
 int bbx_step(bbx_batch* b, const int32_t* actions, double* rewards, uint8_t* dones, int32_t* rows);
 
+/* The vectorised-environment convention: an environment whose episode ends with this step is reset inside the same
+ * launch (dones[e] = 1, rows[e] / the next bbx_obs describe the NEW episode), saving the separate bbx_reset call. */
+int bbx_step_autoreset(bbx_batch* b, const int32_t* actions, double* rewards, uint8_t* dones, int32_t* rows);
+
 /* nsteps steps per environment in one go with a device-side agent, optionally re-drawing a new
  * ideal whenever an episode ends (what the reference's scripts/random_episodes.cpp:13-29 loop does
  * on the host).  rewards/dones/rows describe the LAST step. */

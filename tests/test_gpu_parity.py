@@ -386,3 +386,25 @@ def test_strategy_stats_like_make_strat():
             assert got[n].tolist() == [st["zero_reductions"], st["nonzero_reductions"], st["polynomial_additions"]], (strategy, n)
     got = strategy_stats([trim[-1]], "degree")
     assert got[0].tolist() == [69, 41, 1442]                  # cyclic-5, Degree
+
+
+def test_step_autoreset_vec_convention():
+    from deepgroebner_amd import VecLeadMonomialsEnv
+    bo = ffi.load("bo")
+    B, k = 4, 1
+    env = VecLeadMonomialsEnv("3-20-10-weighted", batch=B, k=k)
+    env.seed(np.arange(B) + 400)
+    oracles = []
+    for e in range(B):
+        o = bo.env("3-20-10-weighted"); o.seed(400 + e); o.reset(); oracles.append(o)
+    obs = env.reset()
+    for t in range(160):
+        acts = np.array([(7 * t + 3 + e) % o.nP for e, o in enumerate(oracles)], dtype=np.int32)
+        obs, r, d, _ = env.step(acts, auto_reset=True)
+        for e, o in enumerate(oracles):
+            assert r[e] == o.step(int(acts[e]))
+            fin = o.nP == 0
+            assert bool(d[e]) == fin
+            if fin:
+                o.reset()
+            assert np.array_equal(obs[e], o.obs(k)), (t, e)
