@@ -139,6 +139,14 @@ def main():
     if rank == 0 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args, env, st1, K + Wm, B)
 
+    traffic, traffic_src = None, None
+    if rank == 0:
+        # HBM bytes of one launch from rocprofv3 PMC passes (scripts/profile_bench.sh; separate --pmc runs, FETCH_SIZE
+        # doubled per MI355X_MICROARCH.md): only valid for the workload it was collected on
+        pf = os.path.join(ROOT, "profiles", "r01_pmc_fast_kernel.json")
+        if os.path.exists(pf) and args.dist == DIST and B == BATCH and K == 1024 and chunk == 1024 and not args.ablate_obs:
+            traffic = json.load(open(pf)).get("hbm_traffic_bytes_per_launch")
+            traffic_src = "profiles/r01_pmc_fast_kernel.json"
     if rank == 0:
         value = steps_done / elapsed
         # the dominant (only) kernel: per launch, algorithmic bytes of ONE GPU / its HIP-event duration
@@ -154,7 +162,8 @@ def main():
                        "global_batch": B * world, "steps_per_launch": chunk, "parallelism": "env-sharded x%d, no collectives" % world},
             "additions_per_s": additions / elapsed,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes/launch",
+                         "traffic_source": traffic_src, "alg_bytes_per_launch": per_launch_bytes,
                          "kernel": "bbx_fast_kernel<false,false>", "alg_bytes_per_env_step": alg_bytes / steps_done,
                          "kernel_ms_per_launch": kernel_ms / nlaunch, "launches": nlaunch, "timed_region_ms": region_ms},
             "cpu_baseline": cpu,

@@ -990,6 +990,19 @@ __global__ __launch_bounds__(512) void bbx_wide_kernel(BbxParams p) {
     coop_helper_loop<W>(cc, smem + coop_cmd_bytes() + (size_t)wave * merge_lds_bytes<W>(), wave, nwaves);
   }
 }
+template <int W>
+__global__ __launch_bounds__(512) void bbx_wide_prof_kernel(BbxParams p, unsigned long long* prof) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  CoopCmd* cc = (CoopCmd*)smem;
+  const int wave = uni((int)(threadIdx.x / WAVE)), nwaves = (int)(blockDim.x / WAVE);
+  if (wave == 0) {
+    step_body<W, false, false, true>(p, smem, prof, cc, nwaves);
+    if (lane_id() == 0) cc->cmd = 2;
+    __syncthreads();
+  } else {
+    coop_helper_loop<W>(cc, smem + coop_cmd_bytes() + (size_t)wave * merge_lds_bytes<W>(), wave, nwaves);
+  }
+}
 // diagnostic build with s_memtime stamps (BBX_PROF=1), never used for reported numbers
 template <int W>
 __global__ __launch_bounds__(256) void bbx_step_prof_kernel(BbxParams p, unsigned long long* prof) {
@@ -1164,6 +1177,22 @@ extern "C" int bbx_launch_step(const BbxParams* p, int kind, int envs_per_block,
                                  : (tr ? (const void*)bbx_wide_kernel<4, true> : (const void*)bbx_wide_kernel<4, false>);
     hipError_t err = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl);
     if (err != hipSuccess) return (int)err;
+    if (!tr && getenv("BBX_PROF") && p->L.W == 4) {
+      static unsigned long long* d_prof = nullptr;
+      if (!d_prof) (void)hipMalloc((void**)&d_prof, (size_t)p->B * 10 * sizeof(unsigned long long));
+      (void)hipFuncSetAttribute((const void*)bbx_wide_prof_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl);
+      hipLaunchKernelGGL((bbx_wide_prof_kernel<4>), dim3(p->B), dim3(nw * WAVE), wl, stream, *p, d_prof);
+      (void)hipStreamSynchronize(stream);
+      std::vector<unsigned long long> h((size_t)p->B * 10);
+      (void)hipMemcpy(h.data(), d_prof, h.size() * 8, hipMemcpyDeviceToHost);
+      double s[10] = {0}, tot = 0;
+      for (int e = 0; e < p->B; e++) for (int i = 0; i < 10; i++) s[i] += (double)h[(size_t)e * 10 + i];
+      for (int i = 0; i < 6; i++) tot += s[i];
+      fprintf(stderr, "[bbx prof wide] nsteps=%d kcycles/env:", p->nsteps);
+      for (int i = 0; i < 6; i++) fprintf(stderr, " p%d=%.0f(%.0f%%)", i, s[i] / p->B / 1e3, 100.0 * s[i] / tot);
+      fprintf(stderr, "\n");
+      return 0;
+    }
     if (p->L.W == 2) { if (tr) hipLaunchKernelGGL((bbx_wide_kernel<2, true>), dim3(p->B), dim3(nw * WAVE), wl, stream, *p);
                        else hipLaunchKernelGGL((bbx_wide_kernel<2, false>), dim3(p->B), dim3(nw * WAVE), wl, stream, *p); }
     else { if (tr) hipLaunchKernelGGL((bbx_wide_kernel<4, true>), dim3(p->B), dim3(nw * WAVE), wl, stream, *p);
