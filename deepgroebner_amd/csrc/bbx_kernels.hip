@@ -254,6 +254,34 @@ __device__ __forceinline__ void merge_partition(const PView<W>& A, const PView<W
   if (chk && m_eq(am, bm)) bj++;
 }
 
+// the same partition for up to 8 boundaries at once, 8 lanes per boundary probing 8 split points per step: the search
+// range shrinks 8x per dependent memory round trip instead of 2x (these probes are the serial part of a merge)
+template <int W>
+__device__ __forceinline__ void merge_partition8(const PView<W>& A, const PView<W>& B, int t0, int& bi, int& bj) {
+  const int na = A.n, nb = B.n, total = na + nb;
+  const int lane = lane_id(), g = lane >> 3, s = lane & 7;
+  int d = (t0 + g) * MT; d = d < total ? d : total;
+  int lo = d - nb > 0 ? d - nb : 0, hi = d < na ? d : na;
+  while (__any(lo < hi)) {
+    const bool act = lo < hi;
+    const int span = hi - lo;
+    const int mid = lo + ((s * span) >> 3);                 // 8 probes across [lo, hi)
+    const Mono<W> am = A.mono(act ? mid : 0), bm = B.mono(act ? d - 1 - mid : 0);
+    const bool pred = act && !m_gt(bm, am);                 // A[mid] >= B[d-1-mid]: the boundary lies beyond mid
+    const uint32_t bits = (uint32_t)(ballot64(pred) >> (g * 8)) & 0xffu;
+    const int c = __popc(bits);                             // pred is monotone in mid: the true probes are a prefix
+    if (act) {
+      const int nlo = c > 0 ? lo + (((c - 1) * span) >> 3) + 1 : lo;
+      const int nhi = c < 8 ? lo + ((c * span) >> 3) : hi;
+      lo = nlo; hi = nhi;
+    }
+  }
+  bi = lo; bj = d - lo;
+  const bool chk = bi > 0 && bj < nb;
+  const Mono<W> am = A.mono(chk ? bi - 1 : 0), bm = B.mono(chk ? bj : 0);
+  if (chk && m_eq(am, bm)) bj++;
+}
+
 // one tile: ranges A[i0..i1) and B[j0..j1) are streamed into LDS (coalesced), ranked against each other there, merged
 // with equal monomials combined and zero sums dropped, and written densely to (dm, dc).  Returns the number written
 // (<= MT); nothing beyond `cap` terms is stored.
@@ -369,7 +397,8 @@ struct CoopCmd {
 constexpr int coop_cmd_bytes() { return (int)((sizeof(CoopCmd) + 255) / 256 * 256); }
 
 template <int W>
-__device__ void coop_work(CoopCmd* cc, char* lds_tile, int wave, int nwaves) {
+__device__ void coop_work(CoopCmd* cc, char* lds_tile, int wave, int nwaves, unsigned long long* prof = nullptr) {
+  unsigned long long tq_ = prof ? __builtin_amdgcn_s_memtime() : 0;
   PView<W> A, B;
   A.m = (const Mono<W>*)cc->am; A.c = (const uint16_t*)cc->ac; A.n = cc->na; A.scale = cc->ascale;
   B.m = (const Mono<W>*)cc->bm; B.c = (const uint16_t*)cc->bc; B.n = cc->nb; B.scale = cc->bscale;
@@ -381,7 +410,9 @@ __device__ void coop_work(CoopCmd* cc, char* lds_tile, int wave, int nwaves) {
     const int c = merge_tile<W>(A, B, cc->bi[t], cc->bj[t], cc->bi[t + 1], cc->bj[t + 1], lds_tile, tm + (size_t)t * MT, tc + (size_t)t * MT, MT);
     if (lane_id() == 0) cc->cnt[t] = c;
   }
+  if (prof) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); prof[1] += t_ - tq_; tq_ = t_; }   // my tiles
   __syncthreads();
+  if (prof) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); prof[2] += t_ - tq_; tq_ = t_; }   // waiting for the others
   Mono<W>* om = (Mono<W>*)cc->om; uint16_t* oc = (uint16_t*)cc->oc;
   for (int t = wave; t < ntiles; t += nwaves) {            // phase 2: to the final offsets
     int off = 0;
@@ -392,19 +423,29 @@ __device__ void coop_work(CoopCmd* cc, char* lds_tile, int wave, int nwaves) {
     for (int q = lane_id(); q < c; q += WAVE) { om[off + q] = tm[(size_t)t * MT + q]; oc[off + q] = tc[(size_t)t * MT + q]; }
   }
   __syncthreads();
+  if (prof) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); prof[3] += t_ - tq_; }              // copy + barrier
 }
 
 // leader side; all helper waves are parked at the first barrier of coop_helper_loop
 template <int W>
 __device__ int coop_merge(const PView<W>& A, const PView<W>& B, CoopCmd* cc, char* lds_tile, int nwaves,
-                          Mono<W>* tm, uint16_t* tc, Mono<W>* om, uint16_t* oc, int ocap) {
+                          Mono<W>* tm, uint16_t* tc, Mono<W>* om, uint16_t* oc, int ocap, unsigned long long* prof = nullptr) {
   const int lane = lane_id();
+  unsigned long long tq_ = prof ? __builtin_amdgcn_s_memtime() : 0;
   const int total = A.n + B.n;
   const int ntiles = (total + MT - 1) / MT;
-  for (int t0 = 0; t0 <= ntiles; t0 += 64) {               // every boundary 0..ntiles
-    int bi, bj;
-    merge_partition<W>(A, B, t0, bi, bj);
-    if (t0 + lane <= ntiles) { cc->bi[t0 + lane] = bi; cc->bj[t0 + lane] = bj; }
+  if (ntiles + 1 <= 16) {                                  // few boundaries: 8 lanes each, 8-ary search
+    for (int t0 = 0; t0 <= ntiles; t0 += 8) {
+      int bi, bj;
+      merge_partition8<W>(A, B, t0, bi, bj);
+      if ((lane & 7) == 0 && t0 + (lane >> 3) <= ntiles) { cc->bi[t0 + (lane >> 3)] = bi; cc->bj[t0 + (lane >> 3)] = bj; }
+    }
+  } else {
+    for (int t0 = 0; t0 <= ntiles; t0 += 64) {             // every boundary 0..ntiles, one per lane
+      int bi, bj;
+      merge_partition<W>(A, B, t0, bi, bj);
+      if (t0 + lane <= ntiles) { cc->bi[t0 + lane] = bi; cc->bj[t0 + lane] = bj; }
+    }
   }
   if (lane == 0) {
     cc->cmd = 1; cc->ntiles = ntiles; cc->ocap = ocap; cc->overflow = 0; cc->na = A.n; cc->nb = B.n;
@@ -413,7 +454,8 @@ __device__ int coop_merge(const PView<W>& A, const PView<W>& B, CoopCmd* cc, cha
     cc->am = A.m; cc->ac = A.c; cc->bm = B.m; cc->bc = B.c; cc->om = om; cc->oc = oc; cc->tm = tm; cc->tc = tc;
   }
   __syncthreads();                                         // barrier 1: wake the helpers
-  coop_work<W>(cc, lds_tile, 0, nwaves);                   // barriers 2 and 3 inside
+  if (prof) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); prof[0] += t_ - tq_; }               // partition + post
+  coop_work<W>(cc, lds_tile, 0, nwaves, prof);             // barriers 2 and 3 inside
   int nout = 0;
   for (int s = lane; s < ntiles; s += WAVE) nout += cc->cnt[s];
   for (int o = 32; o > 0; o >>= 1) nout += __shfl_xor(nout, o, WAVE);
@@ -882,7 +924,7 @@ __device__ __forceinline__ void step_body(const BbxParams& p, char* smem, unsign
         GSTAMP(3);                                // 3: reducer fetch / setup
         const bool big = mlds && A.n > 0 && Bv.n > 0 && A.n + Bv.n > 64;
         int nn;
-        if (big && coop && A.n + Bv.n > 2 * MT && A.n + Bv.n <= COOP_MAXT * MT && A.n + Bv.n + MT <= 2 * maxT) nn = coop_merge<W>(A, Bv, coop, mlds, coop_waves, tm, tc, nm, nc, maxT);
+        if (big && coop && A.n + Bv.n > 2 * MT && A.n + Bv.n <= COOP_MAXT * MT && A.n + Bv.n + MT <= 2 * maxT) nn = coop_merge<W>(A, Bv, coop, mlds, coop_waves, tm, tc, nm, nc, maxT, PROF ? &ps[6] : nullptr);
         else nn = big ? wave_merge_tiled<W>(A, Bv, mlds, nm, nc, maxT) : wave_merge<W>(A, Bv, tm, tc, nm, nc, maxT, PROF ? &ps[6] : nullptr);
         if (nn < 0) { status = BBX_ST_POLY_TOO_LONG; overflow = true; break; }
         GSTAMP(4);                                // 4: reduction merges (6/7: their pass 1 / pass 2)
@@ -1189,7 +1231,7 @@ extern "C" int bbx_launch_step(const BbxParams* p, int kind, int envs_per_block,
       for (int e = 0; e < p->B; e++) for (int i = 0; i < 10; i++) s[i] += (double)h[(size_t)e * 10 + i];
       for (int i = 0; i < 6; i++) tot += s[i];
       fprintf(stderr, "[bbx prof wide] nsteps=%d kcycles/env:", p->nsteps);
-      for (int i = 0; i < 6; i++) fprintf(stderr, " p%d=%.0f(%.0f%%)", i, s[i] / p->B / 1e3, 100.0 * s[i] / tot);
+      for (int i = 0; i < 10; i++) fprintf(stderr, " p%d=%.0f(%.0f%%)", i, s[i] / p->B / 1e3, 100.0 * s[i] / tot);
       fprintf(stderr, "\n");
       return 0;
     }
