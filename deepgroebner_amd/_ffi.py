@@ -48,6 +48,7 @@ SIGNATURES = {
     "bbx_create_ideals": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Caps), C.POINTER(_vp)]),
     "bbx_destroy": (None, [_vp]),
     "bbx_copy": (C.c_int, [_vp, C.POINTER(_vp)]),
+    "bbx_clone_envs": (C.c_int, [_vp, C.c_int, _vp, _vp]),
     "bbx_seed": (C.c_int, [_vp, _vp]),
     "bbx_seed_agent": (C.c_int, [_vp, _vp]),
     "bbx_reset": (C.c_int, [_vp, _vp, _vp]),
@@ -70,6 +71,7 @@ SIGNATURES = {
     "bbx_env_status": (C.c_int, [_vp, _vp]),
     "bbx_state_sizes": (C.c_int, [_vp, C.c_int, _i32p, _i32p, _i32p]),
     "bbx_state_get": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp]),
+    "bbx_reduced_basis": (C.c_int, [_vp, C.c_int, _i32p, _i32p, _vp, _vp, _vp]),
     "bbx_trace_enable": (C.c_int, [_vp, C.c_int]),
     "bbx_trace_read": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp]),
     "bbx_gen_create": (C.c_int, [C.c_char_p, C.POINTER(_vp)]),

@@ -150,6 +150,12 @@ class VecLeadMonomialsEnv:
         _ffi.check(_ffi.lib().bbx_copy(self._h, C.byref(h)))
         return VecLeadMonomialsEnv._from_handle(h, self)
 
+    def clone_envs(self, src, dst):
+        """Copy environments src[i] over dst[i] inside the batch (tree-search node pool): state, queued ideals, RNG."""
+        s = np.ascontiguousarray(src, dtype=np.int32); d = np.ascontiguousarray(dst, dtype=np.int32)
+        _ffi.check(_ffi.lib().bbx_clone_envs(self._h, len(s), _ffi.ptr(s), _ffi.ptr(d)))
+        self.rows[d] = self.rows[s]
+
     # ---- introspection
     def stats(self):
         out = np.zeros((self.batch, 8), dtype=np.int64)
@@ -197,6 +203,21 @@ class VecLeadMonomialsEnv:
         ms, n = C.c_double(), C.c_int32()
         _ffi.check(_ffi.lib().bbx_timing(self._h, int(enable), C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def reduced_basis(self, idx=0):
+        """interreduce(minimalize(G)) of environment idx (the reduced Groebner basis once its episode is over), as a list
+        of term lists [(coef, exps8), ...]."""
+        n, nt = C.c_int32(), C.c_int32()
+        _ffi.check(_ffi.lib().bbx_reduced_basis(self._h, int(idx), C.byref(n), C.byref(nt), None, None, None))
+        nterms = np.zeros(max(n.value, 1), dtype=np.int32)
+        coefs = np.zeros(max(nt.value, 1), dtype=np.int32)
+        exps = np.zeros((max(nt.value, 1), NV), dtype=np.int32)
+        _ffi.check(_ffi.lib().bbx_reduced_basis(self._h, int(idx), C.byref(n), C.byref(nt), _ffi.ptr(nterms), _ffi.ptr(coefs), _ffi.ptr(exps)))
+        out, at = [], 0
+        for g in range(n.value):
+            out.append([(int(coefs[at + t]), tuple(int(x) for x in exps[at + t])) for t in range(nterms[g])])
+            at += nterms[g]
+        return out
 
     def trace_enable(self, capacity):
         _ffi.check(_ffi.lib().bbx_trace_enable(self._h, int(capacity)))

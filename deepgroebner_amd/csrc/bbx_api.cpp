@@ -17,7 +17,8 @@
 #include "bbx_ideals.h"
 
 extern "C" int bbx_launch_step(const BbxParams* p, int kind, int envs_per_block, hipStream_t stream);
-extern "C" int bbx_launch_clone(const char* src_recs, char* dst_recs, const BbxLayout* L, const int32_t* src, int n, const uint32_t* seeds, hipStream_t stream);
+extern "C" int bbx_launch_clone(const char* src_recs, char* dst_recs, const BbxLayout* L, const int32_t* src, const int32_t* dst, int n,
+                                const uint32_t* seeds, int keep_counters, hipStream_t stream);
 extern "C" int bbx_launch_gather_lite(const char* recs, uint32_t rec_bytes, int B, void* out, hipStream_t stream);
 extern "C" int bbx_launch_gather_hdr(const char* recs, uint32_t rec_bytes, int B, BbxHdr* out, hipStream_t stream);
 extern "C" int bbx_launch_init(char* recs, uint32_t rec_bytes, int B, const uint32_t* agent_seeds, hipStream_t stream);
@@ -547,6 +548,44 @@ int bbx_copy(const bbx_batch* s, bbx_batch** out) {
   return BBX_OK;
 }
 
+// In-batch clones for tree search (mcts.py:89,96,147 call env.copy() per expanded node): environment src[i] is copied
+// over environment dst[i] — device record, pending queued ideals and the host generator's RNG state — without any
+// allocation.  src and dst must not overlap.
+int bbx_clone_envs(bbx_batch* b, int n, const int32_t* src, const int32_t* dst) {
+  if (!b || n < 0 || (n && (!src || !dst))) return fail(BBX_E_ARG, "bad arguments");
+  HIPCHK(hipSetDevice(b->device));
+  if (b->in_flight) { int rc = finish(b, b->last_stream); if (rc) return rc; }
+  for (int i = 0; i < n; i++) {
+    if (src[i] < 0 || src[i] >= b->B || dst[i] < 0 || dst[i] >= b->B) return fail(BBX_E_ARG, "environment index out of range");
+    for (int j = 0; j < n; j++) if (src[i] == dst[j]) return fail(BBX_E_ARG, "source and destination sets overlap");
+  }
+  if (n == 0) return BBX_OK;
+  int rc = read_lite(b, 0);                       // current queue heads
+  if (rc) return rc;
+  int32_t *d_s = nullptr, *d_d = nullptr;
+  HIPCHK(hipMalloc((void**)&d_s, (size_t)n * 4)); HIPCHK(hipMalloc((void**)&d_d, (size_t)n * 4));
+  HIPCHK(hipMemcpy(d_s, src, (size_t)n * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(d_d, dst, (size_t)n * 4, hipMemcpyHostToDevice));
+  int lrc = bbx_launch_clone(b->d_recs, b->d_recs, &b->L, d_s, d_d, n, nullptr, 1, 0);
+  HIPCHK(hipDeviceSynchronize());
+  (void)hipFree(d_s); (void)hipFree(d_d);
+  if (lrc) return fail(BBX_E_DEVICE, "clone launch failed: %s", hipGetErrorString((hipError_t)lrc));
+  if (!b->fixed) {
+    const size_t stride = (size_t)b->nslots * b->slot_words;
+    if (b->q_dirty_env.size() != (size_t)b->B) b->q_dirty_env.assign(b->B, b->q_dirty ? 1 : 0);
+    for (int i = 0; i < n; i++) {
+      const int s = src[i], d = dst[i];
+      b->gens[d] = b->gens[s]->clone();
+      b->h_tail[d] = b->h_tail[s]; b->h_head[d] = b->h_head[s];
+      memcpy(b->h_q.data() + (size_t)d * stride, b->h_q.data() + (size_t)s * stride, stride * sizeof(uint32_t));
+      b->q_dirty_env[d] = 1;
+    }
+    b->q_dirty = true;
+    return upload_queue(b);
+  }
+  return BBX_OK;
+}
+
 int bbx_seed(bbx_batch* b, const int64_t* seeds) {
   if (!b || !seeds) return fail(BBX_E_ARG, "null argument");
   if (b->fixed) return BBX_OK;                 // FixedIdealGenerator::seed is a no-op (ideals.h:94)
@@ -780,7 +819,7 @@ int value_rollouts(bbx_batch* b, const std::vector<int32_t>& src, int agent, con
   }
   HIPCHK(hipMemcpy(b->d_vsrc, src.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice));
   if (seeds) HIPCHK(hipMemcpy(b->d_vseeds, seeds->data(), (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice));
-  int lrc = bbx_launch_clone(b->d_recs, b->d_vrecs, &b->L, b->d_vsrc, n, seeds ? b->d_vseeds : nullptr, 0);
+  int lrc = bbx_launch_clone(b->d_recs, b->d_vrecs, &b->L, b->d_vsrc, nullptr, n, seeds ? b->d_vseeds : nullptr, 0, 0);
   if (lrc) return fail(BBX_E_DEVICE, "clone launch failed: %s", hipGetErrorString((hipError_t)lrc));
   std::vector<BbxHdr> vh(n);
   lrc = bbx_launch_gather_hdr(b->d_vrecs, b->L.rec_bytes, n, b->d_vhdr, 0);
@@ -953,6 +992,47 @@ int bbx_state_get(bbx_batch* b, int idx, int32_t* nterms, int32_t* coefs, int32_
     if (order) order[g] = sidx[g];
   }
   if (pairs) for (int r = 0; r < nP; r++) { pairs[2 * r] = (int)(pr[r] & 0xffffu); pairs[2 * r + 1] = (int)(pr[r] >> 16); }
+  return BBX_OK;
+}
+
+// interreduce(minimalize(G)) of environment idx's current basis (what buchberger() returns, buchberger.cpp:265).
+// Two-call protocol like bbx_state_get: sizes first (nterms == NULL), then the data.
+int bbx_reduced_basis(bbx_batch* b, int idx, int32_t* basis_size, int32_t* nterms_total, int32_t* nterms, int32_t* coefs, int32_t* exps) {
+  if (!b || idx < 0 || idx >= b->B) return fail(BBX_E_ARG, "bad environment index");
+  int32_t nG = 0, nP = 0, nT = 0;
+  int rc = bbx_state_sizes(b, idx, &nG, &nP, &nT);
+  if (rc) return rc;
+  std::vector<int32_t> nt(std::max(nG, 1)), cf(std::max(nT, 1)), ex((size_t)std::max(nT, 1) * bbx::kN);
+  rc = bbx_state_get(b, idx, nt.data(), cf.data(), ex.data(), nullptr, nullptr);
+  if (rc) return rc;
+  std::vector<bbx::HPoly> G;
+  size_t at = 0;
+  for (int g = 0; g < nG; g++) {
+    bbx::HPoly f;
+    for (int t = 0; t < nt[g]; t++, at++) {
+      bbx::HTerm h; h.c = cf[at]; h.deg = 0;
+      for (int v = 0; v < bbx::kN; v++) { h.e[v] = ex[at * bbx::kN + v]; h.deg += h.e[v]; }
+      f.t.push_back(h);
+    }
+    f.sugar = f.t.empty() ? 0 : f.t[0].deg;
+    G.push_back(f);
+  }
+  std::vector<bbx::HPoly> R = bbx::interreduce(bbx::minimalize(G));
+  int tot = 0;
+  for (auto& f : R) tot += (int)f.t.size();
+  if (basis_size) *basis_size = (int)R.size();
+  if (nterms_total) *nterms_total = tot;
+  if (nterms) {
+    at = 0;
+    for (size_t g = 0; g < R.size(); g++) {
+      nterms[g] = (int)R[g].t.size();
+      for (auto& t : R[g].t) {
+        if (coefs) coefs[at] = t.c;
+        if (exps) for (int v = 0; v < bbx::kN; v++) exps[at * bbx::kN + v] = t.e[v];
+        at++;
+      }
+    }
+  }
   return BBX_OK;
 }
 

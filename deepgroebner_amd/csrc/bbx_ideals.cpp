@@ -59,6 +59,68 @@ HPoly poly_add(const HPoly& a, const HPoly& b) {
   return g;
 }
 
+// ---------------------------------------------------------------- minimalize / interreduce, buchberger.cpp:102-122
+static bool divides(const HTerm& a, const HTerm& b) {   // a | b
+  for (int i = 0; i < kN; i++) if (a.e[i] > b.e[i]) return false;
+  return true;
+}
+static HPoly scaled_shift(const HPoly& f, int c, const HTerm& m) {     // Term{c, m} * f  (polynomials.cpp:196-202)
+  HPoly g; g.sugar = m.deg + f.sugar;
+  for (auto& t : f.t) {
+    HTerm u; u.c = coef_norm((long long)c * t.c); u.deg = t.deg + m.deg;
+    for (int i = 0; i < kN; i++) u.e[i] = t.e[i] + m.e[i];
+    g.t.push_back(u);
+  }
+  return g;
+}
+static HPoly negated(const HPoly& f) { HPoly g = f; for (auto& t : g.t) t.c = coef_norm((long long)(kP - 1) * t.c); return g; }
+
+HPoly poly_reduce(const HPoly& g, const std::vector<HPoly>& F) {
+  HPoly r, h = g;
+  while (!h.t.empty()) {
+    bool found = false;
+    for (const HPoly& f : F) {
+      if (divides(f.t[0], h.t[0])) {
+        HTerm q; q.deg = h.t[0].deg - f.t[0].deg;
+        for (int i = 0; i < kN; i++) q.e[i] = h.t[0].e[i] - f.t[0].e[i];
+        const int c = coef_norm((long long)h.t[0].c * coef_inv(f.t[0].c));
+        h = poly_add(h, negated(scaled_shift(f, c, q)));
+        found = true;
+        break;
+      }
+    }
+    if (!found) {
+      HPoly lt; lt.t = {h.t[0]}; lt.sugar = h.t[0].deg;
+      r = poly_add(r, lt);
+      h = poly_add(h, negated(lt));
+    }
+  }
+  return poly_add(r, h);
+}
+
+std::vector<HPoly> minimalize(const std::vector<HPoly>& G) {
+  std::vector<HPoly> s = G, out;
+  std::sort(s.begin(), s.end(), [](const HPoly& f, const HPoly& g) { return mono_gt(g.t[0], f.t[0]); });   // std::sort, like the reference
+  for (const HPoly& g : s) {
+    bool ok = true;
+    for (const HPoly& f : out) if (divides(f.t[0], g.t[0])) { ok = false; break; }
+    if (ok) out.push_back(g);
+  }
+  return out;
+}
+
+std::vector<HPoly> interreduce(const std::vector<HPoly>& G) {
+  std::vector<HPoly> out;
+  for (const HPoly& g : G) {
+    HPoly lt; lt.t = {g.t[0]}; lt.sugar = g.t[0].deg;
+    HPoly tail = poly_add(g, negated(lt));
+    HPoly s = poly_add(poly_reduce(tail, G), lt);
+    HTerm one; one.c = 1; one.deg = 0; one.e = {};
+    out.push_back(scaled_shift(s, coef_inv(g.t[0].c), one));
+  }
+  return out;
+}
+
 // ---------------------------------------------------------------- libstdc++ 11 <random>, restated
 void MinStd0::seed(long long s) {   // linear_congruential_engine<uint_fast32_t,16807,0,2147483647>::seed
   x = (uint64_t)s % 2147483647ull;

@@ -25,6 +25,11 @@ bool mono_gt(const HTerm& a, const HTerm& b);   // grevlex on the exponent vecto
 HPoly poly_from_terms(std::vector<HTerm> ts);   // Polynomial ctor: sort descending, sugar = deg LT
 HPoly poly_add(const HPoly& a, const HPoly& b); // polynomials.cpp:148-177
 
+// host-side Groebner-basis post-processing (buchberger.cpp:102-122), used by bbx_reduced_basis
+HPoly poly_reduce(const HPoly& g, const std::vector<HPoly>& F);          // buchberger.cpp:24-49 (remainder only)
+std::vector<HPoly> minimalize(const std::vector<HPoly>& G);              // buchberger.cpp:102-112
+std::vector<HPoly> interreduce(const std::vector<HPoly>& G);             // buchberger.cpp:115-122
+
 class MinStd0 {               // std::default_random_engine
  public:
   void seed(long long s);

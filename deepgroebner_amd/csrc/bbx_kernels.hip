@@ -1085,24 +1085,26 @@ extern "C" int bbx_launch_mark_reset(char* recs, uint32_t rec_bytes, int B, cons
 // value(): clone environment src[k] of one record array into slot k of another (live prefixes only), optionally
 // re-seeding the built-in random agent of the clone
 template <int W>
-__global__ void bbx_clone_kernel(const char* src_recs, char* dst_recs, BbxLayout L, const int32_t* src, int n, const uint32_t* seeds) {
+__global__ void bbx_clone_kernel(const char* src_recs, char* dst_recs, BbxLayout L, const int32_t* src, const int32_t* dst, int n,
+                                 const uint32_t* seeds, int keep_counters) {
   const int k = blockIdx.x * (blockDim.x / WAVE) + (int)(threadIdx.x / WAVE);
   if (k >= n) return;
   char* s = const_cast<char*>(src_recs) + (size_t)src[k] * L.rec_bytes;
-  char* d = dst_recs + (size_t)k * L.rec_bytes;
+  char* d = dst_recs + (size_t)(dst ? dst[k] : k) * L.rec_bytes;
   BbxHdr h = *(const BbxHdr*)s;
   if (L.kind == 1) bstage_copy<W>(benv_view<W>(d, L), benv_view<W>(s, L), h.nG, h.nP);
   else stage_copy<W>(env_view<W>(d, L), env_view<W>(s, L), h.nG, h.nP, h.arena_used);
   if (lane_id() == 0) {
-    h.need_reset = 0; h.budget = 0; h.rollout_pos = 0; h.t = 0;
+    if (!keep_counters) { h.need_reset = 0; h.budget = 0; h.rollout_pos = 0; h.t = 0; }
     if (seeds) h.agent_seed = seeds[k];
     *(BbxHdr*)d = h;
   }
 }
-extern "C" int bbx_launch_clone(const char* src_recs, char* dst_recs, const BbxLayout* L, const int32_t* src, int n, const uint32_t* seeds, hipStream_t stream) {
+extern "C" int bbx_launch_clone(const char* src_recs, char* dst_recs, const BbxLayout* L, const int32_t* src, const int32_t* dst, int n,
+                                const uint32_t* seeds, int keep_counters, hipStream_t stream) {
   const int blocks = (n + 3) / 4;
-  if (L->W == 2) hipLaunchKernelGGL((bbx_clone_kernel<2>), dim3(blocks), dim3(256), 0, stream, src_recs, dst_recs, *L, src, n, seeds);
-  else hipLaunchKernelGGL((bbx_clone_kernel<4>), dim3(blocks), dim3(256), 0, stream, src_recs, dst_recs, *L, src, n, seeds);
+  if (L->W == 2) hipLaunchKernelGGL((bbx_clone_kernel<2>), dim3(blocks), dim3(256), 0, stream, src_recs, dst_recs, *L, src, dst, n, seeds, keep_counters);
+  else hipLaunchKernelGGL((bbx_clone_kernel<4>), dim3(blocks), dim3(256), 0, stream, src_recs, dst_recs, *L, src, dst, n, seeds, keep_counters);
   return (int)hipGetLastError();
 }
 

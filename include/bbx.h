@@ -86,6 +86,11 @@ void bbx_destroy(bbx_batch* b);
  * generators' RNG state. */
 int bbx_copy(const bbx_batch* b, bbx_batch** out);
 
+/* In-batch clones for tree search (the reference's mcts.py:89,96,147 / az.py:82 copy the env per expanded node):
+ * environment src[i] overwrites environment dst[i] — device record, queued ideals and generator RNG state — with no
+ * allocation, so a batch can serve as a pool of search nodes.  src and dst must not overlap. */
+int bbx_clone_envs(bbx_batch* b, int n, const int32_t* src, const int32_t* dst);
+
 /* ---- LeadMonomialsEnv::seed (buchberger.h:243, wrapped.pyx:28-30): one seed per environment ---- */
 int bbx_seed(bbx_batch* b, const int64_t* seeds);
 /* seeds of the built-in BBX_RANDOM_HASH agent: action = bbx_agent_action(seed, t, rows), t = steps taken so far */
@@ -158,6 +163,10 @@ int bbx_state_sizes(bbx_batch* b, int idx, int32_t* basis_size, int32_t* npairs,
 /* G[0..basis_size): nterms[i], then concatenated coefs and exps (8 ints per term); pairs as (i,j);
  * order[r] = index into G of the r-th reducer */
 int bbx_state_get(bbx_batch* b, int idx, int32_t* nterms, int32_t* coefs, int32_t* exps, int32_t* pairs, int32_t* order);
+/* interreduce(minimalize(G)) of environment idx's basis — the reduced Groebner basis buchberger() returns
+ * (buchberger.cpp:102-122, 265) once the environment's pair set is empty; computed on the host.  Call with
+ * nterms == NULL for the sizes, then with buffers (nterms[basis_size], coefs/exps[nterms_total(*8)]). */
+int bbx_reduced_basis(bbx_batch* b, int idx, int32_t* basis_size, int32_t* nterms_total, int32_t* nterms, int32_t* coefs, int32_t* exps);
 int bbx_trace_enable(bbx_batch* b, int capacity_steps);  /* 0 disables */
 int bbx_trace_read(bbx_batch* b, int env, int first, int count, bbx_trace_rec* out);
 

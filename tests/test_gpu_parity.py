@@ -408,3 +408,48 @@ def test_step_autoreset_vec_convention():
             if fin:
                 o.reset()
             assert np.array_equal(obs[e], o.obs(k)), (t, e)
+
+
+def test_reduced_groebner_basis_known_answers():
+    """buchberger() = interreduce(minimalize(G)) after the rollout (buchberger.cpp:265): cyclic-4/5/6 with Degree
+    selection against the reduced bases recorded from the reference (sizes 7/20/45) and a random ideal
+    against the oracle."""
+    from deepgroebner_amd import VecLeadMonomialsEnv
+    from oracle.trace import flat_ideal
+    bo = ffi.load("bo")
+    want = meta()["buchberger"]
+    for n in (4, 5, 6):
+        env = VecLeadMonomialsEnv("cyclic-%d" % n, batch=1, k=1)
+        env.reset()
+        env.rollout("degree", 1 << 30, auto_reset=False)
+        st = env.stats()[0]
+        w = want["cyclic-%d|degree" % n]
+        assert [st[3], st[0] - st[3], st[1]] == [w["zero_reductions"], w["nonzero_reductions"], w["polynomial_additions"]]
+        G = env.reduced_basis(0)
+        assert len(G) == w["basis_size"] and int(fnv64(flat_ideal(G))) == w["basis_hash"]
+    g = bo.generator("3-6-5-0.5-uniform"); g.seed(21); F = g.next()
+    env = VecLeadMonomialsEnv([[[(c, e[:3]) for c, e in f] for f in F]], batch=1, k=1)
+    env.reset(); env.rollout("normal", 1 << 30, auto_reset=False)
+    Gref, _ = bo.buchberger(F, selection="normal")
+    assert env.reduced_basis(0) == Gref
+
+
+def test_in_batch_clones_for_tree_search():
+    """env.copy() per search node (mcts.py:89,96,147) as an in-batch clone: the clone continues exactly like its
+    source, including the ideals it will draw after a reset, and then diverges under different actions."""
+    from deepgroebner_amd import VecLeadMonomialsEnv
+    env = VecLeadMonomialsEnv("3-20-10-weighted", batch=4, k=2)
+    env.seed([11, 12, 13, 14]); env.reset()
+    env.step([0, 1, 2, 3])
+    env.clone_envs([0, 1], [2, 3])
+    o = env.observations()
+    assert np.array_equal(o[0], o[2]) and np.array_equal(o[1], o[3])
+    for t in range(80):                                   # long enough to cross resets: the generator state travelled too
+        acts = np.array([t % r if r else 0 for r in env.rows], dtype=np.int32)
+        acts[2], acts[3] = acts[0], acts[1]
+        obs, r, d, _ = env.step(acts, auto_reset=True)
+        assert r[0] == r[2] and r[1] == r[3] and d[0] == d[2] and d[1] == d[3]
+        assert np.array_equal(obs[0], obs[2]) and np.array_equal(obs[1], obs[3])
+    env.step([0, 0, 1 % max(1, env.rows[2]), 0], auto_reset=True)
+    with pytest.raises(Exception):
+        env.clone_envs([0], [0])
