@@ -97,12 +97,14 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
   if (p.set_budget) { budget = p.nsteps; rollout_pos = 0; done_last = 0; }
   if (p.pass == 1 && !(status == BBX_ST_OK && (need_reset || (budget > 0 && nP > 0)))) return;
 
-  // HBM record arrays (binomial layout: every array 16-B aligned, capacities hbmG / maxP)
-  const uint32_t HG = p.hbmG;
-  M2* g_lm = (M2*)(grec + 128);            M2* g_tm = (M2*)(grec + 128 + 8 * HG);
-  M2* g_slm = (M2*)(grec + 128 + 16 * HG); M2* g_stm = (M2*)(grec + 128 + 24 * HG);
-  uint2* g_gi = (uint2*)(grec + 128 + 40 * HG); uint2* g_si = (uint2*)(grec + 128 + 48 * HG);
-  uint32_t* g_pr = (uint32_t*)(grec + 128 + 56 * HG);
+  // HBM record arrays (binomial layout: every array 16-B aligned, capacities hbmG / maxP); the addresses are only
+  // formed where the record is read or written (launch start / end), never kept live across the step loop
+#define F_HBM_PTRS \
+  const uint32_t HG = p.hbmG; char* grec_ = p.recs + (size_t)env * p.rec_bytes; \
+  M2* g_lm = (M2*)(grec_ + 128);            M2* g_tm = (M2*)(grec_ + 128 + 8 * HG); \
+  M2* g_slm = (M2*)(grec_ + 128 + 16 * HG); M2* g_stm = (M2*)(grec_ + 128 + 24 * HG); \
+  uint2* g_gi = (uint2*)(grec_ + 128 + 40 * HG); uint2* g_si = (uint2*)(grec_ + 128 + 48 * HG); \
+  uint32_t* g_pr = (uint32_t*)(grec_ + 128 + 56 * HG);
   // LDS working arrays at compile-time offsets
   char* lbase = smem + wave_in_block * FLDS_BYTES;
   M2* lm = (M2*)(lbase + FOFF_LM); M2* tm = (M2*)(lbase + FOFF_TM);
@@ -116,6 +118,7 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
   if (status == BBX_ST_OK) {
     if (nG > limG || nP > limP) status = BBX_ST_SPILL;
     else {
+      F_HBM_PTRS
       if (lane < nG) { S.slmA = g_slm[lane]; S.stmA = g_stm[lane]; S.sinA = g_si[lane]; lm[lane] = g_lm[lane]; tm[lane] = g_tm[lane]; gi[lane] = g_gi[lane]; }
       if (lane + 64 < nG) { S.slmB = g_slm[lane + 64]; S.stmB = g_stm[lane + 64]; S.sinB = g_si[lane + 64];
                             lm[lane + 64] = g_lm[lane + 64]; tm[lane + 64] = g_tm[lane + 64]; gi[lane + 64] = g_gi[lane + 64]; }
@@ -129,7 +132,7 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
   uint32_t hv = bbx_agent_hash32(agent_seed, (uint32_t)((t_agent & ~63) + lane));
   int steps_done = 0, adds = 0, episodes = 0, zero_red = 0;
   long long bytes_total = 0;
-  double last_reward = 0.0;
+  int last_nred = -1;                                  // reward of the last step, kept as its integer reduction count
   const bool tracing = TRACE && p.trace != nullptr;
   const int n = p.nvars, kk = p.k;
   const int per_row = 2 * kk;
@@ -430,8 +433,7 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
     }
     FSTAMP(4);                                             // 4: add_poly (pair update, insert)
     if (ACCT) { bytes += nP * obs_row_bytes; bytes_total += bytes; }
-    const double reward = p.rewards_mode == BBX_REW_ADDITIONS ? (-1.0 - (double)nred) : -1.0;
-    last_reward = reward;
+    last_nred = nred;
     adds += 1 + nred; t_agent++; steps_done++;
     if ((t_agent & 63) == 0) hv = bbx_agent_hash32(agent_seed, (uint32_t)(t_agent + lane));
     const bool done = nP == 0;
@@ -459,7 +461,8 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
       }
       if (lane == 0) {
         BbxTraceRec& tr = p.trace[(size_t)env * p.trace_stride + rollout_pos];
-        tr.action = action; tr.nP = nP; tr.nG = nG; tr.done = done ? 1 : 0; tr.reward = reward;
+        tr.action = action; tr.nP = nP; tr.nG = nG; tr.done = done ? 1 : 0;
+        tr.reward = p.rewards_mode == BBX_REW_ADDITIONS ? (-1.0 - (double)nred) : -1.0;
         tr.obs_hash = oh; tr.pairs_hash = ph; tr.newpoly_hash = nh;
       }
     }
@@ -474,19 +477,21 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
   if (p.obs && status == BBX_ST_OK) write_obs(true, false);
   if (staged_in) {                                                   // write the live prefixes back to the HBM record
     wave_sync();
+    F_HBM_PTRS
     if (lane < nG) { g_slm[lane] = S.slmA; g_stm[lane] = S.stmA; g_si[lane] = S.sinA; g_lm[lane] = lm[lane]; g_tm[lane] = tm[lane]; g_gi[lane] = gi[lane]; }
     if (lane + 64 < nG) { g_slm[lane + 64] = S.slmB; g_stm[lane + 64] = S.stmB; g_si[lane + 64] = S.sinB;
                           g_lm[lane + 64] = lm[lane + 64]; g_tm[lane + 64] = tm[lane + 64]; g_gi[lane + 64] = gi[lane + 64]; }
     for (int i = lane; i < nP; i += WAVE) g_pr[i] = pairs[i];
   }
   if (lane == 0) {
-    BbxHdr* h = ghdr;
+    BbxHdr* h = (BbxHdr*)(p.recs + (size_t)env * p.rec_bytes);
     h->nG = nG; h->nP = nP; h->arena_used = 0; h->status = status; h->need_reset = need_reset;
     h->q_head = q_head; h->t = t_agent; h->total_steps += steps_done; h->total_additions += adds;
     h->episodes += episodes; h->zero_reductions += zero_red; h->steps_done = steps_done;
     h->budget = budget; h->rollout_pos = rollout_pos; h->done_last = done_last; h->alg_bytes += bytes_total;
     if (!handoff) {
-      if (p.rewards && (steps_done > 0 || p.pass == 0)) p.rewards[env] = last_reward;
+      if (p.rewards && (steps_done > 0 || p.pass == 0))
+        p.rewards[env] = last_nred < 0 ? 0.0 : (p.rewards_mode == BBX_REW_ADDITIONS ? (-1.0 - (double)last_nred) : -1.0);
       if (p.dones) p.dones[env] = (uint8_t)((done_last || (nP == 0 && !need_reset)) ? 1 : 0);
       if (p.rows) p.rows[env] = nP;
     }
