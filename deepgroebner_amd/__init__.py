@@ -2,4 +2,5 @@
 LeadMonomialsEnv / CLeadMonomialsEnv and its ideal generators)."""
 from .buchberger import CLeadMonomialsEnv, LeadMonomialsEnv, VecLeadMonomialsEnv, strategy_stats  # noqa: F401
 from .ideals import (FixedIdealGenerator, RandomBinomialIdealGenerator, RandomIdealGenerator,  # noqa: F401
-                     basis, cyclic, degree_distribution, parse_ideal_dist)
+                     basis, cyclic, degree_distribution, format_ideal, parse_ideal_dist, parse_ideal_string,
+                     parse_polynomial)

@@ -13,7 +13,8 @@ LIB_PATH = os.path.join(HERE, "libbbx.so")
 
 BBX_GEBAUERMOELLER, BBX_LCM, BBX_NONE = 0, 1, 2
 BBX_ADDITIONS, BBX_REDUCTIONS = 0, 1
-AGENTS = {"external": 0, "random": 1, "degree": 2, "first": 3, "normal": 4, "sugar": 5}
+AGENTS = {"external": 0, "random": 1, "degree": 2, "first": 3, "normal": 4, "sugar": 5,
+          "last": 6, "codegree": 7, "strange": 8, "spice": 9, "random_std": 10}
 ELIMINATION = {"gebauermoeller": 0, "lcm": 1, "none": 2}
 REWARDS = {"additions": 0, "reductions": 1}
 
@@ -51,6 +52,7 @@ SIGNATURES = {
     "bbx_clone_envs": (C.c_int, [_vp, C.c_int, _vp, _vp]),
     "bbx_seed": (C.c_int, [_vp, _vp]),
     "bbx_seed_agent": (C.c_int, [_vp, _vp]),
+    "bbx_seed_strategy": (C.c_int, [_vp, _vp]),
     "bbx_reset": (C.c_int, [_vp, _vp, _vp]),
     "bbx_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "bbx_step_autoreset": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
@@ -80,6 +82,8 @@ SIGNATURES = {
     "bbx_gen_nvars": (C.c_int, [_vp]),
     "bbx_gen_next": (C.c_int, [_vp, _i32p, _i32p]),
     "bbx_gen_get": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "bbx_parse_ideal": (C.c_int, [C.c_char_p, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp]),
+    "bbx_format_ideal": (C.c_int, [C.c_int, _vp, _vp, _vp, C.c_char_p, C.c_int]),
     "bbx_agent_hash": (C.c_uint32, [C.c_uint32, C.c_uint32]),
     "bbx_agent_action": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_uint32]),
     "bbx_last_error": (C.c_char_p, []),

@@ -51,7 +51,8 @@ class VecLeadMonomialsEnv:
                     for _, e in f:
                         exps[r, :len(e)] = e
                         r += 1
-            nv = max(len(e) for F in ideals for f in F for _, e in f)
+            used = np.flatnonzero(exps.any(axis=0))                # trailing all-zero slots are not variables
+            nv = int(used[-1]) + 1 if len(used) else 1
             _ffi.check(L.bbx_create_ideals(len(ideals), _ffi.ptr(npolys), _ffi.ptr(nterms), _ffi.ptr(coefs), _ffi.ptr(exps), nv, el, rw,
                                            int(sort_input), int(sort_reducers), self.k, self.batch, int(device),
                                            _caps(caps), C.byref(self._h)))
@@ -106,6 +107,11 @@ class VecLeadMonomialsEnv:
     def seed_agent(self, seeds):
         s = np.ascontiguousarray(np.broadcast_to(np.asarray(seeds, dtype=np.uint32), (self.batch,)))
         _ffi.check(_ffi.lib().bbx_seed_agent(self._h, _ffi.ptr(s)))
+
+    def seed_strategy(self, seeds):
+        """Seed the "random_std" agent: the reference's seeded Random selection (buchberger.cpp:200-203, 244)."""
+        s = np.ascontiguousarray(np.broadcast_to(np.asarray(seeds, dtype=np.int64), (self.batch,)))
+        _ffi.check(_ffi.lib().bbx_seed_strategy(self._h, _ffi.ptr(s)))
 
     def reset(self, mask=None):
         m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
@@ -272,12 +278,19 @@ class LeadMonomialsEnv(CLeadMonomialsEnv):
         return self._vec.value(0, "degree", gamma)
 
 
-def strategy_stats(ideals, strategy="degree", elimination="gebauermoeller", sort_reducers=True, device=0, caps=None):
+def strategy_stats(ideals, strategy="degree", elimination="gebauermoeller", sort_reducers=True, device=0, caps=None,
+                   seed=None):
     """Full Buchberger runs of one selection strategy over a list of ideals, all at once on the GPU: the columns
     scripts/make_strat.cpp:44-70 of the reference writes per ideal.  Returns int64 [len(ideals), 3] =
-    (ZeroReductions, NonzeroReductions, PolynomialAdditions)."""
+    (ZeroReductions, NonzeroReductions, PolynomialAdditions).  strategy is one of first / degree / normal / sugar /
+    random / last / codegree / strange / spice; "random" with a seed is the reference's seeded Random selection (the
+    same seed for every ideal, make_strat.cpp:66), without one it is the counter-hash agent (the reference then seeds
+    from std::random_device, so there is nothing to reproduce)."""
     env = VecLeadMonomialsEnv(list(ideals), batch=len(ideals), elimination=elimination, sort_reducers=sort_reducers,
                               k=1, device=device, caps=caps)
+    if strategy == "random" and seed is not None:
+        strategy = "random_std"
+        env.seed_strategy(int(seed))
     env.reset()
     if int(env.rows.max()) > 0:
         env.rollout(strategy, 1 << 30, auto_reset=False)

@@ -608,6 +608,21 @@ int bbx_seed_agent(bbx_batch* b, const uint32_t* seeds) {
   return BBX_OK;
 }
 
+int bbx_seed_strategy(bbx_batch* b, const int64_t* seeds) {
+  if (!b || !seeds) return fail(BBX_E_ARG, "null argument");
+  HIPCHK(hipSetDevice(b->device));
+  if (b->in_flight) { int rc = finish(b, b->last_stream); if (rc) return rc; }
+  // linear_congruential_engine<uint_fast32_t, 16807, 0, 2^31-1>::seed(s): the int seed converts to the 64-bit
+  // unsigned result_type first; x = s mod m, and 0 becomes 1 (libstdc++-11 bits/random.tcc)
+  std::vector<uint32_t> st(b->B);
+  for (int e = 0; e < b->B; e++) {
+    uint32_t x = (uint32_t)((uint64_t)seeds[e] % 2147483647ull);
+    st[e] = x ? x : 1u;
+  }
+  HIPCHK(hipMemcpy2D(b->d_recs + offsetof(BbxHdr, std_rng), b->L.rec_bytes, st.data(), sizeof(uint32_t), sizeof(uint32_t), b->B, hipMemcpyHostToDevice));
+  return BBX_OK;
+}
+
 int bbx_reset(bbx_batch* b, const uint8_t* mask, int32_t* rows) {
   if (!b) return fail(BBX_E_ARG, "null argument");
   HIPCHK(hipSetDevice(b->device));
@@ -647,7 +662,7 @@ int bbx_step_autoreset(bbx_batch* b, const int32_t* actions, double* rewards, ui
 }
 
 int bbx_rollout(bbx_batch* b, int agent, int nsteps, int auto_reset, double* rewards, uint8_t* dones, int32_t* rows) {
-  if (!b || nsteps < 0 || agent < BBX_RANDOM_HASH || agent > BBX_SUGAR) return fail(BBX_E_ARG, "bad rollout arguments");
+  if (!b || nsteps < 0 || agent < BBX_RANDOM_HASH || agent > BBX_RANDOM_STD) return fail(BBX_E_ARG, "bad rollout arguments");
   HIPCHK(hipSetDevice(b->device));
   if (b->d_trace && nsteps > b->trace_cap) return fail(BBX_E_ARG, "rollout of %d steps exceeds the trace capacity %d", nsteps, b->trace_cap);
   BbxParams p; fill_params(b, &p);
@@ -672,7 +687,7 @@ int bbx_step_device(bbx_batch* b, const int32_t* d_actions, double* d_rewards, u
 
 int bbx_rollout_device(bbx_batch* b, int agent, int nsteps, int auto_reset, double* d_rewards, uint8_t* d_dones,
                        int32_t* d_rows, int32_t* d_obs, int obs_rows, int obs_fill, int obs_every_step, void* stream) {
-  if (!b || nsteps < 0 || agent < BBX_RANDOM_HASH || agent > BBX_SUGAR) return fail(BBX_E_ARG, "bad rollout arguments");
+  if (!b || nsteps < 0 || agent < BBX_RANDOM_HASH || agent > BBX_RANDOM_STD) return fail(BBX_E_ARG, "bad rollout arguments");
   HIPCHK(hipSetDevice(b->device));
   BbxParams p; fill_params(b, &p);
   p.obs_every_step = obs_every_step ? 1 : 0;
@@ -1094,6 +1109,46 @@ int bbx_gen_get(const bbx_gen* g, int32_t* nterms, int32_t* coefs, int32_t* exps
     }
   }
   return BBX_OK;
+}
+
+int bbx_parse_ideal(const char* text, int32_t cap_polys, int32_t cap_terms, int32_t* npolys, int32_t* nterms_total,
+                    int32_t* nterms, int32_t* coefs, int32_t* exps) {
+  if (!text || !npolys || !nterms_total) return fail(BBX_E_ARG, "null argument");
+  bbx::HIdeal F; std::string err;
+  if (!bbx::parse_ideal_string(text, F, &err)) return fail(BBX_E_ARG, "%s", err.c_str());
+  size_t total = 0;
+  for (auto& f : F) total += f.t.size();
+  *npolys = (int32_t)F.size(); *nterms_total = (int32_t)total;
+  if (!nterms && !coefs && !exps) return BBX_OK;             // size query
+  if ((int64_t)F.size() > cap_polys || (int64_t)total > cap_terms) return fail(BBX_E_CAPACITY, "output buffers too small: %zu polynomials, %zu terms", F.size(), total);
+  size_t at = 0;
+  for (size_t p = 0; p < F.size(); p++) {
+    if (nterms) nterms[p] = (int32_t)F[p].t.size();
+    for (auto& t : F[p].t) {
+      if (coefs) coefs[at] = t.c;
+      if (exps) for (int v = 0; v < bbx::kN; v++) exps[at * bbx::kN + v] = t.e[v];
+      at++;
+    }
+  }
+  return BBX_OK;
+}
+
+int bbx_format_ideal(int npolys, const int32_t* nterms, const int32_t* coefs, const int32_t* exps, char* out, int cap) {
+  if (npolys < 0 || (npolys && (!nterms || !coefs || !exps)) || cap < 0 || (cap && !out)) return fail(BBX_E_ARG, "bad argument");
+  std::string s;
+  size_t at = 0;
+  for (int p = 0; p < npolys; p++) {
+    std::vector<bbx::HTerm> ts;
+    for (int k = 0; k < nterms[p]; k++, at++) {
+      bbx::HTerm t; t.c = bbx::coef_norm(coefs[at]); t.deg = 0;
+      for (int v = 0; v < bbx::kN; v++) { t.e[v] = exps[at * bbx::kN + v]; if (t.e[v] < 0) return fail(BBX_E_ARG, "negative exponent"); t.deg += t.e[v]; }
+      if (t.c) ts.push_back(t);
+    }
+    if (p) s += '|';
+    s += bbx::format_polynomial(bbx::poly_from_terms(ts));
+  }
+  if ((int)s.size() + 1 <= cap) memcpy(out, s.c_str(), s.size() + 1);
+  return (int)s.size();                                          // length needed, excluding the terminator
 }
 
 }  // extern "C"

@@ -225,6 +225,7 @@ __device__ __forceinline__ void binom_body(const BbxParams& p, char* smem) {
   int episodes = uni(ghdr->episodes), zero_red = uni(ghdr->zero_reductions);
   long long total_steps = ghdr->total_steps, total_adds = ghdr->total_additions, alg_bytes = ghdr->alg_bytes;
   const uint32_t agent_seed = (uint32_t)uni((int)ghdr->agent_seed);
+  uint32_t std_rng = (uint32_t)uni((int)ghdr->std_rng);
   int budget = uni(ghdr->budget), rollout_pos = uni(ghdr->rollout_pos);
   int done_last = uni(ghdr->done_last);
   if (status == BBX_ST_STARVED || status == BBX_ST_SPILL) status = BBX_ST_OK;
@@ -265,6 +266,8 @@ __device__ __forceinline__ void binom_body(const BbxParams& p, char* smem) {
     if (p.agent == BBX_AGENT_EXTERNAL) action = p.actions[env];
     else if (p.agent == BBX_AGENT_HASH) action = (int)bbx_agent_action32(agent_seed, (uint32_t)t_agent, (uint32_t)nP);
     else if (p.agent == BBX_AGENT_FIRST) action = 0;
+    else if (p.agent == BBX_AGENT_LAST) action = nP - 1;
+    else if (p.agent == BBX_AGENT_STDRANDOM) action = std_choice(std_rng, nP);
     else action = select_pair<W>(e, nP, p.agent, [&](int g) { return (int)(e.ginfo[g].y >> 16); });
     action = uni(action);
     if (action < 0 || action >= nP) { status = BBX_ST_BAD_ACTION; break; }
@@ -394,7 +397,7 @@ __device__ __forceinline__ void binom_body(const BbxParams& p, char* smem) {
   if (lane == 0) {
     BbxHdr* h = ghdr;
     h->nG = nG; h->nP = nP; h->arena_used = 0; h->status = status; h->need_reset = need_reset;
-    h->q_head = q_head; h->t = t_agent; h->episode_steps = episode_steps; h->total_steps = total_steps;
+    h->q_head = q_head; h->t = t_agent; h->std_rng = std_rng; h->episode_steps = episode_steps; h->total_steps = total_steps;
     h->total_additions = total_adds; h->episodes = episodes; h->zero_reductions = zero_red; h->steps_done = steps_done;
     h->budget = budget; h->rollout_pos = rollout_pos; h->done_last = done_last; h->alg_bytes = alg_bytes;
     h->vret = vret; h->vdisc = vdisc;

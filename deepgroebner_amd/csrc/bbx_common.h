@@ -56,7 +56,7 @@ struct BbxHdr {             // 128 bytes
   int32_t budget;           // steps still owed in the current rollout (survives queue starvation)
   int32_t rollout_pos;      // steps completed in the current rollout (trace slot)
   int32_t done_last;        // the last executed step ended an episode
-  int32_t reserved0;
+  uint32_t std_rng;         // state of the minstd_rand0 engine behind the reference's seeded Random selection (buchberger.cpp:200-206)
   int64_t alg_bytes;        // algorithmic bytes moved so far (SURVEY.md 8d formula), for the roofline figure
   double vret, vdisc;       // value() rollouts: discounted return so far and the current discount (buchberger.cpp:248-252)
   int32_t reserved[6];
@@ -93,7 +93,9 @@ struct BbxTraceRec {        // one per environment per step when tracing (tests 
   uint64_t obs_hash, pairs_hash, newpoly_hash;
 };
 
-enum { BBX_AGENT_EXTERNAL = 0, BBX_AGENT_HASH = 1, BBX_AGENT_DEGREE = 2, BBX_AGENT_FIRST = 3, BBX_AGENT_NORMAL = 4, BBX_AGENT_SUGAR = 5 };
+enum { BBX_AGENT_EXTERNAL = 0, BBX_AGENT_HASH = 1, BBX_AGENT_DEGREE = 2, BBX_AGENT_FIRST = 3, BBX_AGENT_NORMAL = 4, BBX_AGENT_SUGAR = 5,
+       // the reversed orders of buchberger.cpp:207-240 and the seeded std::default_random_engine choice of :200-206,244
+       BBX_AGENT_LAST = 6, BBX_AGENT_CODEGREE = 7, BBX_AGENT_STRANGE = 8, BBX_AGENT_SPICE = 9, BBX_AGENT_STDRANDOM = 10 };
 enum { BBX_ELIM_GM = 0, BBX_ELIM_LCM = 1, BBX_ELIM_NONE = 2 };
 enum { BBX_REW_ADDITIONS = 0, BBX_REW_REDUCTIONS = 1 };
 

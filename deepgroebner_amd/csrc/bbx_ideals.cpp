@@ -406,4 +406,105 @@ std::unique_ptr<IdealGen> parse_ideal_dist(const std::string& ideal_dist, std::s
   }
 }
 
+// ---------------------------------------------------------------- text format, polynomials.cpp:226-300
+// The reference parses by mutual recursion over an istringstream; the language it accepts is
+//   poly := term*            term := ('+' | '-')* ( INT ['*' mono] | mono )
+//   mono := <end> | VAR ['^' INT] ['*' mono]          VAR := 'a'..'h'
+// and the value is the sum of the terms (like monomials merge, zero sums vanish).  Written here as one left-to-right
+// scan.  Where the reference runs into undefined behaviour this parser reports an error instead: variable 'i'
+// (index N, polynomials.cpp:228), negative or missing exponents, coefficients that are 0 mod 32003 (the reference
+// keeps such a term in the polynomial) and empty polynomials inside an ideal.
+namespace {
+struct Scan {
+  const std::string& s; size_t at = 0;
+  int peek() const { return at < s.size() ? (unsigned char)s[at] : -1; }
+  int get() { return at < s.size() ? (unsigned char)s[at++] : -1; }
+  bool number(long long* v) {           // digits only
+    if (peek() < '0' || peek() > '9') return false;
+    long long x = 0;
+    while (peek() >= '0' && peek() <= '9') { x = x * 10 + (get() - '0'); if (x > 2147483647LL) return false; }
+    *v = x; return true;
+  }
+};
+}  // namespace
+
+bool parse_polynomial(const std::string& text, HPoly& out, std::string* err) {
+  auto fail = [&](const std::string& m, size_t at) { if (err) *err = m + " at column " + std::to_string(at + 1) + " of '" + text + "'"; return false; };
+  Scan sc{text};
+  std::vector<HTerm> ts;
+  while (sc.peek() != -1) {
+    long long sign = 1;
+    while (sc.peek() == '+' || sc.peek() == '-') if (sc.get() == '-') sign = -sign;    // Term{-1,{}} * parse_term
+    HTerm t; t.c = 1; t.e = {}; t.deg = 0;
+    bool mono = true;
+    if (sc.peek() >= '0' && sc.peek() <= '9') {
+      long long c;
+      if (!sc.number(&c)) return fail("coefficient out of range", sc.at);
+      t.c = coef_norm(c);
+      if (sc.peek() == '*') sc.get(); else mono = false;      // "3" is a constant; "3a" is 3 + a
+    }
+    while (mono && sc.peek() != -1) {                          // parse_monomial; "3*" at the end is the constant 3
+      const size_t vat = sc.at;
+      const int v = sc.get() - 'a';
+      if (v < 0 || v >= kN) return fail("invalid variable name", vat);
+      long long pw = 1;
+      if (sc.peek() == '^') {
+        sc.get();
+        if (!sc.number(&pw)) return fail("bad exponent", sc.at);
+      }
+      t.e[v] += (int)pw; t.deg += (int)pw;
+      if (t.deg > 65535) return fail("degree above 65535", vat);
+      if (sc.peek() == '*') sc.get(); else mono = false;
+    }
+    t.c = coef_norm(sign * t.c);
+    if (t.c == 0) return fail("coefficient is zero in GF(32003)", sc.at ? sc.at - 1 : 0);
+    ts.push_back(t);
+  }
+  // Polynomial{t} + (Polynomial{t'} + ...): a sum of single terms, evaluated from the right
+  HPoly acc;
+  for (size_t k = ts.size(); k-- > 0;) {
+    HPoly one; one.t = {ts[k]}; one.sugar = ts[k].deg;
+    acc = poly_add(one, acc);
+  }
+  out = acc;
+  return true;
+}
+
+bool parse_ideal_string(const std::string& text, HIdeal& out, std::string* err) {
+  out.clear();
+  std::istringstream iss(text);
+  std::string piece;
+  while (std::getline(iss, piece, '|')) {
+    while (!piece.empty() && (piece.back() == '\r' || piece.back() == '\n')) piece.pop_back();
+    HPoly f;
+    if (!parse_polynomial(piece, f, err)) return false;
+    if (f.t.empty()) { if (err) *err = "zero polynomial in ideal '" + text + "'"; return false; }
+    out.push_back(std::move(f));
+  }
+  if (out.empty()) { if (err) *err = "empty ideal string"; return false; }
+  return true;
+}
+
+std::string format_polynomial(const HPoly& f) {
+  if (f.t.empty()) return "0";
+  std::string s;
+  for (size_t k = 0; k < f.t.size(); k++) {
+    const HTerm& t = f.t[k];
+    const int c = t.c > kP / 2 ? t.c - kP : t.c;            // signed representative
+    const int a = c < 0 ? -c : c;
+    if (c < 0) s += '-'; else if (k) s += '+';
+    if (t.deg == 0) { s += std::to_string(a); continue; }
+    if (a != 1) { s += std::to_string(a); s += '*'; }
+    bool first = true;
+    for (int v = 0; v < kN; v++) {
+      if (!t.e[v]) continue;
+      if (!first) s += '*';
+      first = false;
+      s += (char)('a' + v);
+      if (t.e[v] != 1) { s += '^'; s += std::to_string(t.e[v]); }
+    }
+  }
+  return s;
+}
+
 }  // namespace bbx

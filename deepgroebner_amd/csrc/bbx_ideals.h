@@ -59,4 +59,10 @@ std::unique_ptr<IdealGen> make_fixed(const HIdeal& F);
 std::unique_ptr<IdealGen> make_list(std::shared_ptr<const std::vector<HIdeal>> ideals, int first, int stride, int nvars);
 std::unique_ptr<IdealGen> parse_ideal_dist(const std::string& dist, std::string* err);  // ideals.cpp:103-143
 
+// text format of data/stats/<dist>/<dist>.csv: polynomials "413*a^2*b^5*c+32*d^2-5" joined by '|'
+// (parse_polynomial polynomials.cpp:226-300, parse_ideal_string scripts/make_strat.cpp:12-19)
+bool parse_polynomial(const std::string& text, HPoly& out, std::string* err);
+bool parse_ideal_string(const std::string& text, HIdeal& out, std::string* err);
+std::string format_polynomial(const HPoly& f);   // the same format, signed coefficient representatives like Macaulay2 prints
+
 }  // namespace bbx

@@ -711,10 +711,11 @@ __device__ uint64_t wave_poly_hash(const Env<W>& e, int g) {
   return wave_sum64(h);
 }
 
-// ------------------------------------------------------------------ selection strategies (buchberger.cpp:165-198)
-// First index of the pair with the minimal key.  P is always in ascending (j, i) order (new pairs carry the largest
-// j and are appended sorted by i, removals keep the order), so "first minimal row" IS the reference's (key, j, i)
-// tie-break.  Keys: Degree = deg lcm; Normal = lcm in grevlex; Sugar = (sugar of the pair, lcm).
+// ------------------------------------------------------------------ selection strategies (buchberger.cpp:165-240)
+// Index of the pair with the minimal key (First/Degree/Normal/Sugar) or the maximal one (Last/Codegree/Strange/
+// Spice).  P is always in ascending (j, i) order (new pairs carry the largest j and are appended sorted by i,
+// removals keep the order), so the row index IS the reference's (j, i) tie-break in both directions.
+// Keys: Degree = deg lcm; Normal = lcm in grevlex; Sugar = (sugar of the pair, lcm).
 template <int W> struct SelKey { uint32_t s; Mono<W> m; uint32_t r; };
 template <int W> __device__ __forceinline__ bool sel_less(const SelKey<W>& a, const SelKey<W>& b) {
   if (a.s != b.s) return a.s < b.s;
@@ -724,31 +725,49 @@ template <int W> __device__ __forceinline__ bool sel_less(const SelKey<W>& a, co
 }
 template <int W, class EnvT, class SugarFn>
 __device__ int select_pair(const EnvT& e, int nP, int agent, SugarFn sugar_of) {
-  SelKey<W> best; best.s = 0xFFFFFFFFu; best.m = m_zero<W>(); best.r = 0xFFFFFFFFu;
+  const bool rev = agent >= BBX_AGENT_LAST;          // pick the maximum
+  const bool by_deg = agent == BBX_AGENT_DEGREE || agent == BBX_AGENT_CODEGREE;
+  const bool by_sugar = agent == BBX_AGENT_SUGAR || agent == BBX_AGENT_SPICE;
+  SelKey<W> best; best.m = m_zero<W>();
+  best.s = rev ? 0u : 0xFFFFFFFFu; best.r = rev ? 0u : 0xFFFFFFFFu;   // the identity of min / max: never beats a real row
   for (int r = lane_id(); r < nP; r += WAVE) {
     const uint32_t pr = e.pairs[r];
     const int i = pr & 0xffffu, j = pr >> 16;
     const Mono<W> li = e.lm[i], lj = e.lm[j];
     const Mono<W> l = m_lcm(li, lj);
     SelKey<W> c; c.r = (uint32_t)r; c.m = m_zero<W>(); c.s = 0;
-    if (agent == BBX_AGENT_DEGREE) c.s = m_deg(l);
+    if (by_deg) c.s = m_deg(l);
     else {
       c.m = l;
-      if (agent == BBX_AGENT_SUGAR) {
+      if (by_sugar) {
         const uint32_t si = (uint32_t)sugar_of(i) + m_deg(m_div(l, li)), sj = (uint32_t)sugar_of(j) + m_deg(m_div(l, lj));
         c.s = si > sj ? si : sj;
       }
     }
-    if (sel_less<W>(c, best)) best = c;
+    if (rev ? sel_less<W>(best, c) : sel_less<W>(c, best)) best = c;
   }
   for (int o = 32; o > 0; o >>= 1) {
     SelKey<W> t;
     t.s = (uint32_t)__shfl_xor((int)best.s, o, WAVE); t.r = (uint32_t)__shfl_xor((int)best.r, o, WAVE);
 #pragma unroll
     for (int q = 0; q < W; q++) t.m.w[q] = (uint32_t)__shfl_xor((int)best.m.w[q], o, WAVE);
-    if (sel_less<W>(t, best)) best = t;
+    if (rev ? sel_less<W>(best, t) : sel_less<W>(t, best)) best = t;
   }
   return (int)best.r;
+}
+// choice(P.begin(), P.end(), rng) with std::default_random_engine (= minstd_rand0, x <- 16807 x mod 2^31-1) and a
+// fresh std::uniform_int_distribution<>(0, n-1) per call (ideals.h:68-73): libstdc++'s downscaling branch, since
+// the engine's range 2^31-3 always exceeds n-1: draw until below n*floor(range/n), then divide.
+__device__ __forceinline__ int std_choice(uint32_t& x, int n) {
+  const uint32_t urngrange = 2147483645u, uerange = (uint32_t)n;
+  const uint32_t scaling = urngrange / uerange, past = uerange * scaling;
+  uint32_t ret;
+  if (x == 0u || x >= 2147483647u) x = 1u;      // never a state of the engine; guards the loop against a corrupt header
+  do {
+    x = (uint32_t)(((uint64_t)x * 16807u) % 2147483647u);
+    ret = x - 1u;
+  } while (ret >= past);
+  return (int)(ret / scaling);
 }
 // discounted-return bookkeeping of value(): stats.discounted_return += discount * reward; discount *= gamma,
 // in double and without fusing the multiply into the add (the reference runs on x86-64 without FMA)
@@ -793,6 +812,7 @@ __device__ __forceinline__ void step_body(const BbxParams& p, char* smem, unsign
   int episodes = uni(ghdr->episodes), zero_red = uni(ghdr->zero_reductions);
   long long total_steps = ghdr->total_steps, total_adds = ghdr->total_additions, alg_bytes = ghdr->alg_bytes;
   const uint32_t agent_seed = uni((int)ghdr->agent_seed);
+  uint32_t std_rng = (uint32_t)uni((int)ghdr->std_rng);
   int budget = uni(ghdr->budget), rollout_pos = uni(ghdr->rollout_pos);
   int done_last = uni(ghdr->done_last);
   if (status == BBX_ST_STARVED || status == BBX_ST_SPILL) status = BBX_ST_OK;   // transient states: try again
@@ -854,6 +874,8 @@ __device__ __forceinline__ void step_body(const BbxParams& p, char* smem, unsign
     if (p.agent == BBX_AGENT_EXTERNAL) action = p.actions[env];
     else if (p.agent == BBX_AGENT_HASH) action = (int)bbx_agent_action32(agent_seed, (uint32_t)t_agent, (uint32_t)nP);
     else if (p.agent == BBX_AGENT_FIRST) action = 0;
+    else if (p.agent == BBX_AGENT_LAST) action = nP - 1;
+    else if (p.agent == BBX_AGENT_STDRANDOM) action = std_choice(std_rng, nP);
     else action = select_pair<W>(e, nP, p.agent, [&](int g) { return (int)e.psug[g]; });
     action = uni(action);
     if (action < 0 || action >= nP) { status = BBX_ST_BAD_ACTION; break; }
@@ -993,7 +1015,7 @@ __device__ __forceinline__ void step_body(const BbxParams& p, char* smem, unsign
   if (lane == 0) {
     BbxHdr* h = ghdr;
     h->nG = nG; h->nP = nP; h->arena_used = arena_used; h->status = status; h->need_reset = need_reset;
-    h->q_head = q_head; h->t = t_agent; h->episode_steps = episode_steps; h->total_steps = total_steps;
+    h->q_head = q_head; h->t = t_agent; h->std_rng = std_rng; h->episode_steps = episode_steps; h->total_steps = total_steps;
     h->total_additions = total_adds; h->episodes = episodes; h->zero_reductions = zero_red; h->steps_done = steps_done;
     h->budget = budget; h->rollout_pos = rollout_pos; h->done_last = done_last; h->alg_bytes = alg_bytes;
     h->vret = vret; h->vdisc = vdisc;
@@ -1063,6 +1085,7 @@ __global__ void bbx_init_kernel(char* recs, uint32_t rec_bytes, int B, const uin
   BbxHdr* h = (BbxHdr*)(recs + (size_t)env * rec_bytes);
   BbxHdr z = {};
   z.agent_seed = agent_seeds ? agent_seeds[env] : (uint32_t)env;
+  z.std_rng = 1u;                               // std::default_random_engine's default seed
   *h = z;
 }
 // request a reset (mask == null: every environment); clears a sticky error so the slot can be reused

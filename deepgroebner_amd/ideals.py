@@ -134,3 +134,44 @@ def degree_distribution(n, d, dist="uniform", constants=False):
         raise ValueError("unrecognized distribution type")
     tot = float(sum(w))
     return [x / tot for x in w]
+
+
+def parse_ideal_string(text):
+    """One line of data/stats/<dist>/<dist>.csv -> ideal: polynomials like "413*a^2*b^5*c+32*d^2-5" joined by "|"
+    (reference parse_polynomial, polynomials.cpp:226-300; parse_ideal_string, scripts/make_strat.cpp:12-19).
+    Exponent tuples keep all 8 slots, as the reference's Monomial does."""
+    raw = text.strip().encode()
+    cap_p, cap_t = raw.count(b"|") + 1, max(len(raw), 1)
+    np_, nt = C.c_int32(), C.c_int32()
+    nterms = np.zeros(cap_p, dtype=np.int32)
+    coefs = np.zeros(cap_t, dtype=np.int32)
+    exps = np.zeros((cap_t, NV), dtype=np.int32)
+    _ffi.check(_ffi.lib().bbx_parse_ideal(raw, cap_p, cap_t, C.byref(np_), C.byref(nt), _ffi.ptr(nterms), _ffi.ptr(coefs),
+                                          _ffi.ptr(exps)))
+    return _terms(nterms[:np_.value], coefs, exps, NV)
+
+
+def parse_polynomial(text):
+    """reference parse_polynomial (polynomials.cpp:297-300) for one non-zero polynomial."""
+    if "|" in text:
+        raise ValueError("one polynomial expected")
+    return parse_ideal_string(text)[0]
+
+
+def format_ideal(F):
+    """The inverse of parse_ideal_string: the line scripts/make_dist.m2:69-77 of the reference writes for an ideal."""
+    nterms = np.array([len(f) for f in F], dtype=np.int32)
+    coefs = np.array([c for f in F for c, _ in f], dtype=np.int32)
+    exps = np.zeros((max(len(coefs), 1), NV), dtype=np.int32)
+    r = 0
+    for f in F:
+        for _, e in f:
+            exps[r, :len(e)] = e
+            r += 1
+    L = _ffi.lib()
+    need = L.bbx_format_ideal(len(F), _ffi.ptr(nterms), _ffi.ptr(coefs), _ffi.ptr(exps), None, 0)
+    if need < 0:
+        _ffi.check(need)
+    buf = C.create_string_buffer(need + 1)
+    _ffi.check(min(0, L.bbx_format_ideal(len(F), _ffi.ptr(nterms), _ffi.ptr(coefs), _ffi.ptr(exps), buf, need + 1)))
+    return buf.value.decode()

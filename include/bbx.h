@@ -37,7 +37,10 @@ enum bbx_status {
 enum { BBX_GEBAUERMOELLER = 0, BBX_LCM = 1, BBX_NONE = 2 };
 enum { BBX_ADDITIONS = 0, BBX_REDUCTIONS = 1 };
 /* built-in device-side agents for bbx_rollout (0 = actions supplied by the caller) */
-enum { BBX_EXTERNAL = 0, BBX_RANDOM_HASH = 1, BBX_DEGREE = 2, BBX_FIRST = 3, BBX_NORMAL = 4, BBX_SUGAR = 5 };
+enum { BBX_EXTERNAL = 0, BBX_RANDOM_HASH = 1, BBX_DEGREE = 2, BBX_FIRST = 3, BBX_NORMAL = 4, BBX_SUGAR = 5,
+       /* the remaining SelectionType values of buchberger.h:111 / buchberger.cpp:200-240: the reversed orders, and
+          Random as the reference draws it from a seeded std::default_random_engine (see bbx_seed_strategy) */
+       BBX_LAST = 6, BBX_CODEGREE = 7, BBX_STRANGE = 8, BBX_SPICE = 9, BBX_RANDOM_STD = 10 };
 
 /* Per-environment capacities; 0 picks a default suited to the distribution. */
 typedef struct bbx_caps {
@@ -95,6 +98,10 @@ int bbx_clone_envs(bbx_batch* b, int n, const int32_t* src, const int32_t* dst);
 int bbx_seed(bbx_batch* b, const int64_t* seeds);
 /* seeds of the built-in BBX_RANDOM_HASH agent: action = bbx_agent_action(seed, t, rows), t = steps taken so far */
 int bbx_seed_agent(bbx_batch* b, const uint32_t* seeds);
+/* seeds of the BBX_RANDOM_STD agent: rng.seed(seed) of buchberger(..., SelectionType::Random, ..., seed)
+ * (buchberger.cpp:200-203); every pick is choice(P.begin(), P.end(), rng) (buchberger.cpp:244, ideals.h:68-73).
+ * scripts/make_strat.cpp:66 passes the same seed for every ideal. */
+int bbx_seed_strategy(bbx_batch* b, const int64_t* seeds);
 
 /* ---- LeadMonomialsEnv::reset (buchberger.cpp:384-395, wrapped.pyx:18-21) ----------------------
  * mask == NULL resets every environment, else those with mask[e] != 0.  rows[e] = |P|. */
@@ -180,6 +187,17 @@ int bbx_gen_nvars(const bbx_gen* g);
  * the ideal drawn last: nterms[npolys], coefs[nterms_total], exps[nterms_total*8]; sugars may be NULL */
 int bbx_gen_next(bbx_gen* g, int32_t* npolys, int32_t* nterms_total);
 int bbx_gen_get(const bbx_gen* g, int32_t* nterms, int32_t* coefs, int32_t* exps, int32_t* sugars);
+
+/* ---- ideals as text (data/stats/<dist>/<dist>.csv lines) ------------------------------------------
+ * bbx_parse_ideal reads polynomials such as "413*a^2*b^5*c+32*d^2-5" joined by '|' (parse_polynomial,
+ * polynomials.cpp:226-300; parse_ideal_string, scripts/make_strat.cpp:12-19) into the flat layout bbx_create_ideals
+ * takes.  It always reports the sizes; with nterms == coefs == exps == NULL it only does that.  Inputs on which the
+ * reference has undefined behaviour (variable beyond 'h', zero coefficients, empty polynomials) are BBX_E_ARG.
+ * bbx_format_ideal writes the same format (coefficients as signed representatives, the way Macaulay2's make_dist.m2
+ * prints them) and returns the length needed excluding the terminator; nothing is written when cap is too small. */
+int bbx_parse_ideal(const char* text, int32_t cap_polys, int32_t cap_terms, int32_t* npolys, int32_t* nterms_total,
+                    int32_t* nterms, int32_t* coefs, int32_t* exps);
+int bbx_format_ideal(int npolys, const int32_t* nterms, const int32_t* coefs, const int32_t* exps, char* out, int cap);
 
 uint32_t bbx_agent_hash(uint32_t seed, uint32_t t);
 uint32_t bbx_agent_action(uint32_t seed, uint32_t t, uint32_t rows);   /* (hash * rows) >> 32 */

@@ -79,3 +79,43 @@ def test_no_silent_cpu_fallback(ffi_):
     with pytest.raises(ffi_.BbxError) as ei:
         VecLeadMonomialsEnv("3-20-10-weighted", batch=2)
     assert ei.value.code == -2
+
+
+# ---- the text format of data/stats/*.csv (host code, no device involved) -------------------------------------
+@pytest.mark.parametrize("s,want", [                       # tests/test_polynomials.cpp:219-246 of the reference
+    ("a^2*b+c*d", [(1, (2, 1, 0, 0)), (1, (0, 0, 1, 1))]),
+    ("413*a^2*b^5*c+32*d^2-5", [(413, (2, 5, 1, 0)), (32, (0, 0, 0, 2)), (32003 - 5, (0, 0, 0, 0))]),
+    ("3", [(3, ())]),
+    ("12*a^2-b*c+13*d", [(12, (2, 0, 0, 0)), (32003 - 1, (0, 1, 1, 0)), (13, (0, 0, 0, 1))]),
+])
+def test_parse_polynomial_known_answers(ffi_, s, want):
+    from deepgroebner_amd import parse_polynomial
+    pad = lambda e: tuple(e) + (0,) * (8 - len(e))          # noqa: E731
+    assert parse_polynomial(s) == [(c, pad(e)) for c, e in want]
+
+
+def test_parse_matches_oracle_and_round_trips(ffi_):
+    from oracle import ffi as offi
+    from deepgroebner_amd import format_ideal, parse_ideal_dist, parse_ideal_string, parse_polynomial
+    bo = offi.load("bo")
+    for dist, seed in (("3-20-10-weighted", 1), ("5-10-5-uniform", 2), ("3-6-5-0.5-uniform-consts", 3), ("4-3-6-1.5-maximum", 4)):
+        g = parse_ideal_dist(dist); g.seed(seed)
+        for _ in range(5):
+            F = next(g)
+            line = format_ideal(F)
+            assert " " not in line and line.count("|") == len(F) - 1
+            assert parse_ideal_string(line) == F
+            for text, f in zip(line.split("|"), F):
+                got = bo.parse_polynomial(text)             # the restated reference parser reads what we write
+                assert [(c, tuple(e)) for c, e in got] == f
+    # the grammar's corners, settled by the reference's recursion (polynomials.cpp:226-294)
+    for s in ("a-a+b", "3a", "--3*a*", "+a", "a*b^2*a", "2*a+3*a", "h^2-1"):
+        got = bo.parse_polynomial(s)
+        assert parse_polynomial(s) == [(c, tuple(e)) for c, e in got], s
+
+
+@pytest.mark.parametrize("bad", ["a+i", "a^-2", "32003*a", "a||b", "a*3", "a^b", "", "a-a", "99999999999*a"])
+def test_parse_rejects_what_the_reference_leaves_undefined(ffi_, bad):
+    from deepgroebner_amd import parse_ideal_string
+    with pytest.raises(ffi_.BbxError):
+        parse_ideal_string(bad)

@@ -1,6 +1,8 @@
 """Parity of the HIP path (through the C ABI) against the golden vectors recorded from the
 compiled reference and against the CPU oracle.  Bit-exact: every action, reward, |P|, |G|,
 observation matrix, pair list and new basis element of every step, plus the full final state."""
+import os
+
 import numpy as np
 import pytest
 
@@ -386,6 +388,59 @@ def test_strategy_stats_like_make_strat():
             assert got[n].tolist() == [st["zero_reductions"], st["nonzero_reductions"], st["polynomial_additions"]], (strategy, n)
     got = strategy_stats([trim[-1]], "degree")
     assert got[0].tolist() == [69, 41, 1442]                  # cyclic-5, Degree
+
+
+def test_strategy_stats_reversed_and_seeded_random():
+    """The remaining SelectionType values of make_strat.cpp:49-59: Last / Codegree / Strange / Spice (maximum instead
+    of minimum, buchberger.cpp:207-240) and Random drawn from std::default_random_engine seeded per run
+    (buchberger.cpp:200-203, 244) — the same seed for every ideal, as make_strat.cpp:66 passes it."""
+    from deepgroebner_amd import strategy_stats
+    bo = ffi.load("bo")
+    ideals = []
+    for dist, seed in (("3-20-10-weighted", 3), ("3-6-5-0.5-uniform", 4), ("4-5-4-weighted", 5), ("3-20-10-uniform", 6)):
+        g = bo.generator(dist); g.seed(seed)
+        ideals += [g.next() for _ in range(3)]
+    ideals.append(bo.cyclic(4))
+    trim = [[[(c, e[:5]) for c, e in f] for f in F] for F in ideals]
+    binom = trim[:3] + trim[9:12]                             # one batch that takes the binomial kernel class
+    for strategy, seed in (("last", None), ("codegree", None), ("strange", None), ("spice", None), ("random", 5),
+                           ("random", -7), ("random", 2147483647)):
+        for sub in (trim, binom):
+            got = strategy_stats(sub, strategy, seed=seed)
+            for n, F in enumerate(sub):
+                _, st = bo.buchberger(F, selection=strategy, want_basis=False, seed=seed)
+                assert got[n].tolist() == [st["zero_reductions"], st["nonzero_reductions"], st["polynomial_additions"]], (strategy, seed, n)
+
+
+def test_make_strat_pipeline(tmp_path):
+    """scripts/make_dist.py -> scripts/make_strat.py: the CSV files of the reference's pipeline (make_strat.cpp:22-72),
+    and its exit codes for a missing input (2) and an existing output (3)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    run = lambda *a: subprocess.run([sys.executable, *a], cwd=tmp_path, capture_output=True, text=True)   # noqa: E731
+    assert run(os.path.join(root, "scripts/make_strat.py"), "3-20-10-weighted", "degree").returncode == 2
+    r = run(os.path.join(root, "scripts/make_dist.py"), "3-20-10-weighted", "20", "9")
+    assert r.returncode == 0, r.stderr
+    r = run(os.path.join(root, "scripts/make_strat.py"), "3-20-10-weighted", "degree")
+    assert r.returncode == 0, r.stderr
+    assert run(os.path.join(root, "scripts/make_strat.py"), "3-20-10-weighted", "degree").returncode == 3
+    r = run(os.path.join(root, "scripts/make_strat.py"), "3-20-10-weighted", "random", "11")
+    assert r.returncode == 0, r.stderr
+    bo = ffi.load("bo")
+    from deepgroebner_amd import parse_ideal_string
+    d = tmp_path / "data/stats/3-20-10-weighted"
+    lines = (d / "3-20-10-weighted.csv").read_text().splitlines()
+    assert lines[0] == "Ideal" and len(lines) == 21
+    g = bo.generator("3-20-10-weighted"); g.seed(9)
+    for name, sel, seed in (("3-20-10-weighted_degree.csv", "degree", None), ("3-20-10-weighted_random_11.csv", "random", 11)):
+        out = (d / name).read_text().splitlines()
+        assert out[0] == "ZeroReductions,NonzeroReductions,PolynomialAdditions" and len(out) == 21
+        for n, line in enumerate(lines[1:]):
+            F = parse_ideal_string(line)
+            _, st = bo.buchberger(F, selection=sel, want_basis=False, seed=seed)
+            assert out[1 + n] == "%d,%d,%d" % (st["zero_reductions"], st["nonzero_reductions"], st["polynomial_additions"])
+    for line in lines[1:]:                                    # the file holds the generator's own stream
+        assert parse_ideal_string(line) == g.next()
 
 
 def test_step_autoreset_vec_convention():
