@@ -76,7 +76,12 @@ struct FastState {                 // reducer-order arrays, lane l <-> reducers 
 // TRACE: per-step parity hashes (tests).  ACCT: count the algorithmic bytes of every step (roofline numerator;
 // a property of the workload, so the lean production variant leaves it out and bench.py obtains it from an
 // accounting run over a copy of the same batch).
-#define FSTAMP(slot) do { if (PROF) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); prof_sum[slot] += t_ - prof_last; prof_last = t_; } } while (0)
+#ifdef BBX_MARK
+#define FMARK(slot) asm volatile("; FMARK " #slot)
+#else
+#define FMARK(slot)
+#endif
+#define FSTAMP(slot) do { FMARK(slot); if (PROF) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); prof_sum[slot] += t_ - prof_last; prof_last = t_; } } while (0)
 template <bool TRACE, bool ACCT, bool PROF = false>
 __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
   unsigned long long prof_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -288,6 +293,7 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
   };
 
   for (;;) {
+    nG = uni(nG); nP = uni(nP); status = uni(status); need_reset = uni(need_reset); q_head = uni(q_head); budget = uni(budget);
     if (status != BBX_ST_OK) break;
     if (need_reset) {                                      // BuchbergerEnv::reset from the next queued ideal(s)
       bool ok = true;
@@ -295,7 +301,7 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
         const uint32_t* slot;
         if (p.q_fixed) slot = p.qwords;
         else {
-          const int tail = p.qtail[env];
+          const int tail = uni(p.qtail[env]);            // (a plain load would count as divergent and drag nG / nP into VGPRs)
           if (q_head >= tail) { status = BBX_ST_STARVED; ok = false; break; }
           slot = p.qwords + (size_t)env * p.q_env_stride + (size_t)(q_head % (int)p.q_nslots) * p.q_slot_words;
         }
@@ -375,43 +381,68 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
 
     FSTAMP(2);                                             // 2: S-polynomial
     // ---- reduce (buchberger.cpp:24-49), entirely in registers -----------------------------------------------------------
-    BTerm<2> r0, r1;
-    r0.c = 0; r1.c = 0; r0.m = m_zero<2>(); r1.m = m_zero<2>();
+    // h and r are wave-uniform, so they are carried as scalars (SGPRs): the loop's control flow is then scalar
+    // branches (no exec masking, no per-lane copies at the joins) and its arithmetic runs on the scalar unit; only
+    // the divisor scan over the reducer registers and the v_readlane of the chosen reducer are vector instructions.
+    // Monomial quotient / product are plain word subtracts / adds here: no field borrows (the divisor divides) and
+    // no field carries while degrees stay below 2^16, which the sugar bound checked below guarantees.
+    uint32_t h0c = (uint32_t)uni((int)h0.c), h0a = (uint32_t)uni((int)h0.m.w[0]), h0b = (uint32_t)uni((int)h0.m.w[1]);
+    uint32_t h1c = (uint32_t)uni((int)h1.c), h1a = (uint32_t)uni((int)h1.m.w[0]), h1b = (uint32_t)uni((int)h1.m.w[1]);
+    uint32_t r0c = 0, r0a = 0, r0b = 0, r1c = 0, r1a = 0, r1b = 0;
     int nred = 0, rsug = 0;
-    while (uni((int)h0.c) != 0) {
-      const int hn = h1.c ? 2 : 1;
-      const uint64_t mA = ballot64(m_divides(S.slmA, h0.m));        // sentinels never divide
+    while (h0c != 0) {
+      const int hn = h1c ? 2 : 1;
+      M2 hm; hm.w[0] = h0a; hm.w[1] = h0b;
       int found = -1;
-      M2 lmg, tmg; uint2 sg;
-      if (mA) { found = __builtin_ctzll(mA); lmg = f_fetch(S.slmA, found); tmg = f_fetch(S.stmA, found); sg = f_fetch(S.sinA, found); }
-      else if (nG > 64) {
-        const uint64_t mB = ballot64(m_divides(S.slmB, h0.m));
-        if (mB) { const int l = __builtin_ctzll(mB); found = 64 + l; lmg = f_fetch(S.slmB, l); tmg = f_fetch(S.stmB, l); sg = f_fetch(S.sinB, l); }
+      uint32_t lg0 = 0, lg1 = 0, tg0 = 0, tg1 = 0, sx = 0, sy = 0;
+      const uint64_t mA = ballot64(m_divides(S.slmA, hm));          // sentinels never divide
+      if (mA) {
+        found = __builtin_ctzll(mA);
+        lg0 = f_readlane(S.slmA.w[0], found); lg1 = f_readlane(S.slmA.w[1], found);
+        tg0 = f_readlane(S.stmA.w[0], found); tg1 = f_readlane(S.stmA.w[1], found);
+        sx = f_readlane(S.sinA.x, found); sy = f_readlane(S.sinA.y, found);
+      } else if (nG > 64) {
+        const uint64_t mB = ballot64(m_divides(S.slmB, hm));
+        if (mB) {
+          const int l = __builtin_ctzll(mB);
+          found = 64 + l;
+          lg0 = f_readlane(S.slmB.w[0], l); lg1 = f_readlane(S.slmB.w[1], l);
+          tg0 = f_readlane(S.stmB.w[0], l); tg1 = f_readlane(S.stmB.w[1], l);
+          sx = f_readlane(S.sinB.x, l); sy = f_readlane(S.sinB.y, l);
+        }
       }
       if (found >= 0) {                                              // h <- h - (LT h / LT f) f
-        const uint32_t tcg = sg.x & 0xffffu, invg = sg.x >> 16;
-        const M2 q = m_div(h0.m, lmg);
-        const uint32_t c = mulmod(h0.c, invg);
-        BTerm<2> b;
-        b.c = tcg ? negmod(mulmod(c, tcg)) : 0u;
-        b.m = m_mul(tmg, q);
-        const int fs = (int)(sg.y & 0xffffu) + (int)m_deg(q);
-        hsug = fs > hsug ? fs : hsug;                  // checked once after the loop: nothing is modified until then
-        BTerm<2> n0, n1;
-        merge2<2>(h1, b, n0, n1);
-        if (ACCT) bytes += 8 * (found + 1) + 12 * (tcg ? 2 : 1) + 12 * (hn + (n0.c ? 1 : 0) + (n1.c ? 1 : 0));
-        h0 = n0; h1 = n1;
+        const uint32_t tcg = sx & 0xffffu, invg = sx >> 16;
+        const uint32_t q0 = h0a - lg0, q1 = h0b - lg1;               // LT h / LT f
+        const uint32_t c = mulmod(h0c, invg);
+        const uint32_t bc = negmod(mulmod(c, tcg));                  // 0 when f has no tail
+        const uint32_t b0 = tg0 + q0, b1 = tg1 + q1;
+        const int fs = (int)(sy & 0xffffu) + (int)(q1 >> 16);
+        hsug = fs > hsug ? fs : hsug;
+        if (hsug > 65535) break;                                     // reported below; nothing has been modified
+        // h1 + b  (polynomials.cpp:148-177 on single optional terms)
+        const uint64_t kx = (((uint64_t)h1b << 32) | h1a) ^ 0x0000FFFFFFFFFFFFull;
+        const uint64_t ky = (((uint64_t)b1 << 32) | b0) ^ 0x0000FFFFFFFFFFFFull;
+        uint32_t n0c, n0a, n0b, n1c, n1a, n1b;
+        if (bc == 0) { n0c = h1c; n0a = h1a; n0b = h1b; n1c = 0; n1a = 0; n1b = 0; }
+        else if (h1c == 0 || ky > kx) { n0c = bc; n0a = b0; n0b = b1; n1c = h1c; n1a = h1a; n1b = h1b; }
+        else if (kx > ky) { n0c = h1c; n0a = h1a; n0b = h1b; n1c = bc; n1a = b0; n1b = b1; }
+        else { n0c = addmod(h1c, bc); n0a = h1a; n0b = h1b; n1c = 0; n1a = 0; n1b = 0; }   // a zero sum drops the term
+        if (ACCT) bytes += 8 * (found + 1) + 12 * (tcg ? 2 : 1) + 12 * (hn + (n0c ? 1 : 0) + (n1c ? 1 : 0));
+        h0c = n0c; h0a = n0a; h0b = n0b; h1c = n1c; h1a = n1a; h1b = n1b;
         nred++;                                        // (terminates: the lead monomial strictly decreases)
       } else {                                                       // r <- r + LT h ; h <- h - LT h
         if (ACCT) bytes += 8 * nG + 12 * (2 * hn - 1);
-        if (r0.c == 0) r0 = h0; else r1 = h0;
-        const int d = (int)m_deg(h0.m);
+        if (r0c == 0) { r0c = h0c; r0a = h0a; r0b = h0b; } else { r1c = h0c; r1a = h0a; r1b = h0b; }
+        const int d = (int)(h0b >> 16);
         rsug = d > rsug ? d : rsug;
-        h0 = h1; h1.c = 0;
+        h0c = h1c; h0a = h1a; h0b = h1b; h1c = 0;
       }
     }
     if (hsug > 65535) { status = BBX_ST_DEG_OVERFLOW; break; }
-    rsug = uni(rsug > hsug ? rsug : hsug);
+    rsug = rsug > hsug ? rsug : hsug;
+    BTerm<2> r0, r1;
+    r0.c = r0c; r0.m.w[0] = r0a; r0.m.w[1] = r0b; r1.c = r1c; r1.m.w[0] = r1a; r1.m.w[1] = r1b;
 
     FSTAMP(3);                                             // 3: reduce
     // ---- basis / pair-set update (buchberger.cpp:321-327) ------------------------------------------------------------

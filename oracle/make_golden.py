@@ -103,7 +103,7 @@ def main():
     stats = {}
     from .trace import fnv64
     for n, sels in ((3, tuple(ffi.SELECTION)), (4, ("degree", "normal", "sugar", "first", "last", "codegree", "strange", "spice")),
-                    (5, ("degree", "normal", "sugar")), (6, ("degree",))):
+                    (5, ("degree", "normal", "sugar")), (6, ("degree",)), (7, ("degree",))):
         for sel in sels:
             if sel == "random":
                 G, st = ref.buchberger(ref.cyclic(n), selection=sel, seed=77)
