@@ -293,7 +293,10 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
   };
 
   for (;;) {
-    nG = uni(nG); nP = uni(nP); status = uni(status); need_reset = uni(need_reset); q_head = uni(q_head); budget = uni(budget);
+    // |P| is wave-uniform by construction, but the compiler's uniformity analysis loses that across the loop; pinned
+    // here, every branch of the step is a scalar branch (without it the whole body runs under exec masks, with
+    // per-lane copies of all state at each join: +40 % instructions)
+    nP = uni(nP);
     if (status != BBX_ST_OK) break;
     if (need_reset) {                                      // BuchbergerEnv::reset from the next queued ideal(s)
       bool ok = true;

@@ -60,7 +60,13 @@ __device__ __forceinline__ uint32_t wave_min32(uint32_t x) {
 }
 
 // ------------------------------------------------------------------ GF(32003)   polynomials.h:10-26
-__device__ __forceinline__ uint32_t mulmod(uint32_t a, uint32_t b) { return (a * b) % BBX_P; }
+// a, b in [0, P): the product is below 2^30, where floor(x / P) == (x * ceil(2^45 / P)) >> 45 exactly (the error term
+// x * (M*P - 2^45) / (P * 2^45) stays below 2^-15 < 1/P), i.e. one high multiply instead of the generic 33-bit magic
+__device__ __forceinline__ uint32_t mulmod(uint32_t a, uint32_t b) {
+  const uint32_t x = a * b;
+  const uint32_t q = (uint32_t)(((uint64_t)x * 1099408559ull) >> 45);
+  return x - q * BBX_P;
+}
 __device__ __forceinline__ uint32_t addmod(uint32_t a, uint32_t b) { uint32_t s = a + b; return s >= BBX_P ? s - BBX_P : s; }
 __device__ __forceinline__ uint32_t negmod(uint32_t a) { return a ? BBX_P - a : 0u; }
 // inverse (polynomials.cpp:11-23 computes the same unique field element by extended Euclid):
