@@ -104,26 +104,26 @@ __device__ bool bin_reset(BEnv<W>& e, const BbxParams& p, const BbxLayout& L, in
     const uint32_t* slot;
     if (p.q.fixed) slot = p.q.words;
     else {
-      int tail = p.q.tail[env];
+      const int tail = ldc(p.q.tail + env);
       if (q_head >= tail) { *status = BBX_ST_STARVED; return false; }
       slot = p.q.words + (size_t)env * p.q.env_stride + (size_t)(q_head % (int)p.q.nslots) * p.q.slot_words;
     }
     nG = 0; nP = 0;
-    const int npoly = (int)slot[0];
+    const int npoly = (int)ldc(slot);               // queue words come in through scalar loads (see ldc)
     const uint32_t* w = slot + 1;
     for (int f = 0; f < npoly; f++) {
-      const int n = uni((int)w[0]), sugar = uni((int)w[1]);
+      const int n = (int)ldc(w), sugar = (int)ldc(w + 1);
       w += 2;
       if (n < 1 || n > 2) { *status = BBX_ST_POLY_TOO_LONG; return false; }
       BTerm<W> t0, t1;
-      t0.c = w[0];
+      t0.c = ldc(w);
 #pragma unroll
-      for (int i = 0; i < W; i++) t0.m.w[i] = w[1 + i];
+      for (int i = 0; i < W; i++) t0.m.w[i] = ldc(w + 1 + i);
       t1.c = 0; t1.m = m_zero<W>();
       if (n == 2) {
-        t1.c = w[1 + W];
+        t1.c = ldc(w + 1 + W);
 #pragma unroll
-        for (int i = 0; i < W; i++) t1.m.w[i] = w[2 + W + i];
+        for (int i = 0; i < W; i++) t1.m.w[i] = ldc(w + 2 + W + i);
       }
       if (!bin_add_poly<W>(e, p, L, nG, nP, t0, t1, sugar, status)) return false;
       w += (size_t)n * (1 + W);
@@ -308,7 +308,7 @@ __device__ __forceinline__ void binom_body(const BbxParams& p, char* smem) {
     r0.c = 0; r1.c = 0; r0.m = m_zero<W>(); r1.m = m_zero<W>();
     int nsteps_red = 0, rsug = 0;
     bool overflow = false;
-    while (h0.c != 0) {
+    while (uni((int)h0.c) != 0) {
       const int hn = h1.c ? 2 : 1;
       int found = -1;
       Mono<W> lmg = m_zero<W>();
@@ -357,7 +357,7 @@ __device__ __forceinline__ void binom_body(const BbxParams& p, char* smem) {
 
     // ---- basis / pair-set update (buchberger.cpp:321-327) ---------------------------------------------
     const int nG_before = nG, nP_before = nP;
-    if (r0.c != 0) {
+    if (uni((int)r0.c) != 0) {
       if (!bin_add_poly<W>(e, p, L, nG, nP, r0, r1, rsug, &status)) break;
       bytes += 12 * (r1.c ? 2 : 1) + 8 * nG_before + 8 * (nP_before + nP);
     } else zero_red++;

@@ -42,6 +42,12 @@ __device__ __forceinline__ void wave_sync() {
 __device__ __forceinline__ uint64_t ballot64(bool p) { return __ballot(p); }
 __device__ __forceinline__ int prefix_of(uint64_t mask, int lane) { return __popcll(mask & ((1ull << lane) - 1ull)); }
 __device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
+// Load from memory that no kernel writes (the ideal queue: filled by the host between launches) through the constant
+// address space: with a wave-uniform address this is a scalar load, the value lives in an SGPR and everything derived
+// from it (loop bounds, branch conditions) stays on the scalar unit.
+typedef const __attribute__((address_space(4))) uint32_t* bbx_cptr32;
+__device__ __forceinline__ uint32_t ldc(const uint32_t* q) { return *(bbx_cptr32)(uintptr_t)q; }
+__device__ __forceinline__ int ldc(const int32_t* q) { return (int)*(bbx_cptr32)(uintptr_t)q; }
 __device__ __forceinline__ uint64_t wave_sum64(uint64_t v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
   return v;
@@ -501,7 +507,8 @@ __device__ bool wave_update(EnvT& e, const BbxLayout& L, int& nG, int& nP, const
       uint64_t mask = ballot64(keep);
       wave_sync();
       if (keep) e.pairs[w + prefix_of(mask, lane)] = pr;
-      w += __popcll(mask);
+      w = uni(w + __popcll(mask));       // pinned: the optimiser otherwise threads the count through the per-lane
+                                         // branch above and the uniformity analysis gives up on |P| (-> exec-masked code)
       wave_sync();
     }
     nP = w;
@@ -557,7 +564,7 @@ __device__ bool wave_update(EnvT& e, const BbxLayout& L, int& nG, int& nP, const
       const int cnt = __popcll(mask);
       if (nP + cnt > (int)L.maxP) { *status = BBX_ST_P_FULL; return false; }
       if (emit) e.pairs[nP + prefix_of(mask, lane)] = (uint32_t)i | ((uint32_t)m << 16);  // (92) ascending i
-      nP += cnt;
+      nP = uni(nP + cnt);
     }
   } else {
     for (int base = 0; base < m; base += WAVE) {
@@ -568,7 +575,7 @@ __device__ bool wave_update(EnvT& e, const BbxLayout& L, int& nG, int& nP, const
       int cnt = __popcll(mask);
       if (nP + cnt > (int)L.maxP) { *status = BBX_ST_P_FULL; return false; }
       if (emit) e.pairs[nP + prefix_of(mask, lane)] = (uint32_t)i | ((uint32_t)m << 16);
-      nP += cnt;
+      nP = uni(nP + cnt);
     }
   }
   wave_sync();
