@@ -489,6 +489,26 @@ def test_reduced_groebner_basis_known_answers():
     assert env.reduced_basis(0) == Gref
 
 
+def test_cyclic7_degree_agent_to_completion():
+    """ONE cyclic-7 environment driven by the Degree agent until the pair set is empty — 5 882
+    steps with polynomials of up to ~1 800 terms through the cooperative wide kernel — against the numbers recorded from
+    the compiled reference: zero / non-zero reductions 4 592 / 1 290, 1 657 785 polynomial additions, a reduced
+    Groebner basis of 209 elements (hash of every coefficient and exponent), and value('degree', 0.99) of the reset
+    state = -13142.770134825347 (the same rollout in value mode on a device clone), all bit-exact."""
+    from deepgroebner_amd import VecLeadMonomialsEnv
+    from oracle.trace import flat_ideal
+    w = meta()["buchberger"]["cyclic-7|degree"]
+    env = VecLeadMonomialsEnv("cyclic-7", batch=1, k=1)
+    env.reset()
+    assert env.value(0, "degree", 0.99) == w["discounted_return"]
+    env.rollout("degree", 1 << 30, auto_reset=False)
+    st = env.stats()[0]
+    assert [st[3], st[0] - st[3], st[1]] == [w["zero_reductions"], w["nonzero_reductions"], w["polynomial_additions"]]
+    assert st[0] == 5882 and int(env.rows[0]) == 0
+    G = env.reduced_basis(0)
+    assert len(G) == w["basis_size"] == 209 and int(fnv64(flat_ideal(G))) == w["basis_hash"]
+
+
 def test_in_batch_clones_for_tree_search():
     """env.copy() per search node (mcts.py:89,96,147) as an in-batch clone: the clone continues exactly like its
     source, including the ideals it will draw after a reset, and then diverges under different actions."""
