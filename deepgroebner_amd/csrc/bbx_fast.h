@@ -68,6 +68,17 @@ __device__ __forceinline__ void f_shift_in(uint32_t& arr, uint32_t carry, int la
   arr = lane == 0 ? carry : sh;
 }
 
+// Kernel arguments that only cold code needs (reset, the write-back behind the step loop, error paths) are re-read from
+// the kernarg segment where they are used, through a pointer the optimiser cannot see through: otherwise every field is
+// loaded once at kernel entry and stays live across the whole step loop, and the scalar register file (the loop keeps
+// its polynomial state there) spills to VGPR lanes.  Constant address space + uniform address = s_load.
+typedef const __attribute__((address_space(4))) BbxFastParams* FColdParams;
+__device__ __forceinline__ FColdParams f_cold_params() {
+  FColdParams q = (FColdParams)__builtin_amdgcn_kernarg_segment_ptr();   // the kernels take one by-value struct: offset 0
+  asm volatile("" : "+s"(q));
+  return q;
+}
+
 struct FastState {                 // reducer-order arrays, lane l <-> reducers l (A) and l + 64 (B)
   M2 slmA, slmB, stmA, stmB;
   uint2 sinA, sinB;                // .x = tc | (1/lc) << 16 ; .y = sugar | basis index << 16
@@ -104,8 +115,8 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
 
   // HBM record arrays (binomial layout: every array 16-B aligned, capacities hbmG / maxP); the addresses are only
   // formed where the record is read or written (launch start / end), never kept live across the step loop
-#define F_HBM_PTRS \
-  const uint32_t HG = p.hbmG; char* grec_ = p.recs + (size_t)env * p.rec_bytes; \
+#define F_HBM_PTRS(PP) \
+  const uint32_t HG = (PP)->hbmG; char* grec_ = (PP)->recs + (size_t)env * (PP)->rec_bytes; \
   M2* g_lm = (M2*)(grec_ + 128);            M2* g_tm = (M2*)(grec_ + 128 + 8 * HG); \
   M2* g_slm = (M2*)(grec_ + 128 + 16 * HG); M2* g_stm = (M2*)(grec_ + 128 + 24 * HG); \
   uint2* g_gi = (uint2*)(grec_ + 128 + 40 * HG); uint2* g_si = (uint2*)(grec_ + 128 + 48 * HG); \
@@ -123,7 +134,7 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
   if (status == BBX_ST_OK) {
     if (nG > limG || nP > limP) status = BBX_ST_SPILL;
     else {
-      F_HBM_PTRS
+      F_HBM_PTRS(&p)
       if (lane < nG) { S.slmA = g_slm[lane]; S.stmA = g_stm[lane]; S.sinA = g_si[lane]; lm[lane] = g_lm[lane]; tm[lane] = g_tm[lane]; gi[lane] = g_gi[lane]; }
       if (lane + 64 < nG) { S.slmB = g_slm[lane + 64]; S.stmB = g_stm[lane + 64]; S.sinB = g_si[lane + 64];
                             lm[lane + 64] = g_lm[lane + 64]; tm[lane + 64] = g_tm[lane + 64]; gi[lane + 64] = g_gi[lane + 64]; }
@@ -135,9 +146,13 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
 
   // the random agent's hashes for 64 consecutive steps at a time, one per lane (recomputed every 64 steps)
   uint32_t hv = bbx_agent_hash32(agent_seed, (uint32_t)((t_agent & ~63) + lane));
-  int steps_done = 0, adds = 0, episodes = 0, zero_red = 0;
+  // statistics that nothing in the loop branches on live in vector registers (lane-uniform values behind an opaque
+  // zero): their updates cost the vector unit, which has slack, instead of scalar instructions and SGPRs, which do not
+  int vzero; asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
+  int adds = vzero, episodes = vzero, zero_red = vzero;
+  int trace_pos = rollout_pos;                                        // TRACE only
   long long bytes_total = 0;
-  int last_nred = -1;                                  // reward of the last step, kept as its integer reduction count
+  int last_nred = vzero - 1;                           // reward of the last step, kept as its integer reduction count
   const bool tracing = TRACE && p.trace != nullptr;
   const int n = p.nvars, kk = p.k;
   const int per_row = 2 * kk;
@@ -300,23 +315,25 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
     if (status != BBX_ST_OK) break;
     if (need_reset) {                                      // BuchbergerEnv::reset from the next queued ideal(s)
       bool ok = true;
+      const FColdParams cq = f_cold_params();
+      const uint32_t q_slot_words = cq->q_slot_words, q_fixed = cq->q_fixed;
       for (;;) {
         const uint32_t* slot;
-        if (p.q_fixed) slot = p.qwords;
+        if (q_fixed) slot = cq->qwords;
         else {
-          const int tail = uni(p.qtail[env]);            // (a plain load would count as divergent and drag nG / nP into VGPRs)
+          const int tail = uni(cq->qtail[env]);          // (a plain load would count as divergent and drag nG / nP into VGPRs)
           if (q_head >= tail) { status = BBX_ST_STARVED; ok = false; break; }
-          slot = p.qwords + (size_t)env * p.q_env_stride + (size_t)(q_head % (int)p.q_nslots) * p.q_slot_words;
+          slot = cq->qwords + (size_t)env * cq->q_env_stride + (size_t)(q_head % (int)cq->q_nslots) * q_slot_words;
         }
         nG = 0; nP = 0;
         S.slmA.w[0] = S.slmA.w[1] = S.slmB.w[0] = S.slmB.w[1] = FSENT;
         // the whole ideal (<= 128 words for up to 15 binomials) comes in with two coalesced loads, one word per
         // lane; fields are then picked with v_readlane instead of a chain of dependent scalar-address loads
-        const bool small_slot = p.q_slot_words <= 128;
+        const bool small_slot = q_slot_words <= 128;
         uint32_t qA = 0, qB = 0;
         if (small_slot) {
-          if (lane < (int)p.q_slot_words) qA = slot[lane];
-          if (lane + 64 < (int)p.q_slot_words) qB = slot[lane + 64];
+          if (lane < (int)q_slot_words) qA = slot[lane];
+          if (lane + 64 < (int)q_slot_words) qB = slot[lane + 64];
         }
         auto qword = [&](int j) -> uint32_t {
           if (!small_slot) return (uint32_t)uni((int)slot[j]);
@@ -335,8 +352,8 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
           at += 2 + nt * 3;
         }
         if (!ok) break;
-        if (!p.q_fixed) q_head++;
-        if (nP != 0 || p.q_fixed) break;                   // buchberger.cpp:313-314: redraw while the pair set is empty
+        if (!q_fixed) q_head++;
+        if (nP != 0 || q_fixed) break;                   // buchberger.cpp:313-314: redraw while the pair set is empty
       }
       if (!ok) { if (status == BBX_ST_SPILL) { nG = 0; nP = 0; } break; }
       need_reset = 0;
@@ -348,7 +365,7 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
     // ---- choose the pair -----------------------------------------------------------------------------------------
     int action;
     if (p.agent == BBX_AGENT_HASH) action = (int)(((uint64_t)f_readlane(hv, t_agent & 63) * (uint32_t)nP) >> 32);   // bbx_agent_action32
-    else if (p.agent == BBX_AGENT_EXTERNAL) action = uni(p.actions[env]);
+    else if (p.agent == BBX_AGENT_EXTERNAL) action = uni(f_cold_params()->actions[env]);
     else if (p.agent == BBX_AGENT_FIRST) action = 0;
     else {                                                 // degree: first row of minimal deg lcm (buchberger.cpp:171-176)
       uint32_t best = 0xFFFFFFFFu;
@@ -467,8 +484,8 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
     }
     FSTAMP(4);                                             // 4: add_poly (pair update, insert)
     if (ACCT) { bytes += nP * obs_row_bytes; bytes_total += bytes; }
-    last_nred = nred;
-    adds += 1 + nred; t_agent++; steps_done++;
+    last_nred = vzero + nred;
+    adds += 1 + nred; t_agent++;
     if ((t_agent & 63) == 0) hv = bbx_agent_hash32(agent_seed, (uint32_t)(t_agent + lane));
     const bool done = nP == 0;
 
@@ -494,40 +511,45 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
         nh = wave_sum64(nh);
       }
       if (lane == 0) {
-        BbxTraceRec& tr = p.trace[(size_t)env * p.trace_stride + rollout_pos];
+        BbxTraceRec& tr = p.trace[(size_t)env * p.trace_stride + trace_pos];
         tr.action = action; tr.nP = nP; tr.nG = nG; tr.done = done ? 1 : 0;
         tr.reward = p.rewards_mode == BBX_REW_ADDITIONS ? (-1.0 - (double)nred) : -1.0;
         tr.obs_hash = oh; tr.pairs_hash = ph; tr.newpoly_hash = nh;
       }
     }
-    budget--; rollout_pos++;
+    budget--; if (TRACE) trace_pos++;
     done_last = done ? 1 : 0;
     if (done) { episodes++; if (p.auto_reset) need_reset = 1; }
     FSTAMP(5);                                             // 5: observation + bookkeeping
   }
-  if (PROF && p.prof && lane == 0) for (int i = 0; i < 8; i++) p.prof[(size_t)env * 8 + i] = prof_sum[i];
+  const FColdParams cz = f_cold_params();
+  if (PROF && cz->prof && lane == 0) for (int i = 0; i < 8; i++) cz->prof[(size_t)env * 8 + i] = prof_sum[i];
 
   const bool handoff = status == BBX_ST_SPILL;
   if (p.obs && status == BBX_ST_OK) write_obs(true, false);
   if (staged_in) {                                                   // write the live prefixes back to the HBM record
     wave_sync();
-    F_HBM_PTRS
+    F_HBM_PTRS(cz)
     if (lane < nG) { g_slm[lane] = S.slmA; g_stm[lane] = S.stmA; g_si[lane] = S.sinA; g_lm[lane] = lm[lane]; g_tm[lane] = tm[lane]; g_gi[lane] = gi[lane]; }
     if (lane + 64 < nG) { g_slm[lane + 64] = S.slmB; g_stm[lane + 64] = S.stmB; g_si[lane + 64] = S.sinB;
                           g_lm[lane + 64] = lm[lane + 64]; g_tm[lane + 64] = tm[lane + 64]; g_gi[lane + 64] = gi[lane + 64]; }
     for (int i = lane; i < nP; i += WAVE) g_pr[i] = pairs[i];
   }
   if (lane == 0) {
-    BbxHdr* h = (BbxHdr*)(p.recs + (size_t)env * p.rec_bytes);
+    BbxHdr* h = (BbxHdr*)(cz->recs + (size_t)env * cz->rec_bytes);
+    // steps done = the rollout budget this launch started with minus what is left (the header still holds the old one)
+    const int steps_done = (cz->set_budget ? cz->nsteps : h->budget) - budget;
+    rollout_pos = (cz->set_budget ? 0 : h->rollout_pos) + steps_done;
     h->nG = nG; h->nP = nP; h->arena_used = 0; h->status = status; h->need_reset = need_reset;
     h->q_head = q_head; h->t = t_agent; h->total_steps += steps_done; h->total_additions += adds;
     h->episodes += episodes; h->zero_reductions += zero_red; h->steps_done = steps_done;
     h->budget = budget; h->rollout_pos = rollout_pos; h->done_last = done_last; h->alg_bytes += bytes_total;
     if (!handoff) {
-      if (p.rewards && (steps_done > 0 || p.pass == 0))
-        p.rewards[env] = last_nred < 0 ? 0.0 : (p.rewards_mode == BBX_REW_ADDITIONS ? (-1.0 - (double)last_nred) : -1.0);
-      if (p.dones) p.dones[env] = (uint8_t)((done_last || (nP == 0 && !need_reset)) ? 1 : 0);
-      if (p.rows) p.rows[env] = nP;
+      double* rw = cz->rewards; uint8_t* dn = cz->dones; int32_t* rws = cz->rows;
+      if (rw && (steps_done > 0 || cz->pass == 0))
+        rw[env] = last_nred < 0 ? 0.0 : (cz->rewards_mode == BBX_REW_ADDITIONS ? (-1.0 - (double)last_nred) : -1.0);
+      if (dn) dn[env] = (uint8_t)((done_last || (nP == 0 && !need_reset)) ? 1 : 0);
+      if (rws) rws[env] = nP;
     }
   }
 }
