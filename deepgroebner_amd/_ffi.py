@@ -56,6 +56,7 @@ SIGNATURES = {
     "bbx_reset": (C.c_int, [_vp, _vp, _vp]),
     "bbx_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "bbx_step_autoreset": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "bbx_step_obs": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     "bbx_rollout": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
     "bbx_obs": (C.c_int, [_vp, _vp, C.c_int, C.c_int]),
     "bbx_cols": (C.c_int, [_vp]),

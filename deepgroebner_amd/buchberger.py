@@ -113,17 +113,40 @@ class VecLeadMonomialsEnv:
         s = np.ascontiguousarray(np.broadcast_to(np.asarray(seeds, dtype=np.int64), (self.batch,)))
         _ffi.check(_ffi.lib().bbx_seed_strategy(self._h, _ffi.ptr(s)))
 
+    def _step_obs(self, actions, auto_reset):
+        """One library call: the step (actions None: none) and the ragged observation block -> (flat [sum rows, cols],
+        offsets [batch + 1]), fresh copies of the handle's pinned buffers."""
+        obs_p, off_p = C.POINTER(C.c_int32)(), C.POINTER(C.c_int32)()
+        _ffi.check(_ffi.lib().bbx_step_obs(self._h, _ffi.ptr(actions), int(auto_reset), _ffi.ptr(self._rewards),
+                                           _ffi.ptr(self._dones), _ffi.ptr(self.rows), C.byref(obs_p), C.byref(off_p)))
+        off = np.ctypeslib.as_array(off_p, shape=(self.batch + 1,)).copy()
+        total = int(off[-1])
+        if total == 0:
+            return np.zeros((0, self.cols), dtype=np.int32), off
+        flat = np.ctypeslib.as_array(obs_p, shape=(total * self.cols,)).copy().reshape(total, self.cols)
+        return flat, off
+
+    def _as_list(self, flat, off):
+        return [flat] if self.batch == 1 else np.split(flat, off[1:-1])
+
     def reset(self, mask=None):
         m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
         _ffi.check(_ffi.lib().bbx_reset(self._h, _ffi.ptr(m), _ffi.ptr(self.rows)))
-        return self.observations()
+        return self._as_list(*self._step_obs(None, False))
 
     def step(self, actions, auto_reset=False):
-        """auto_reset=True: finished environments start their next episode inside the same call (VecEnv style)."""
+        """auto_reset=True: finished environments start their next episode inside the same call (VecEnv style).
+        Returns (list of per-environment int32 [rows_e, cols] matrices, rewards, dones, infos)."""
         a = np.ascontiguousarray(np.broadcast_to(np.asarray(actions, dtype=np.int32), (self.batch,)))
-        fn = _ffi.lib().bbx_step_autoreset if auto_reset else _ffi.lib().bbx_step
-        _ffi.check(fn(self._h, _ffi.ptr(a), _ffi.ptr(self._rewards), _ffi.ptr(self._dones), _ffi.ptr(self.rows)))
-        return self.observations(), self._rewards.copy(), self._dones.astype(bool), [{} for _ in range(self.batch)]
+        flat, off = self._step_obs(a, auto_reset)
+        return self._as_list(flat, off), self._rewards.copy(), self._dones.astype(bool), [{} for _ in range(self.batch)]
+
+    def step_ragged(self, actions, auto_reset=False):
+        """step() for vectorised consumers: (flat int32 [sum rows, cols], offsets int32 [batch + 1], rewards, dones);
+        environment e owns flat[offsets[e]:offsets[e + 1]]."""
+        a = np.ascontiguousarray(np.broadcast_to(np.asarray(actions, dtype=np.int32), (self.batch,)))
+        flat, off = self._step_obs(a, auto_reset)
+        return flat, off, self._rewards.copy(), self._dones.astype(bool)
 
     def rollout(self, agent="random", nsteps=1, auto_reset=True):
         _ffi.check(_ffi.lib().bbx_rollout(self._h, _ffi.AGENTS[agent], int(nsteps), int(auto_reset),

@@ -21,6 +21,8 @@ extern "C" int bbx_launch_clone(const char* src_recs, char* dst_recs, const BbxL
                                 const uint32_t* seeds, int keep_counters, hipStream_t stream);
 extern "C" int bbx_launch_gather_lite(const char* recs, uint32_t rec_bytes, int B, void* out, hipStream_t stream);
 extern "C" int bbx_launch_gather_hdr(const char* recs, uint32_t rec_bytes, int B, BbxHdr* out, hipStream_t stream);
+extern "C" int bbx_launch_scatter_queue(const uint32_t* stage, int n, uint32_t ring_words, uint32_t* q, int32_t* tail, hipStream_t stream);
+extern "C" int bbx_launch_obs_pack(const int32_t* padded, int cap, int cols, const int32_t* rows, int B, int32_t* off, int32_t* packed, hipStream_t stream);
 extern "C" int bbx_launch_init(char* recs, uint32_t rec_bytes, int B, const uint32_t* agent_seeds, hipStream_t stream);
 extern "C" int bbx_launch_mark_reset(char* recs, uint32_t rec_bytes, int B, const uint8_t* mask, hipStream_t stream);
 
@@ -96,7 +98,14 @@ struct bbx_batch {
   char* d_recs = nullptr;
   uint32_t* d_q = nullptr;
   int32_t* d_tail = nullptr;
-  char* d_out = nullptr; double* d_rewards = nullptr; int32_t* d_rows = nullptr; uint8_t* d_dones = nullptr;
+  // one device block polled after every launch: lite[B][4] {status, q_head, budget, |P|} | rewards f64[B] | rows i32[B] |
+  // dones u8[B]; the kernels write it themselves, the host fetches it with ONE copy into pinned memory
+  char* d_out = nullptr; int32_t* d_lite = nullptr; double* d_rewards = nullptr; int32_t* d_rows = nullptr; uint8_t* d_dones = nullptr;
+  char* h_io = nullptr; size_t io_bytes = 0;      // pinned mirror of d_out
+  int32_t* h_act = nullptr;                       // pinned staging of host actions
+  // ragged observations (bbx_step_obs): device offsets [B+1] + packed rows, and their pinned mirror handed to the caller
+  int32_t* d_obs_off = nullptr; int32_t* d_obs_packed = nullptr; int32_t* h_obs = nullptr; size_t obs_packed_cap = 0;
+  uint32_t* h_stage = nullptr; uint32_t* d_stage = nullptr; size_t stage_words = 0;   // queue refill staging (pinned / device)
   int32_t* d_actions = nullptr; uint8_t* d_mask = nullptr; uint32_t* d_seeds = nullptr;
   int32_t* d_obs = nullptr; size_t obs_rows_cap = 0;
   BbxTraceRec* d_trace = nullptr; int trace_cap = 0;
@@ -159,31 +168,49 @@ int pack_ideal(const bbx_batch* b, bbx::HIdeal F, uint32_t* slot) {
   return BBX_OK;
 }
 
-int upload_queue(bbx_batch* b) {
+int upload_queue(bbx_batch* b, hipStream_t stream = 0) {
   if (!b->q_dirty) return BBX_OK;
   const size_t stride = b->fixed ? b->h_q.size() : (size_t)b->nslots * b->slot_words;
-  if (b->fixed || b->q_dirty_env.empty()) {
+  int nd = 0;
+  if (!b->fixed && !b->q_dirty_env.empty()) for (int e = 0; e < b->B; e++) nd += b->q_dirty_env[e] ? 1 : 0;
+  if (b->fixed || b->q_dirty_env.empty() || (size_t)nd * 4 > (size_t)b->B) {
+    // everything (first fill, prefetch): plain copies
     HIPCHK(hipMemcpy(b->d_q, b->h_q.data(), b->h_q.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-  } else {
-    // upload runs of consecutive environments whose rings changed
-    for (int e = 0; e < b->B;) {
-      if (!b->q_dirty_env[e]) { e++; continue; }
-      int f = e;
-      while (f < b->B && b->q_dirty_env[f]) f++;
-      HIPCHK(hipMemcpy(b->d_q + (size_t)e * stride, b->h_q.data() + (size_t)e * stride, (size_t)(f - e) * stride * sizeof(uint32_t), hipMemcpyHostToDevice));
-      e = f;
+    HIPCHK(hipMemcpy(b->d_tail, b->h_tail.data(), b->h_tail.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  } else if (nd > 0) {
+    // a few rings (the steady state of host-driven stepping): stage them contiguously in pinned memory, ONE copy, and
+    // let a small kernel put them in place — instead of one synchronous copy per run of refilled environments
+    const size_t need = 2 * (size_t)nd + (size_t)nd * stride;
+    if (need > b->stage_words) {
+      if (b->h_stage) (void)hipHostFree(b->h_stage);
+      if (b->d_stage) (void)hipFree(b->d_stage);
+      b->h_stage = nullptr; b->d_stage = nullptr; b->stage_words = 0;
+      const size_t cap = need * 2;
+      HIPCHK(hipHostMalloc((void**)&b->h_stage, cap * sizeof(uint32_t), hipHostMallocDefault));
+      HIPCHK(hipMalloc((void**)&b->d_stage, cap * sizeof(uint32_t)));
+      b->stage_words = cap;
     }
-    std::fill(b->q_dirty_env.begin(), b->q_dirty_env.end(), 0);
+    int i = 0;
+    for (int e = 0; e < b->B; e++) {
+      if (!b->q_dirty_env[e]) continue;
+      b->h_stage[i] = (uint32_t)e;
+      b->h_stage[nd + i] = (uint32_t)b->h_tail[e];
+      memcpy(b->h_stage + 2 * (size_t)nd + (size_t)i * stride, b->h_q.data() + (size_t)e * stride, stride * sizeof(uint32_t));
+      i++;
+    }
+    HIPCHK(hipMemcpy(b->d_stage, b->h_stage, need * sizeof(uint32_t), hipMemcpyHostToDevice));   // pinned: returns once copied
+    int lrc = bbx_launch_scatter_queue(b->d_stage, nd, (uint32_t)stride, b->d_q, b->d_tail, stream);
+    if (lrc) return fail(BBX_E_DEVICE, "queue scatter launch failed: %s", hipGetErrorString((hipError_t)lrc));
   }
-  HIPCHK(hipMemcpy(b->d_tail, b->h_tail.data(), b->h_tail.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  if (!b->q_dirty_env.empty()) std::fill(b->q_dirty_env.begin(), b->q_dirty_env.end(), 0);
   b->q_dirty = false;
   return BBX_OK;
 }
 
 // refill the ring of every environment that holds fewer than min_avail pre-generated ideals
 // (launches pass 1: only rings that are empty; bbx_prefetch passes the ring size: top everything up)
-int fill_queues(bbx_batch* b, int min_avail = 1) {
-  if (b->fixed) return upload_queue(b);
+int fill_queues(bbx_batch* b, int min_avail = 1, hipStream_t stream = 0) {
+  if (b->fixed) return upload_queue(b, stream);
   std::string err;
   bbx::HIdeal F;
   if (b->q_dirty_env.size() != (size_t)b->B) b->q_dirty_env.assign(b->B, b->q_dirty ? 1 : 0);
@@ -199,7 +226,7 @@ int fill_queues(bbx_batch* b, int min_avail = 1) {
       b->q_dirty_env[e] = 1;
     }
   }
-  return upload_queue(b);
+  return upload_queue(b, stream);
 }
 
 int read_headers(bbx_batch* b, hipStream_t stream = 0) {
@@ -234,6 +261,7 @@ void fill_params(bbx_batch* b, BbxParams* p) {
   p->trace = b->d_trace; p->trace_stride = b->trace_cap;
   p->inv_table = b->d_inv;
   p->accounting = b->accounting ? 1 : 0;
+  p->lite = b->d_lite;
 }
 
 // enqueue the kernels of one logical launch: the LDS-staged pass (when the class allows) followed by the
@@ -245,7 +273,10 @@ int enqueue(bbx_batch* b, const BbxParams& p0, bool resume, hipStream_t stream) 
   else if (b->wide) kinds[nk++] = 4;
   else {   // the hand-tuned kernel knows the external / random / degree / first agents; the others take the class kernel
     if (b->staged) kinds[nk++] = (b->fast && p.agent <= BBX_AGENT_FIRST) ? 3 : 1;
-    kinds[nk++] = 0;
+    // the HBM-resident pass behind the LDS-resident one serves environments that outgrow the LDS class inside a
+    // rollout; a single host-driven step does without it: an environment that spills reports BBX_ST_SPILL and
+    // finish() continues it (one launch less on the latency path)
+    if (!b->staged || resume || p.nsteps > 1) kinds[nk++] = 0;
   }
   for (int i = 0; i < nk; i++) {
     if (resume) { p.set_budget = 0; p.pass = 1; }
@@ -274,12 +305,26 @@ int collect_events(bbx_batch* b) {
   return BBX_OK;
 }
 
+int alloc_io(bbx_batch* b, int batch) {
+  b->io_bytes = (size_t)batch * 29;
+  HIPCHK(hipMalloc((void**)&b->d_out, b->io_bytes));
+  HIPCHK(hipMemset(b->d_out, 0, b->io_bytes));
+  b->d_lite = (int32_t*)b->d_out;
+  b->d_rewards = (double*)(b->d_out + (size_t)batch * 16);
+  b->d_rows = (int32_t*)(b->d_out + (size_t)batch * 24);
+  b->d_dones = (uint8_t*)(b->d_out + (size_t)batch * 28);
+  HIPCHK(hipHostMalloc((void**)&b->h_io, b->io_bytes, hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void**)&b->h_act, (size_t)batch * sizeof(int32_t), hipHostMallocDefault));
+  memset(b->h_io, 0, b->io_bytes);
+  return BBX_OK;
+}
+
+// fetch the block the kernels of the last launch left behind (status words and the host-API outputs) in one copy
 int read_lite(bbx_batch* b, hipStream_t stream) {
   b->h_lite.resize((size_t)b->B * 4);
-  int lrc = bbx_launch_gather_lite(b->d_recs, b->L.rec_bytes, b->B, b->d_hdr, stream);   // d_hdr doubles as the compact buffer
-  if (lrc) return fail(BBX_E_DEVICE, "gather launch failed: %s", hipGetErrorString((hipError_t)lrc));
-  HIPCHK(hipMemcpyAsync(b->h_lite.data(), b->d_hdr, (size_t)b->B * 16, hipMemcpyDeviceToHost, stream));
+  HIPCHK(hipMemcpyAsync(b->h_io, b->d_out, b->io_bytes, hipMemcpyDeviceToHost, stream));
   HIPCHK(hipStreamSynchronize(stream));
+  memcpy(b->h_lite.data(), b->h_io, (size_t)b->B * 16);
   for (int e = 0; e < b->B; e++) b->h_head[e] = b->h_lite[(size_t)e * 4 + 1];
   return BBX_OK;
 }
@@ -305,7 +350,7 @@ int finish(bbx_batch* b, hipStream_t stream) {
     }
     if (!again) break;
     if (round > 100000) return fail(BBX_E_GENERATOR, "ideal queue starvation did not resolve");
-    rc = fill_queues(b);
+    rc = fill_queues(b, 1, stream);
     if (rc) return rc;
     rc = enqueue(b, b->last, true, stream);   // continue the rollout where each environment stopped
     if (rc) return rc;
@@ -315,7 +360,7 @@ int finish(bbx_batch* b, hipStream_t stream) {
 }
 
 int launch(bbx_batch* b, BbxParams& p, hipStream_t stream) {
-  int rc = fill_queues(b);
+  int rc = fill_queues(b, 1, stream);
   if (rc) return rc;
   b->last = p;
   b->last_stream = stream;
@@ -323,12 +368,11 @@ int launch(bbx_batch* b, BbxParams& p, hipStream_t stream) {
   return enqueue(b, p, false, stream);
 }
 
+// the outputs of a host-API launch: already on the host (finish() fetched the whole block)
 int copy_out(bbx_batch* b, double* rewards, uint8_t* dones, int32_t* rows) {
-  b->h_out.resize((size_t)b->B * 13);
-  HIPCHK(hipMemcpy(b->h_out.data(), b->d_out, (size_t)b->B * 13, hipMemcpyDeviceToHost));
-  if (rewards) memcpy(rewards, b->h_out.data(), (size_t)b->B * 8);
-  if (rows) memcpy(rows, b->h_out.data() + (size_t)b->B * 8, (size_t)b->B * 4);
-  if (dones) memcpy(dones, b->h_out.data() + (size_t)b->B * 12, (size_t)b->B);
+  if (rewards) memcpy(rewards, b->h_io + (size_t)b->B * 16, (size_t)b->B * 8);
+  if (rows) memcpy(rows, b->h_io + (size_t)b->B * 24, (size_t)b->B * 4);
+  if (dones) memcpy(dones, b->h_io + (size_t)b->B * 28, (size_t)b->B);
   return BBX_OK;
 }
 
@@ -424,8 +468,7 @@ int create_common(std::unique_ptr<bbx::IdealGen> proto, int nvars_obs, int elimi
   HIPCHK(hipMalloc((void**)&b->d_recs, (size_t)batch * b->L.rec_bytes));
   HIPCHK(hipMalloc((void**)&b->d_q, qwords * sizeof(uint32_t)));
   HIPCHK(hipMalloc((void**)&b->d_tail, (size_t)batch * sizeof(int32_t)));
-  HIPCHK(hipMalloc((void**)&b->d_out, (size_t)batch * 13));
-  b->d_rewards = (double*)b->d_out; b->d_rows = (int32_t*)(b->d_out + (size_t)batch * 8); b->d_dones = (uint8_t*)(b->d_out + (size_t)batch * 12);
+  { int rc_ = alloc_io(b.get(), batch); if (rc_) return rc_; }
   HIPCHK(hipMalloc((void**)&b->d_actions, (size_t)batch * sizeof(int32_t)));
   HIPCHK(hipMalloc((void**)&b->d_mask, (size_t)batch));
   HIPCHK(hipMalloc((void**)&b->d_seeds, (size_t)batch * sizeof(uint32_t)));
@@ -515,6 +558,13 @@ void bbx_destroy(bbx_batch* b) {
   void* bufs[] = {b->d_recs, b->d_q, b->d_tail, b->d_out, b->d_actions, b->d_mask, b->d_seeds, b->d_obs, b->d_trace, b->d_hdr, b->d_inv,
                   b->d_vrecs, b->d_vhdr, b->d_vsrc, b->d_vseeds, b->d_vvals};
   for (void* p : bufs) (void)hipFree(p);
+  if (b->h_io) (void)hipHostFree(b->h_io);
+  if (b->h_act) (void)hipHostFree(b->h_act);
+  if (b->h_stage) (void)hipHostFree(b->h_stage);
+  if (b->d_stage) (void)hipFree(b->d_stage);
+  if (b->h_obs) (void)hipHostFree(b->h_obs);
+  if (b->d_obs_off) (void)hipFree(b->d_obs_off);
+  if (b->d_obs_packed) (void)hipFree(b->d_obs_packed);
   delete b;
 }
 
@@ -534,8 +584,7 @@ int bbx_copy(const bbx_batch* s, bbx_batch** out) {
   HIPCHK(hipMemcpy(b->d_recs, s->d_recs, (size_t)batch * b->L.rec_bytes, hipMemcpyDeviceToDevice));
   HIPCHK(hipMalloc((void**)&b->d_q, b->h_q.size() * sizeof(uint32_t)));
   HIPCHK(hipMalloc((void**)&b->d_tail, (size_t)batch * sizeof(int32_t)));
-  HIPCHK(hipMalloc((void**)&b->d_out, (size_t)batch * 13));
-  b->d_rewards = (double*)b->d_out; b->d_rows = (int32_t*)(b->d_out + (size_t)batch * 8); b->d_dones = (uint8_t*)(b->d_out + (size_t)batch * 12);
+  { int rc_ = alloc_io(b.get(), batch); if (rc_) return rc_; }
   HIPCHK(hipMalloc((void**)&b->d_actions, (size_t)batch * sizeof(int32_t)));
   HIPCHK(hipMalloc((void**)&b->d_mask, (size_t)batch));
   HIPCHK(hipMalloc((void**)&b->d_seeds, (size_t)batch * sizeof(uint32_t)));
@@ -643,7 +692,8 @@ int bbx_reset(bbx_batch* b, const uint8_t* mask, int32_t* rows) {
 static int step_host(bbx_batch* b, const int32_t* actions, double* rewards, uint8_t* dones, int32_t* rows, int auto_reset) {
   if (!b || !actions) return fail(BBX_E_ARG, "null argument");
   HIPCHK(hipSetDevice(b->device));
-  HIPCHK(hipMemcpy(b->d_actions, actions, (size_t)b->B * sizeof(int32_t), hipMemcpyHostToDevice));
+  memcpy(b->h_act, actions, (size_t)b->B * sizeof(int32_t));
+  HIPCHK(hipMemcpyAsync(b->d_actions, b->h_act, (size_t)b->B * sizeof(int32_t), hipMemcpyHostToDevice, 0));
   BbxParams p; fill_params(b, &p);
   p.nsteps = 1; p.set_budget = 1; p.agent = BBX_AGENT_EXTERNAL; p.auto_reset = auto_reset; p.actions = b->d_actions;
   p.rewards = b->d_rewards; p.dones = b->d_dones; p.rows = b->d_rows;
@@ -659,6 +709,78 @@ int bbx_step(bbx_batch* b, const int32_t* actions, double* rewards, uint8_t* don
 }
 int bbx_step_autoreset(bbx_batch* b, const int32_t* actions, double* rewards, uint8_t* dones, int32_t* rows) {
   return step_host(b, actions, rewards, dones, rows, 1);
+}
+
+// (re)size the padded device observation block
+static int ensure_obs_block(bbx_batch* b, int rows_cap) {
+  if (b->obs_rows_cap >= (size_t)rows_cap) return BBX_OK;
+  const size_t cols = (size_t)2 * b->nvars * b->k;
+  if (b->d_obs) HIPCHK(hipFree(b->d_obs));
+  b->d_obs = nullptr; b->obs_rows_cap = 0;
+  HIPCHK(hipMalloc((void**)&b->d_obs, (size_t)b->B * rows_cap * cols * sizeof(int32_t)));
+  b->obs_rows_cap = rows_cap;
+  return BBX_OK;
+}
+
+int bbx_step_obs(bbx_batch* b, const int32_t* actions, int auto_reset, double* rewards, uint8_t* dones, int32_t* rows,
+                 const int32_t** obs, const int32_t** offsets) {
+  if (!b || !obs || !offsets) return fail(BBX_E_ARG, "null argument");
+  HIPCHK(hipSetDevice(b->device));
+  const int cols = 2 * b->nvars * b->k;
+  int rc = ensure_obs_block(b, b->obs_rows_cap ? (int)b->obs_rows_cap : 128);
+  if (rc) return rc;
+  if (!b->d_obs_off) HIPCHK(hipMalloc((void**)&b->d_obs_off, ((size_t)b->B + 1) * sizeof(int32_t)));
+  BbxParams p; fill_params(b, &p);
+  p.set_budget = 1; p.agent = BBX_AGENT_EXTERNAL; p.auto_reset = auto_reset ? 1 : 0;
+  p.rewards = b->d_rewards; p.dones = b->d_dones; p.rows = b->d_rows;
+  if (actions) {
+    memcpy(b->h_act, actions, (size_t)b->B * sizeof(int32_t));
+    HIPCHK(hipMemcpyAsync(b->d_actions, b->h_act, (size_t)b->B * sizeof(int32_t), hipMemcpyHostToDevice, 0));
+    p.nsteps = 1; p.actions = b->d_actions;
+  } else p.nsteps = 0;                                      // observation of the current state only
+  for (int attempt = 0;; attempt++) {
+    p.obs = b->d_obs; p.obs_rows = (int)b->obs_rows_cap; p.obs_fill = 0; p.obs_every_step = 0;
+    if (attempt) { p.nsteps = 0; p.actions = nullptr; }     // the step is done: only rewrite the observation
+    rc = launch(b, p, 0);
+    if (rc) return rc;
+    rc = finish(b, 0);
+    if (rc) return rc;
+    if (!attempt) copy_out(b, rewards, dones, rows);
+    int maxr = 0; size_t total = 0;
+    for (int e = 0; e < b->B; e++) { const int r = b->h_lite[(size_t)e * 4 + 3]; maxr = r > maxr ? r : maxr; total += (size_t)r; }
+    if ((size_t)maxr > b->obs_rows_cap) {                   // some pair set outgrew the block: enlarge it and write again
+      int cap = (int)b->obs_rows_cap;
+      while (cap < maxr) cap *= 2;
+      rc = ensure_obs_block(b, cap);
+      if (rc) return rc;
+      continue;
+    }
+    const size_t need = (total ? total : 1) * (size_t)cols + (size_t)b->B + 1;
+    if (need > b->obs_packed_cap) {
+      if (b->d_obs_packed) (void)hipFree(b->d_obs_packed);
+      if (b->h_obs) (void)hipHostFree(b->h_obs);
+      b->d_obs_packed = nullptr; b->h_obs = nullptr; b->obs_packed_cap = 0;
+      HIPCHK(hipMalloc((void**)&b->d_obs_packed, need * 2 * sizeof(int32_t)));
+      HIPCHK(hipHostMalloc((void**)&b->h_obs, need * 2 * sizeof(int32_t), hipHostMallocDefault));
+      b->obs_packed_cap = need * 2;
+    }
+    // pinned layout: [B + 1 offsets (rows)] [total * cols values]; the offsets are a host-side prefix sum of the rows
+    // just fetched (the device computes the same ones for its pack kernel)
+    b->h_obs[0] = 0;
+    for (int e = 0; e < b->B; e++) b->h_obs[e + 1] = b->h_obs[e] + b->h_lite[(size_t)e * 4 + 3];
+    if (total) {
+      const int32_t* src = b->d_obs;                         // one environment: its padded block IS the ragged one
+      if (b->B > 1) {
+        int lrc = bbx_launch_obs_pack(b->d_obs, (int)b->obs_rows_cap, cols, b->d_rows, b->B, b->d_obs_off, b->d_obs_packed, 0);
+        if (lrc) return fail(BBX_E_DEVICE, "observation pack launch failed: %s", hipGetErrorString((hipError_t)lrc));
+        src = b->d_obs_packed;
+      }
+      HIPCHK(hipMemcpyAsync(b->h_obs + b->B + 1, src, total * cols * sizeof(int32_t), hipMemcpyDeviceToHost, 0));
+      HIPCHK(hipStreamSynchronize(0));
+    }
+    *offsets = b->h_obs; *obs = b->h_obs + b->B + 1;
+    return BBX_OK;
+  }
 }
 
 int bbx_rollout(bbx_batch* b, int agent, int nsteps, int auto_reset, double* rewards, uint8_t* dones, int32_t* rows) {
@@ -848,6 +970,7 @@ int value_rollouts(bbx_batch* b, const std::vector<int32_t>& src, int agent, con
   BbxParams p; fill_params(b, &p);
   p.recs = b->d_vrecs; p.B = n; p.nsteps = 1 << 30; p.set_budget = 1; p.agent = agent; p.auto_reset = 0;
   p.value_mode = 1; p.gamma = gamma; p.values = b->d_vvals; p.trace = nullptr; p.accounting = 0;
+  p.lite = nullptr;                                           // the clones are not the batch's environments
   lrc = bbx_launch_step(&p, 0, b->envs_per_block, 0);       // HBM-resident class kernel (no resets, no staging)
   if (lrc) return fail(BBX_E_DEVICE, "kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
   lrc = bbx_launch_gather_hdr(b->d_vrecs, b->L.rec_bytes, n, b->d_vhdr, 0);

@@ -401,6 +401,7 @@ __device__ __forceinline__ void binom_body(const BbxParams& p, char* smem) {
     h->total_additions = total_adds; h->episodes = episodes; h->zero_reductions = zero_red; h->steps_done = steps_done;
     h->budget = budget; h->rollout_pos = rollout_pos; h->done_last = done_last; h->alg_bytes = alg_bytes;
     h->vret = vret; h->vdisc = vdisc;
+    if (p.lite) *(int4*)(p.lite + 4 * (size_t)env) = make_int4(status, q_head, budget, nP);
     if (p.value_mode && p.values) p.values[env] = vret;
     if (!handoff) {
       if (p.rewards && (steps_done > 0 || p.pass == 0)) p.rewards[env] = last_reward;

@@ -125,6 +125,7 @@ struct BbxParams {
   int32_t accounting;       // 1: count algorithmic bytes per step (BbxHdr.alg_bytes); the lean fast kernel omits it
   int32_t pass;             // 0: primary launch; 1: follow-up launch serving only environments with work left
   const uint16_t* inv_table; // [32003] inverses in GF(32003) (L2-resident), binomial class
+  int32_t* lite;            // [B][4] {status, q_head, budget, |P|}: what the host polls after a launch, or null
   BbxTraceRec* trace;       // [B, trace_stride] or null
   int32_t trace_stride;
 };

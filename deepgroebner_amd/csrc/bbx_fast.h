@@ -32,6 +32,7 @@ struct BbxFastParams {
   uint32_t q_env_stride, q_slot_words, q_nslots, q_fixed;
   int32_t B, nsteps, obs_rows, trace_stride, k, nvars, lim_G, lim_P;
   int32_t agent, auto_reset, set_budget, pass, obs_every_step, obs_fill, rewards_mode;
+  int32_t* lite;                                      // [B][4] {status, q_head, budget, |P|} for the host, or null
   unsigned long long* prof;                           // diagnostic build only: [B][8] cycle sums per phase
 };
 
@@ -544,6 +545,7 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
     h->q_head = q_head; h->t = t_agent; h->total_steps += steps_done; h->total_additions += adds;
     h->episodes += episodes; h->zero_reductions += zero_red; h->steps_done = steps_done;
     h->budget = budget; h->rollout_pos = rollout_pos; h->done_last = done_last; h->alg_bytes += bytes_total;
+    if (cz->lite) *(int4*)(cz->lite + 4 * (size_t)env) = make_int4(status, q_head, budget, nP);
     if (!handoff) {
       double* rw = cz->rewards; uint8_t* dn = cz->dones; int32_t* rws = cz->rows;
       if (rw && (steps_done > 0 || cz->pass == 0))

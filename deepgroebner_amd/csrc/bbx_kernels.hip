@@ -1032,6 +1032,7 @@ __device__ __forceinline__ void step_body(const BbxParams& p, char* smem, unsign
     h->total_additions = total_adds; h->episodes = episodes; h->zero_reductions = zero_red; h->steps_done = steps_done;
     h->budget = budget; h->rollout_pos = rollout_pos; h->done_last = done_last; h->alg_bytes = alg_bytes;
     h->vret = vret; h->vdisc = vdisc;
+    if (p.lite) *(int4*)(p.lite + 4 * (size_t)env) = make_int4(status, q_head, budget, nP);
     if (p.value_mode && p.values) p.values[env] = vret;
     if (!handoff) {
       if (p.rewards && (steps_done > 0 || p.pass == 0)) p.rewards[env] = last_reward;
@@ -1108,6 +1109,57 @@ __global__ void bbx_mark_reset_kernel(char* recs, uint32_t rec_bytes, int B, con
   if (mask && !mask[env]) return;
   BbxHdr* h = (BbxHdr*)(recs + (size_t)env * rec_bytes);
   h->need_reset = 1; h->status = BBX_ST_OK; h->nP = 0; h->nG = 0; h->arena_used = 0; h->done_last = 0;
+}
+// refill of the ideal queue: the host stages the rings of the environments it topped up ([n ids][n tails][n rings]) and
+// uploads them with one copy; this kernel moves every ring to its place (one workgroup per ring)
+__global__ void bbx_scatter_queue_kernel(const uint32_t* stage, int n, uint32_t ring_words, uint32_t* q, int32_t* tail) {
+  const int i = blockIdx.x;
+  if (i >= n) return;
+  const int env = (int)stage[i];
+  const uint32_t* src = stage + 2 * (size_t)n + (size_t)i * ring_words;
+  uint32_t* dst = q + (size_t)env * ring_words;
+  for (uint32_t w = threadIdx.x; w < ring_words; w += blockDim.x) dst[w] = src[w];
+  if (threadIdx.x == 0) tail[env] = (int32_t)stage[n + i];
+}
+extern "C" int bbx_launch_scatter_queue(const uint32_t* stage, int n, uint32_t ring_words, uint32_t* q, int32_t* tail, hipStream_t stream) {
+  hipLaunchKernelGGL(bbx_scatter_queue_kernel, dim3(n), dim3(256), 0, stream, stage, n, ring_words, q, tail);
+  return (int)hipGetLastError();
+}
+// ragged observation: the rows of every environment back to back (what a list of per-environment matrices needs),
+// packed on the device from the padded block a step launch leaves behind.  Kernel 1: off[e] = sum of min(rows, cap)
+// over the environments before e (one workgroup); kernel 2: one workgroup per environment copies its rows.
+__global__ __launch_bounds__(1024) void bbx_obs_offsets_kernel(const int32_t* rows, int B, int cap, int32_t* off) {
+  __shared__ int part[1024];
+  const int t = threadIdx.x, per = (B + 1023) / 1024;
+  int s = 0;
+  for (int i = 0; i < per; i++) { const int e = t * per + i; if (e < B) { const int r = rows[e]; s += r < cap ? r : cap; } }
+  part[t] = s;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {                     // inclusive scan (Hillis-Steele)
+    const int v = t >= d ? part[t - d] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  int base = t ? part[t - 1] : 0;
+  for (int i = 0; i < per; i++) {
+    const int e = t * per + i;
+    if (e < B) { off[e] = base; const int r = rows[e]; base += r < cap ? r : cap; }
+  }
+  if (t == 1023) off[B] = part[1023];
+}
+__global__ void bbx_obs_pack_kernel(const int32_t* padded, int cap, int cols, const int32_t* off, int B, int32_t* packed) {
+  const int e = blockIdx.x;
+  if (e >= B) return;
+  const int n = (off[e + 1] - off[e]) * cols;
+  const int32_t* src = padded + (size_t)e * cap * cols;
+  int32_t* dst = packed + (size_t)off[e] * cols;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+}
+extern "C" int bbx_launch_obs_pack(const int32_t* padded, int cap, int cols, const int32_t* rows, int B, int32_t* off, int32_t* packed, hipStream_t stream) {
+  hipLaunchKernelGGL(bbx_obs_offsets_kernel, dim3(1), dim3(1024), 0, stream, rows, B, cap, off);
+  hipLaunchKernelGGL(bbx_obs_pack_kernel, dim3(B), dim3(64), 0, stream, padded, cap, cols, off, B, packed);
+  return (int)hipGetLastError();
 }
 extern "C" int bbx_launch_init(char* recs, uint32_t rec_bytes, int B, const uint32_t* agent_seeds, hipStream_t stream) {
   hipLaunchKernelGGL(bbx_init_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, recs, rec_bytes, B, agent_seeds);
@@ -1224,6 +1276,7 @@ static int launch_fast(const BbxParams* p, int blocks, int threads, int envs_per
   f.lim_G = (int)p->LL.maxG; f.lim_P = (int)p->LL.maxP;
   f.agent = p->agent; f.auto_reset = p->auto_reset; f.set_budget = p->set_budget; f.pass = p->pass;
   f.obs_every_step = p->obs_every_step; f.obs_fill = p->obs_fill; f.rewards_mode = p->rewards_mode;
+  f.lite = p->lite;
   const size_t lds = (size_t)envs_per_block * FLDS_BYTES;
   static unsigned long long* d_prof = nullptr;
   if (getenv("BBX_PROF") && !p->trace) {          // diagnostic: per-phase cycle sums, printed by bbx_prof_dump()

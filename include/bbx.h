@@ -125,6 +125,14 @@ int bbx_rollout(bbx_batch* b, int agent, int nsteps, int auto_reset, double* rew
  * out is int32 [batch, max_rows, cols], cols = 2*nvars*k; rows beyond |P| are filled with -1 when
  * fill != 0 (the padding the reference's agents apply, pg.py:217-226). */
 int bbx_obs(bbx_batch* b, int32_t* out, int max_rows, int fill);
+/* One call per vector step of the Gym-style loop: the step (actions != NULL; NULL = only refresh the observation), its
+ * outputs, and the observation of every environment as a RAGGED block: *offsets -> int32 [batch + 1] row offsets,
+ * *obs -> int32 [offsets[batch], cols], environment e owning rows offsets[e] .. offsets[e+1]-1 (exactly the `state`
+ * matrices wrapped.pyx:20,25 returns, back to back, no padding).  Both point into pinned memory owned by the handle and
+ * stay valid until the next call on it.  One kernel launch for the step, two small ones to pack, two device-to-host
+ * copies sized by what the pair sets actually hold (3-4 MB instead of a 25 MB padded block at batch 4096). */
+int bbx_step_obs(bbx_batch* b, const int32_t* actions, int auto_reset, double* rewards, uint8_t* dones, int32_t* rows,
+                 const int32_t** obs, const int32_t** offsets);
 int bbx_cols(const bbx_batch* b);
 int bbx_nvars(const bbx_batch* b);
 int bbx_batch_size(const bbx_batch* b);

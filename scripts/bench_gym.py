@@ -41,3 +41,20 @@ for t in range(T):
     _ffi.check(L.bbx_obs(env._h, _ffi.ptr(obs), 128, 1))
 t1 = time.perf_counter()
 print("gym path, auto-reset, with padded observation block: %.3f ms per vector step -> %.1f M env-steps/s" % ((t1 - t0) / T * 1e3, B * T / (t1 - t0) / 1e6))
+t0 = time.perf_counter()
+for t in range(T):
+    acts[:] = 0
+    flat, off, r, d = env.step_ragged(acts, auto_reset=True)
+t1 = time.perf_counter()
+print("python step_ragged (fused step + ragged observation, %.1f MB): %.3f ms per vector step -> %.1f M env-steps/s" % (flat.nbytes / 1e6, (t1 - t0) / T * 1e3, B * T / (t1 - t0) / 1e6))
+t0 = time.perf_counter()
+for t in range(20):
+    obs_list, r, d, _ = env.step(acts, auto_reset=True)
+t1 = time.perf_counter()
+print("python step (list of %d per-environment matrices): %.3f ms per vector step" % (B, (t1 - t0) / 20 * 1e3))
+obs_p, off_p = C.POINTER(C.c_int32)(), C.POINTER(C.c_int32)()
+t0 = time.perf_counter()
+for t in range(T):
+    _ffi.check(L.bbx_step_obs(env._h, _ffi.ptr(acts), 1, _ffi.ptr(rew), _ffi.ptr(done), _ffi.ptr(rows), C.byref(obs_p), C.byref(off_p)))
+t1 = time.perf_counter()
+print("bbx_step_obs (C ABI only: step + ragged observation into pinned memory): %.3f ms per vector step -> %.1f M env-steps/s" % ((t1 - t0) / T * 1e3, B * T / (t1 - t0) / 1e6))
