@@ -443,6 +443,40 @@ def test_make_strat_pipeline(tmp_path):
         assert parse_ideal_string(line) == g.next()
 
 
+def test_step_obs_ragged_block_and_growth():
+    """bbx_step_obs (what env.step()/reset() call): the ragged observation block against the oracle's matrices on a
+    distribution whose pair sets outgrow the initial 128-row device block (5-10-5-uniform: |P| in the hundreds), so the
+    block is enlarged and rewritten mid-run; step_ragged's flat/offsets view agrees with the list view."""
+    from deepgroebner_amd import VecLeadMonomialsEnv
+    bo = ffi.load("bo")
+    B, k = 3, 2
+    env = VecLeadMonomialsEnv("5-10-5-uniform", batch=B, k=k)
+    env.seed(np.arange(B) + 70)
+    oracles = []
+    for e in range(B):
+        o = bo.env("5-10-5-uniform"); o.seed(70 + e); o.reset(); oracles.append(o)
+    obs = env.reset()
+    for e, o in enumerate(oracles):
+        assert np.array_equal(obs[e], o.obs(k))
+    grown = False
+    for t in range(700):
+        acts = np.array([(5 * t + e) % max(o.nP, 1) for e, o in enumerate(oracles)], dtype=np.int32)
+        if t % 2:
+            flat, off, r, d = env.step_ragged(acts, auto_reset=True)
+            obs = [flat[off[e]:off[e + 1]] for e in range(B)]
+            assert off[0] == 0 and off[-1] == flat.shape[0]
+        else:
+            obs, r, d, _ = env.step(acts, auto_reset=True)
+        for e, o in enumerate(oracles):
+            assert r[e] == o.step(int(acts[e]))
+            if o.nP == 0:
+                assert d[e]
+                o.reset()
+            assert np.array_equal(obs[e], o.obs(k)), (t, e)
+            grown |= o.nP > 128
+    assert grown, "the run never exceeded the initial observation block: pick a longer one"
+
+
 def test_step_autoreset_vec_convention():
     from deepgroebner_amd import VecLeadMonomialsEnv
     bo = ffi.load("bo")
