@@ -228,32 +228,20 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
     if (lane == 0) { lm[g] = f; tm[g] = tail; }
     // (70-76) drop old pairs (i,j): LM f | lcm_ij and lcm_ij != lcm_if and lcm_ij != lcm_jf.  Only exponents matter,
     // so the lcms are raw v_pk_max words with the degree slot masked out of the comparisons.
-    int w = 0;
-    for (int base = 0; base < nP; base += WAVE) {
-      const int k = base + lane;
-      const bool valid = k < nP;
-      const uint32_t pr = valid ? pairs[k] : 0u;
-      const M2 li = lm[pr & 0xffffu], lj = lm[pr >> 16];
-      const uint32_t a0 = pk_max(li.w[0], lj.w[0]), a1 = pk_max(li.w[1], lj.w[1]);
-      const uint32_t b0 = pk_max(li.w[0], f.w[0]), b1 = pk_max(li.w[1], f.w[1]);
-      const uint32_t c0 = pk_max(lj.w[0], f.w[0]), c1 = pk_max(lj.w[1], f.w[1]);
-      const bool fdiv = (pk_subsat(f.w[0], a0) | (pk_subsat(f.w[1], a1) & 0xffffu)) == 0;
-      const bool eqi = ((a0 ^ b0) | ((a1 ^ b1) & 0xffffu)) == 0;
-      const bool eqj = ((a0 ^ c0) | ((a1 ^ c1) & 0xffffu)) == 0;
-      const bool keep = valid && k != skip && !(fdiv && !eqi && !eqj);
-      const uint64_t mask = ballot64(keep);
-      if (keep) pairs[w + prefix_of(mask, lane)] = pr;
-      w += __popcll(mask);
-    }
-    nP = w;
+    // The gathers of the first 64 pairs are issued here and consumed behind the register-only peel below, which
+    // hides their two dependent LDS round trips.
+    const int nP_old = nP;
+    const uint32_t pr_first = lane < nP_old ? pairs[lane] : 0u;
+    const M2 li_first = lm[pr_first & 0xffffu], lj_first = lm[pr_first >> 16];
     // (78-91) new pairs (i, g): minimal lcms by degree peeling
+    uint64_t emitA = 0, emitB = 0;
     {
       const M2 lA = lm[lane], lB = lm[lane + 64];          // basis order; lanes >= g hold garbage (masked by valid)
       const uint64_t validA = f_lowmask(g < 64 ? g : 64), validB = g > 64 ? f_lowmask(g - 64) : 0ull;
       const M2 LA = m_lcm(lA, f), LB = m_lcm(lB, f);
       const uint64_t cpA = ballot64(m_coprime(lA, f)) & validA, cpB = validB ? (ballot64(m_coprime(lB, f)) & validB) : 0ull;
       const uint32_t dA = LA.w[1] >> 16, dB = LB.w[1] >> 16;
-      uint64_t candA = validA, candB = validB, emitA = 0, emitB = 0;
+      uint64_t candA = validA, candB = validB;
       while (candA | candB) {
         const bool inA = (candA >> lane) & 1, inB = (candB >> lane) & 1;
         uint32_t dm = inA ? dA : 0xFFFFFFFFu;
@@ -273,6 +261,27 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
           candA &= ~divA; candB &= ~divB;
         }
       }
+    }
+    int w = 0;
+    for (int base = 0; base < nP_old; base += WAVE) {
+      const int k = base + lane;
+      const bool valid = k < nP_old;
+      uint32_t pr; M2 li, lj;
+      if (base == 0) { pr = pr_first; li = li_first; lj = lj_first; }
+      else { pr = valid ? pairs[k] : 0u; li = lm[pr & 0xffffu]; lj = lm[pr >> 16]; }
+      const uint32_t a0 = pk_max(li.w[0], lj.w[0]), a1 = pk_max(li.w[1], lj.w[1]);
+      const uint32_t b0 = pk_max(li.w[0], f.w[0]), b1 = pk_max(li.w[1], f.w[1]);
+      const uint32_t c0 = pk_max(lj.w[0], f.w[0]), c1 = pk_max(lj.w[1], f.w[1]);
+      const bool fdiv = (pk_subsat(f.w[0], a0) | (pk_subsat(f.w[1], a1) & 0xffffu)) == 0;
+      const bool eqi = ((a0 ^ b0) | ((a1 ^ b1) & 0xffffu)) == 0;
+      const bool eqj = ((a0 ^ c0) | ((a1 ^ c1) & 0xffffu)) == 0;
+      const bool keep = valid && k != skip && !(fdiv && !eqi && !eqj);
+      const uint64_t mask = ballot64(keep);
+      if (keep) pairs[w + prefix_of(mask, lane)] = pr;
+      w += __popcll(mask);
+    }
+    nP = w;
+    {
       // (92) ascending i, appended behind the surviving old pairs (98)
       if ((emitA >> lane) & 1) pairs[nP + prefix_of(emitA, lane)] = (uint32_t)lane | ((uint32_t)g << 16);
       nP += __popcll(emitA);
