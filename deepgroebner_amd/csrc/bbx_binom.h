@@ -149,19 +149,30 @@ __device__ uint64_t bin_obs(const BEnv<W>& e, const BbxParams& p, int env, int n
     const int rl = lane / per_row, slot = lane - rl * per_row;
     const int half = slot >= k ? 1 : 0, t = slot - half * k;
     const bool active = rl < rows_per_sweep;
-    for (int r0 = 0; r0 < rows; r0 += rows_per_sweep) {
-      const int r = r0 + rl;
-      if (active && r < rows) {
-        uint32_t pr = e.pairs[r];
-        int g = half ? (int)(pr >> 16) : (int)(pr & 0xffffu);
-        Mono<W> mm = m_zero<W>();
-        if (t == 0) mm = e.lm[g];
-        else if (t == 1 && (e.ginfo[g].x >> 16) != 0) mm = e.tm[g];
-        const int base = (r * per_row + slot) * n;
-        for (int v = 0; v < n; v++) {
-          uint32_t x = m_exp(mm, v);
-          if (out) out[base + v] = (int32_t)x;
-          if (HASH && want_hash) h += bbx_mix64((uint64_t)(base + v), x);
+    // four sweeps per trip with all gathers of a level in flight together: for HBM-resident environments each level is
+    // a trip to L2/HBM, and a single dependent chain per trip left the wave idle for microseconds.  tm[g] is the
+    // zero monomial when G[g] has no tail (bin_add_poly stores it that way), so no look at ginfo is needed.
+    constexpr int U = 4;
+    for (int r0 = 0; r0 < rows; r0 += U * rows_per_sweep) {
+      int rr[U]; bool on[U]; uint32_t pr[U]; Mono<W> mm[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        rr[u] = r0 + u * rows_per_sweep + rl;
+        on[u] = active && rr[u] < rows;
+        pr[u] = on[u] ? e.pairs[rr[u]] : 0u;
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int g = half ? (int)(pr[u] >> 16) : (int)(pr[u] & 0xffffu);
+        mm[u] = m_zero<W>();
+        if (on[u]) { if (t == 0) mm[u] = e.lm[g]; else if (t == 1) mm[u] = e.tm[g]; }
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        if (on[u]) {
+          const int base = (rr[u] * per_row + slot) * n;
+          if (out) obs_store<W>(out + base, mm[u], n);
+          if (HASH && want_hash) for (int v = 0; v < n; v++) h += bbx_mix64((uint64_t)(base + v), m_exp(mm[u], v));
         }
       }
     }
@@ -176,11 +187,8 @@ __device__ uint64_t bin_obs(const BEnv<W>& e, const BbxParams& p, int env, int n
       if (t == 0) mm = e.lm[g];
       else if (t == 1 && (e.ginfo[g].x >> 16) != 0) mm = e.tm[g];
       const int base = it * n;
-      for (int v = 0; v < n; v++) {
-        uint32_t x = m_exp(mm, v);
-        if (out) out[base + v] = (int32_t)x;
-        if (HASH && want_hash) h += bbx_mix64((uint64_t)(base + v), x);
-      }
+      if (out) obs_store<W>(out + base, mm, n);
+      if (HASH && want_hash) for (int v = 0; v < n; v++) h += bbx_mix64((uint64_t)(base + v), m_exp(mm, v));
     }
   }
   if (out && p.obs_fill) {

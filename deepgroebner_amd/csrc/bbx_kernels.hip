@@ -164,6 +164,25 @@ template <int W> __device__ __forceinline__ uint32_t m_exp(const Mono<W>& a, int
   return (v & 1) ? (w >> 16) : (w & 0xffffu);
 }
 
+// the n exponents of one monomial slot of the observation matrix, written with the widest stores 4-byte alignment
+// allows (dwordx4 / dwordx2 / dword) instead of n single dwords: the observation is the largest output of a step
+struct __attribute__((aligned(4))) ObsI4 { int32_t a, b, c, d; };
+struct __attribute__((aligned(4))) ObsI2 { int32_t a, b; };
+template <int W> __device__ __forceinline__ void obs_store(int32_t* dst, const Mono<W>& mm, int n) {
+  int32_t x[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < W; i++) { x[2 * i] = (int32_t)(mm.w[i] & 0xffffu); x[2 * i + 1] = (int32_t)(mm.w[i] >> 16); }
+  switch (n) {                                             // wave-uniform
+    case 1: dst[0] = x[0]; break;
+    case 2: *(ObsI2*)dst = ObsI2{x[0], x[1]}; break;
+    case 3: *(ObsI2*)dst = ObsI2{x[0], x[1]}; dst[2] = x[2]; break;
+    case 4: *(ObsI4*)dst = ObsI4{x[0], x[1], x[2], x[3]}; break;
+    case 5: *(ObsI4*)dst = ObsI4{x[0], x[1], x[2], x[3]}; dst[4] = x[4]; break;
+    case 6: *(ObsI4*)dst = ObsI4{x[0], x[1], x[2], x[3]}; *(ObsI2*)(dst + 4) = ObsI2{x[4], x[5]}; break;
+    default: *(ObsI4*)dst = ObsI4{x[0], x[1], x[2], x[3]}; *(ObsI2*)(dst + 4) = ObsI2{x[4], x[5]}; dst[6] = x[6]; break;
+  }
+}
+
 // ------------------------------------------------------------------ environment view
 template <int W> struct Env {
   BbxHdr* hdr;
@@ -689,11 +708,8 @@ __device__ uint64_t wave_obs(const Env<W>& e, const BbxParams& p, int env, int n
     bool have = t < (int)e.plen[g];
     Mono<W> mm = have ? e.am[e.poff[g] + t] : m_zero<W>();
     int base = it * n;
-    for (int v = 0; v < n; v++) {
-      uint32_t x = m_exp(mm, v);
-      if (out) out[base + v] = (int32_t)x;
-      if (HASH && want_hash) h += bbx_mix64((uint64_t)(base + v), x);
-    }
+    if (out) obs_store<W>(out + base, mm, n);
+    if (HASH && want_hash) for (int v = 0; v < n; v++) h += bbx_mix64((uint64_t)(base + v), m_exp(mm, v));
   }
   if (out && p.obs_fill) {
     for (int idx = rows * cols + lane; idx < p.obs_rows * cols; idx += WAVE) out[idx] = -1;
