@@ -94,6 +94,7 @@ struct bbx_batch {
   std::vector<int32_t> h_lite;        // per environment {status, q_head, budget, nP}: what is polled after every launch
   bool q_dirty = true;
   std::vector<uint8_t> q_dirty_env;
+  std::vector<std::string> gen_error;   // per environment: a generator failure met while drawing ahead (see fill_queues)
   // device
   char* d_recs = nullptr;
   uint32_t* d_q = nullptr;
@@ -217,7 +218,16 @@ int fill_queues(bbx_batch* b, int min_avail = 1, hipStream_t stream = 0) {
   for (int e = 0; e < b->B; e++) {
     if (b->h_tail[e] - b->h_head[e] >= std::min(min_avail, (int)b->nslots)) continue;
     while (b->h_tail[e] - b->h_head[e] < (int)b->nslots) {
-      if (!b->gens[e]->next(F, &err)) return fail(BBX_E_GENERATOR, "%s", err.c_str());
+      // A generator failure (the reference throws: e.g. no two distinct monomials after 1000 trials) is reported when
+      // the environment NEEDS that ideal, as in the reference, not when it is drawn ahead of time: the failure is
+      // parked and the ring not topped up any further; the draws it consumed stay consumed, exactly as after a caught
+      // exception.
+      if (!b->gen_error.empty() && !b->gen_error[e].empty()) break;   // parked: finish() raises it if the environment starves
+      if (!b->gens[e]->next(F, &err)) {
+        if (b->gen_error.size() != (size_t)b->B) b->gen_error.assign(b->B, std::string());
+        b->gen_error[e] = err;
+        continue;
+      }
       uint32_t* slot = b->h_q.data() + (size_t)e * b->nslots * b->slot_words + (size_t)(b->h_tail[e] % (int)b->nslots) * b->slot_words;
       int rc = pack_ideal(b, F, slot);
       if (rc) return rc;
@@ -339,6 +349,12 @@ int finish(bbx_batch* b, hipStream_t stream) {
     bool again = false;
     for (int e = 0; e < b->B; e++) {
       int st = b->h_lite[(size_t)e * 4];
+      if (st == BBX_ST_STARVED && !b->gen_error.empty() && !b->gen_error[e].empty() && b->h_tail[e] - b->h_head[e] <= 0) {
+        const std::string msg = b->gen_error[e];       // the draw this environment is waiting for is the one that failed
+        b->gen_error[e].clear();
+        b->in_flight = false;
+        return fail(BBX_E_GENERATOR, "%s", msg.c_str());
+      }
       if (st == BBX_ST_STARVED || st == BBX_ST_SPILL) again = true;
       else if (st == BBX_ST_BAD_ACTION) return fail(BBX_E_ACTION, "environment %d: %s", e, status_name(st));
       else if (st != BBX_ST_OK) {
@@ -579,6 +595,7 @@ int bbx_copy(const bbx_batch* s, bbx_batch** out) {
   b->h_q = s->h_q; b->h_tail = s->h_tail; b->h_head = s->h_head; b->q_dirty = true;
   b->wide = s->wide; b->accounting = s->accounting; b->staged = s->staged; b->fast = s->fast; b->envs_per_block = s->envs_per_block;
   for (auto& g : s->gens) b->gens.push_back(g->clone());
+  b->gen_error = s->gen_error;
   const int batch = s->B;
   HIPCHK(hipMalloc((void**)&b->d_recs, (size_t)batch * b->L.rec_bytes));
   HIPCHK(hipMemcpy(b->d_recs, s->d_recs, (size_t)batch * b->L.rec_bytes, hipMemcpyDeviceToDevice));
@@ -625,6 +642,7 @@ int bbx_clone_envs(bbx_batch* b, int n, const int32_t* src, const int32_t* dst) 
     for (int i = 0; i < n; i++) {
       const int s = src[i], d = dst[i];
       b->gens[d] = b->gens[s]->clone();
+      if (!b->gen_error.empty()) b->gen_error[d] = b->gen_error[s];
       b->h_tail[d] = b->h_tail[s]; b->h_head[d] = b->h_head[s];
       memcpy(b->h_q.data() + (size_t)d * stride, b->h_q.data() + (size_t)s * stride, stride * sizeof(uint32_t));
       b->q_dirty_env[d] = 1;
@@ -642,6 +660,7 @@ int bbx_seed(bbx_batch* b, const int64_t* seeds) {
   int rc = read_headers(b);                    // ideals generated ahead from the old stream are dropped
   if (rc) return rc;
   for (int e = 0; e < b->B; e++) { b->gens[e]->seed(seeds[e]); b->h_tail[e] = b->h_head[e]; }
+  b->gen_error.clear();
   b->q_dirty = true; b->q_dirty_env.clear();
   return BBX_OK;
 }

@@ -299,6 +299,48 @@ def test_lead_monomial_padding_and_k_sweep():
             assert r == o.step(a)
 
 
+@pytest.mark.parametrize("dist", ["2-8-4-weighted", "4-5-4-weighted", "6-4-4-uniform", "7-3-4-weighted",
+                                  "2-5-4-0.8-uniform", "6-3-4-0.5-weighted"])
+def test_observation_width_sweep(dist):
+    """Every row width the observation writer knows how to store (n = 2..7 variables: dword / dwordx2 / dwordx4
+    combinations), binomial and general classes, k = 1 and 3, against the oracle for a whole episode prefix."""
+    from deepgroebner_amd import CLeadMonomialsEnv
+    bo = ffi.load("bo")
+    n = int(dist.split("-")[0])
+    for k in (1, 3):
+        env = CLeadMonomialsEnv(dist, k=k); env.seed(5)
+        o = bo.env(dist); o.seed(5); o.reset()
+        state = env.reset()
+        for t in range(40):
+            assert state.shape[1] == 2 * n * k and np.array_equal(state, o.obs(k)), (dist, k, t)
+            if len(state) == 0:
+                break
+            a = (3 * t + 1) % len(state)
+            state, r, done, _ = env.step(a)
+            assert r == o.step(a)
+
+
+def test_generator_failure_surfaces_when_the_ideal_is_needed():
+    """1-variable binomials: the generator soon fails to draw two distinct monomials (the reference throws,
+    ideals.cpp:190-192).  Ideals are drawn ahead of time here (a ring of 8 per environment), but the error must appear
+    at the reset that consumes the failing draw — where the reference raises — and not earlier; the resets before it
+    match the oracle."""
+    from deepgroebner_amd import CLeadMonomialsEnv, _ffi
+    bo = ffi.load("bo")
+    g = bo.generator("1-6-3-uniform"); g.seed(5)
+    first_bad = next(i for i in range(10000) if len(g.next()) < 3)     # a failed draw leaves the ideal incomplete
+    assert 1 <= first_bad < 200
+    env = CLeadMonomialsEnv("1-6-3-uniform", k=1); env.seed(5)
+    o = bo.env("1-6-3-uniform"); o.seed(5)
+    for episode in range(first_bad):
+        o.reset()
+        state = env.reset()
+        assert np.array_equal(state, o.obs(1)), episode
+        assert len(state) > 0                                          # (no redraws: one ideal per reset)
+    with pytest.raises(_ffi.BbxError, match="distinct"):
+        env.reset()
+
+
 def test_padded_observation_block():
     """[batch, max_rows, cols] with -1 fill: the layout the reference's agents build on the host (pg.py:217-226)."""
     from deepgroebner_amd import VecLeadMonomialsEnv
