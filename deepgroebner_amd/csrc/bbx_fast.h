@@ -163,6 +163,30 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
   const int rows_per_sweep = per_row <= WAVE ? WAVE / per_row : 0;
 
   // ---- helpers as lambdas over the state above ----------------------------------------------------------------------
+  // The observation of the headline shape (3 variables, k = 2: rows of 4 monomials x 3 exponents = 48 bytes) with
+  // everything that depends on the lane decided once per launch: lane -> (row in the sweep, which pair member, lead or
+  // tail) and its output address; per trip two pair gathers, two monomial gathers and two 12-byte stores.
+  struct __attribute__((aligned(4))) ObsI3 { int32_t a, b, c; };
+  const bool obs32 = n == 3 && kk == 2 && p.obs != nullptr;
+  const int o3_row = lane >> 2, o3_hi = (lane >> 1) & 1;
+  const char* o3_mono = lbase + ((lane & 1) ? FOFF_TM : FOFF_LM);
+  int32_t* const o3_out = obs32 ? p.obs + (size_t)env * p.obs_rows * 12 + lane * 3 : nullptr;
+  auto write_obs32 = [&]() {
+    const int rows = nP < p.obs_rows ? nP : p.obs_rows;
+    for (int r0 = 0; r0 < rows; r0 += 32) {
+      const int ra = r0 + o3_row, rb = ra + 16;
+      const bool oa = ra < rows, ob = rb < rows;
+      const uint32_t pa = oa ? pairs[ra] : 0u, pb = ob ? pairs[rb] : 0u;
+      const uint32_t ga = o3_hi ? pa >> 16 : pa & 0xffffu, gb = o3_hi ? pb >> 16 : pb & 0xffffu;
+      const M2 ma = *(const M2*)(o3_mono + ga * 8), mb = *(const M2*)(o3_mono + gb * 8);
+      if (oa) *(ObsI3*)(o3_out + r0 * 12) = ObsI3{(int32_t)(ma.w[0] & 0xffffu), (int32_t)(ma.w[0] >> 16), (int32_t)(ma.w[1] & 0xffffu)};
+      if (ob) *(ObsI3*)(o3_out + r0 * 12 + 192) = ObsI3{(int32_t)(mb.w[0] & 0xffffu), (int32_t)(mb.w[0] >> 16), (int32_t)(mb.w[1] & 0xffffu)};
+    }
+    if (p.obs_fill) {
+      int32_t* out = p.obs + (size_t)env * p.obs_rows * 12;
+      for (int idx = rows * 12 + lane; idx < p.obs_rows * 12; idx += WAVE) out[idx] = -1;
+    }
+  };
   auto write_obs = [&](bool write, bool want_hash) -> uint64_t {
     const int cols = per_row * n;
     int32_t* out = (write && p.obs) ? p.obs + (size_t)env * p.obs_rows * cols : nullptr;
@@ -499,7 +523,7 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
     if ((t_agent & 63) == 0) hv = bbx_agent_hash32(agent_seed, (uint32_t)(t_agent + lane));
     const bool done = nP == 0;
 
-    if (p.obs_every_step && p.obs) write_obs(true, false);
+    if (p.obs_every_step && p.obs) { if (obs32) write_obs32(); else write_obs(true, false); }
     if (TRACE && tracing) {
       const uint64_t oh = write_obs(false, true);
       uint64_t ph = 0;
@@ -536,7 +560,7 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
   if (PROF && cz->prof && lane == 0) for (int i = 0; i < 8; i++) cz->prof[(size_t)env * 8 + i] = prof_sum[i];
 
   const bool handoff = status == BBX_ST_SPILL;
-  if (p.obs && status == BBX_ST_OK) write_obs(true, false);
+  if (p.obs && status == BBX_ST_OK) { if (obs32) write_obs32(); else write_obs(true, false); }
   if (staged_in) {                                                   // write the live prefixes back to the HBM record
     wave_sync();
     F_HBM_PTRS(cz)
