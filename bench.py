@@ -164,7 +164,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes/launch",
                          "traffic_source": traffic_src, "alg_bytes_per_launch": per_launch_bytes,
-                         "kernel": "bbx_fast_kernel<false,false>", "alg_bytes_per_env_step": alg_bytes / steps_done,
+                         "kernel": "bbx_fast_headline_kernel" if not args.ablate_obs else "bbx_fast_kernel<false,false>", "alg_bytes_per_env_step": alg_bytes / steps_done,
                          "kernel_ms_per_launch": kernel_ms / nlaunch, "launches": nlaunch, "timed_region_ms": region_ms},
             "cpu_baseline": cpu,
         }

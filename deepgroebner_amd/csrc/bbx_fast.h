@@ -94,7 +94,10 @@ struct FastState {                 // reducer-order arrays, lane l <-> reducers 
 #define FMARK(slot)
 #endif
 #define FSTAMP(slot) do { FMARK(slot); if (PROF) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); prof_sum[slot] += t_ - prof_last; prof_last = t_; } } while (0)
-template <bool TRACE, bool ACCT, bool PROF = false>
+// HL: the headline rollout shape as compile-time constants (random-hash agent, 3 variables, k = 2, the observation
+// written after every step without fill, auto-reset): no dispatch on launch parameters inside the step loop and fewer
+// scalar registers live across it.  The launcher picks it when the parameters say exactly that.
+template <bool TRACE, bool ACCT, bool PROF = false, bool HL = false>
 __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
   unsigned long long prof_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long prof_last = PROF ? __builtin_amdgcn_s_memtime() : 0;
@@ -155,7 +158,11 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
   long long bytes_total = 0;
   int last_nred = vzero - 1;                           // reward of the last step, kept as its integer reduction count
   const bool tracing = TRACE && p.trace != nullptr;
-  const int n = p.nvars, kk = p.k;
+  const int n = HL ? 3 : p.nvars, kk = HL ? 2 : p.k;
+  const int agent = HL ? BBX_AGENT_HASH : p.agent;
+  const bool auto_reset = HL ? true : p.auto_reset != 0;
+  const bool obs_fill = HL ? false : p.obs_fill != 0;
+  const bool obs_step = HL ? true : (p.obs_every_step && p.obs);
   const int per_row = 2 * kk;
   const int obs_row_bytes = 4 * per_row * n;
   // lane -> (row within a sweep, slot) of the observation matrix, fixed for the launch
@@ -167,7 +174,7 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
   // everything that depends on the lane decided once per launch: lane -> (row in the sweep, which pair member, lead or
   // tail) and its output address; per trip two pair gathers, two monomial gathers and two 12-byte stores.
   struct __attribute__((aligned(4))) ObsI3 { int32_t a, b, c; };
-  const bool obs32 = n == 3 && kk == 2 && p.obs != nullptr;
+  const bool obs32 = HL ? true : (n == 3 && kk == 2 && p.obs != nullptr);
   const int o3_row = lane >> 2, o3_hi = (lane >> 1) & 1;
   const char* o3_mono = lbase + ((lane & 1) ? FOFF_TM : FOFF_LM);
   int32_t* const o3_out = obs32 ? p.obs + (size_t)env * p.obs_rows * 12 + lane * 3 : nullptr;
@@ -182,7 +189,7 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
       if (oa) *(ObsI3*)(o3_out + r0 * 12) = ObsI3{(int32_t)(ma.w[0] & 0xffffu), (int32_t)(ma.w[0] >> 16), (int32_t)(ma.w[1] & 0xffffu)};
       if (ob) *(ObsI3*)(o3_out + r0 * 12 + 192) = ObsI3{(int32_t)(mb.w[0] & 0xffffu), (int32_t)(mb.w[0] >> 16), (int32_t)(mb.w[1] & 0xffffu)};
     }
-    if (p.obs_fill) {
+    if (obs_fill) {
       int32_t* out = p.obs + (size_t)env * p.obs_rows * 12;
       for (int idx = rows * 12 + lane; idx < p.obs_rows * 12; idx += WAVE) out[idx] = -1;
     }
@@ -234,7 +241,7 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
         }
       }
     }
-    if (out && p.obs_fill) for (int idx = rows * cols + lane; idx < p.obs_rows * cols; idx += WAVE) out[idx] = -1;
+    if (out && obs_fill) for (int idx = rows * cols + lane; idx < p.obs_rows * cols; idx += WAVE) out[idx] = -1;
     return (TRACE && want_hash) ? wave_sum64(h) : 0;
   };
 
@@ -398,9 +405,9 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
 
     // ---- choose the pair -----------------------------------------------------------------------------------------
     int action;
-    if (p.agent == BBX_AGENT_HASH) action = (int)(((uint64_t)f_readlane(hv, t_agent & 63) * (uint32_t)nP) >> 32);   // bbx_agent_action32
-    else if (p.agent == BBX_AGENT_EXTERNAL) action = uni(f_cold_params()->actions[env]);
-    else if (p.agent == BBX_AGENT_FIRST) action = 0;
+    if (agent == BBX_AGENT_HASH) action = (int)(((uint64_t)f_readlane(hv, t_agent & 63) * (uint32_t)nP) >> 32);   // bbx_agent_action32
+    else if (agent == BBX_AGENT_EXTERNAL) action = uni(f_cold_params()->actions[env]);
+    else if (agent == BBX_AGENT_FIRST) action = 0;
     else {                                                 // degree: first row of minimal deg lcm (buchberger.cpp:171-176)
       uint32_t best = 0xFFFFFFFFu;
       for (int r = lane; r < nP; r += WAVE) {
@@ -523,7 +530,7 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
     if ((t_agent & 63) == 0) hv = bbx_agent_hash32(agent_seed, (uint32_t)(t_agent + lane));
     const bool done = nP == 0;
 
-    if (p.obs_every_step && p.obs) { if (obs32) write_obs32(); else write_obs(true, false); }
+    if (obs_step) { if (obs32) write_obs32(); else write_obs(true, false); }
     if (TRACE && tracing) {
       const uint64_t oh = write_obs(false, true);
       uint64_t ph = 0;
@@ -553,7 +560,7 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
     }
     budget--; if (TRACE) trace_pos++;
     done_last = done ? 1 : 0;
-    if (done) { episodes++; if (p.auto_reset) need_reset = 1; }
+    if (done) { episodes++; if (auto_reset) need_reset = 1; }
     FSTAMP(5);                                             // 5: observation + bookkeeping
   }
   const FColdParams cz = f_cold_params();
@@ -593,6 +600,10 @@ template <bool TRACE, bool ACCT>
 __global__ __launch_bounds__(256) void bbx_fast_kernel(BbxFastParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   fast_body<TRACE, ACCT>(p, smem);
+}
+__global__ __launch_bounds__(256) void bbx_fast_headline_kernel(BbxFastParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  fast_body<false, false, false, true>(p, smem);
 }
 // diagnostic build with s_memtime stamps between the phases of a step (never timed, never shipped as a result)
 __global__ __launch_bounds__(256) void bbx_fast_prof_kernel(BbxFastParams p) {

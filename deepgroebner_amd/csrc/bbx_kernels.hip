@@ -1311,6 +1311,8 @@ static int launch_fast(const BbxParams* p, int blocks, int threads, int envs_per
   }
   if (p->trace) hipLaunchKernelGGL((bbx_fast_kernel<true, true>), dim3(blocks), dim3(threads), lds, stream, f);
   else if (p->accounting) hipLaunchKernelGGL((bbx_fast_kernel<false, true>), dim3(blocks), dim3(threads), lds, stream, f);
+  else if (f.agent == BBX_AGENT_HASH && f.nvars == 3 && f.k == 2 && f.obs && f.obs_every_step && !f.obs_fill && f.auto_reset)
+    hipLaunchKernelGGL(bbx_fast_headline_kernel, dim3(blocks), dim3(threads), lds, stream, f);
   else hipLaunchKernelGGL((bbx_fast_kernel<false, false>), dim3(blocks), dim3(threads), lds, stream, f);
   return 0;
 }

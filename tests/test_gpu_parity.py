@@ -381,6 +381,45 @@ def test_rollout_device_with_torch_buffers():
         assert np.array_equal(got[:o.nP], o.obs(k)) and (got[o.nP:] == -1).all()
 
 
+def test_headline_kernel_variant_vs_oracle():
+    """The launch shape bench.py times — counter-hash agent, 3 variables, k = 2, observation written after every step
+    without fill, auto-reset — takes the compile-time specialised kernel; a few launches of it (episodes end and restart
+    inside them) against the oracle: last reward / done / rows, the observation block, the step and addition counters
+    and the complete final state."""
+    import torch
+    from deepgroebner_amd import VecLeadMonomialsEnv
+    bo = ffi.load("bo")
+    B, k = 48, 2
+    env = VecLeadMonomialsEnv("3-20-10-weighted", batch=B, k=k)
+    env.seed(np.arange(B) + 300); env.seed_agent(np.arange(B) + 17); env.reset()
+    obs = torch.zeros((B, 128, env.cols), dtype=torch.int32, device="cuda")
+    rew = torch.zeros(B, dtype=torch.float64, device="cuda")
+    done = torch.zeros(B, dtype=torch.uint8, device="cuda")
+    rows = torch.zeros(B, dtype=torch.int32, device="cuda")
+    s = torch.cuda.current_stream()
+    oracles, tcount, adds = [], [0] * B, [0] * B
+    for e in range(B):
+        o = bo.env("3-20-10-weighted"); o.seed(300 + e); o.reset(); oracles.append(o)
+    for T in (1, 63, 130, 200):
+        env.rollout_device("random", T, True, s.cuda_stream, rew, done, rows, obs, 128, False, True)
+        env.sync(); torch.cuda.synchronize()
+        for e, o in enumerate(oracles):
+            r = 0.0
+            for _ in range(T):
+                r = o.step(ffi.agent_action(17 + e, tcount[e], o.nP)); tcount[e] += 1; adds[e] += int(-r)
+                d = o.nP == 0
+                if d:
+                    o.reset()
+            assert float(rew[e]) == r and bool(done[e]) == d and int(rows[e]) == o.nP, (T, e)
+            assert np.array_equal(obs[e, :o.nP].cpu().numpy(), o.obs(k)), (T, e)
+    st = env.stats()
+    assert st[:, 0].tolist() == tcount and st[:, 1].tolist() == adds
+    for e in (0, B // 2, B - 1):
+        basis, pairs, order = env.state(e)
+        assert np.array_equal(_state_words(basis, pairs, order),
+                              _state_words(oracles[e].basis(), oracles[e].pairs(), oracles[e].reducer_order())), e
+
+
 @pytest.mark.parametrize("wide", [0, -1, 3])
 def test_long_polynomials_cyclic7_all_merge_paths(wide):
     """cyclic-7 far enough into an episode that polynomials have hundreds to thousands of terms: exercises the
