@@ -11,7 +11,7 @@ for f in sorted(glob.glob('gpurun_out/pmc_%s_*/p_counter_collection.csv' % tag))
     for r in csv.DictReader(open(f)):
         if want is not None and want not in r['Kernel_Name']:
             continue
-        if 'bbx_' in r['Kernel_Name'] and any(t in r['Kernel_Name'] for t in ('step_kernel', 'binom_kernel', 'fast_kernel')):
+        if 'bbx_' in r['Kernel_Name'] and any(t in r['Kernel_Name'] for t in ('step_kernel', 'binom_kernel', 'fast_kernel', 'fast_headline_kernel')):
             by[r['Dispatch_Id']][r['Counter_Name']] = float(r['Counter_Value'])
             names[r['Dispatch_Id']] = r['Kernel_Name']
             dur[r['Dispatch_Id']] = int(r['End_Timestamp']) - int(r['Start_Timestamp'])
