@@ -94,6 +94,9 @@ struct bbx_batch {
   std::vector<int32_t> h_lite;        // per environment {status, q_head, budget, nP}: what is polled after every launch
   bool q_dirty = true;
   std::vector<uint8_t> q_dirty_env;
+  // ideals drawn on the device (binomial distributions): the table the kernels read, the per-environment engine state
+  // lives in the record headers (BbxHdr.gen_rng); the host-side generators and the ideal queue are then unused
+  uint32_t* d_gen = nullptr; size_t gen_words = 0; bool device_gen = false;
   std::vector<std::string> gen_error;   // per environment: a generator failure met while drawing ahead (see fill_queues)
   // device
   char* d_recs = nullptr;
@@ -211,6 +214,7 @@ int upload_queue(bbx_batch* b, hipStream_t stream = 0) {
 // refill the ring of every environment that holds fewer than min_avail pre-generated ideals
 // (launches pass 1: only rings that are empty; bbx_prefetch passes the ring size: top everything up)
 int fill_queues(bbx_batch* b, int min_avail = 1, hipStream_t stream = 0) {
+  if (b->device_gen) return BBX_OK;                 // the kernels draw their own ideals
   if (b->fixed) return upload_queue(b, stream);
   std::string err;
   bbx::HIdeal F;
@@ -272,6 +276,7 @@ void fill_params(bbx_batch* b, BbxParams* p) {
   p->inv_table = b->d_inv;
   p->accounting = b->accounting ? 1 : 0;
   p->lite = b->d_lite;
+  p->gen = b->device_gen ? b->d_gen : nullptr;
 }
 
 // enqueue the kernels of one logical launch: the LDS-staged pass (when the class allows) followed by the
@@ -315,6 +320,14 @@ int collect_events(bbx_batch* b) {
   return BBX_OK;
 }
 
+// engine state of std::default_random_engine after seed(s) (MinStd0::seed), written into the record headers
+int write_gen_states(bbx_batch* b, const std::vector<long long>& seeds) {
+  std::vector<uint32_t> st(b->B);
+  for (int e = 0; e < b->B; e++) { bbx::MinStd0 r; r.seed(seeds[e]); st[e] = (uint32_t)r.x; }
+  HIPCHK(hipMemcpy2D(b->d_recs + offsetof(BbxHdr, gen_rng), b->L.rec_bytes, st.data(), sizeof(uint32_t), sizeof(uint32_t), b->B, hipMemcpyHostToDevice));
+  return BBX_OK;
+}
+
 int alloc_io(bbx_batch* b, int batch) {
   b->io_bytes = (size_t)batch * 29;
   HIPCHK(hipMalloc((void**)&b->d_out, b->io_bytes));
@@ -355,6 +368,7 @@ int finish(bbx_batch* b, hipStream_t stream) {
         b->in_flight = false;
         return fail(BBX_E_GENERATOR, "%s", msg.c_str());
       }
+      if (st == BBX_ST_GEN_FAIL) { b->in_flight = false; return fail(BBX_E_GENERATOR, "failed to generate two distinct random monomials after 1000 trials"); }
       if (st == BBX_ST_STARVED || st == BBX_ST_SPILL) again = true;
       else if (st == BBX_ST_BAD_ACTION) return fail(BBX_E_ACTION, "environment %d: %s", e, status_name(st));
       else if (st != BBX_ST_OK) {
@@ -497,6 +511,21 @@ int create_common(std::unique_ptr<bbx::IdealGen> proto, int nvars_obs, int elimi
   }
   int lrc = bbx_launch_init(b->d_recs, b->L.rec_bytes, batch, nullptr, 0);
   if (lrc) return fail(BBX_E_DEVICE, "init launch failed: %s", hipGetErrorString((hipError_t)lrc));
+  // binomial distributions: draw the ideals on the device (same seeded streams; see gen_binomial in bbx_kernels.hip).
+  // Not with sort_input (the generators would have to be sorted first), ideal lists, or the general class.
+  if (!b->fixed && !list && b->binom && !sort_input && !getenv("BBX_HOST_GEN")) {
+    std::vector<uint32_t> table;
+    if (b->gens[0]->device_table(b->W, &table)) {
+      HIPCHK(hipMalloc((void**)&b->d_gen, table.size() * sizeof(uint32_t)));
+      HIPCHK(hipMemcpy(b->d_gen, table.data(), table.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+      b->device_gen = true; b->gen_words = table.size();
+      std::vector<long long> seeds(batch);
+      for (int e = 0; e < batch; e++) seeds[e] = 5489 + e;          // the default seeding of the host generators above
+      HIPCHK(hipDeviceSynchronize());
+      int rc = write_gen_states(b.get(), seeds);
+      if (rc) return rc;
+    }
+  }
   lrc = bbx_launch_mark_reset(b->d_recs, b->L.rec_bytes, batch, nullptr, 0);
   if (lrc) return fail(BBX_E_DEVICE, "init launch failed: %s", hipGetErrorString((hipError_t)lrc));
   HIPCHK(hipDeviceSynchronize());
@@ -578,6 +607,7 @@ void bbx_destroy(bbx_batch* b) {
   if (b->h_act) (void)hipHostFree(b->h_act);
   if (b->h_stage) (void)hipHostFree(b->h_stage);
   if (b->d_stage) (void)hipFree(b->d_stage);
+  if (b->d_gen) (void)hipFree(b->d_gen);
   if (b->h_obs) (void)hipHostFree(b->h_obs);
   if (b->d_obs_off) (void)hipFree(b->d_obs_off);
   if (b->d_obs_packed) (void)hipFree(b->d_obs_packed);
@@ -594,6 +624,11 @@ int bbx_copy(const bbx_batch* s, bbx_batch** out) {
   b->fixed = s->fixed; b->binom = s->binom; b->L = s->L; b->LL = s->LL; b->slot_words = s->slot_words; b->nslots = s->nslots;
   b->h_q = s->h_q; b->h_tail = s->h_tail; b->h_head = s->h_head; b->q_dirty = true;
   b->wide = s->wide; b->accounting = s->accounting; b->staged = s->staged; b->fast = s->fast; b->envs_per_block = s->envs_per_block;
+  if (s->device_gen) {
+    HIPCHK(hipMalloc((void**)&b->d_gen, s->gen_words * sizeof(uint32_t)));
+    HIPCHK(hipMemcpy(b->d_gen, s->d_gen, s->gen_words * sizeof(uint32_t), hipMemcpyDeviceToDevice));
+    b->device_gen = true; b->gen_words = s->gen_words;
+  }
   for (auto& g : s->gens) b->gens.push_back(g->clone());
   b->gen_error = s->gen_error;
   const int batch = s->B;
@@ -657,6 +692,12 @@ int bbx_seed(bbx_batch* b, const int64_t* seeds) {
   if (!b || !seeds) return fail(BBX_E_ARG, "null argument");
   if (b->fixed) return BBX_OK;                 // FixedIdealGenerator::seed is a no-op (ideals.h:94)
   HIPCHK(hipSetDevice(b->device));
+  if (b->device_gen) {
+    if (b->in_flight) { int rc = finish(b, b->last_stream); if (rc) return rc; }
+    std::vector<long long> s(seeds, seeds + b->B);
+    for (int e = 0; e < b->B; e++) b->gens[e]->seed(seeds[e]);     // (kept in step for bbx_copy of a host-generating twin)
+    return write_gen_states(b, s);
+  }
   int rc = read_headers(b);                    // ideals generated ahead from the old stream are dropped
   if (rc) return rc;
   for (int e = 0; e < b->B; e++) { b->gens[e]->seed(seeds[e]); b->h_tail[e] = b->h_head[e]; }

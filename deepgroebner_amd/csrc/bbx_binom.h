@@ -99,7 +99,25 @@ __device__ bool bin_add_poly(BEnv<W>& e, const BbxParams& p, const BbxLayout& L,
 }
 
 template <int W>
-__device__ bool bin_reset(BEnv<W>& e, const BbxParams& p, const BbxLayout& L, int env, int& nG, int& nP, int& q_head, int* status) {
+__device__ bool bin_reset(BEnv<W>& e, const BbxParams& p, const BbxLayout& L, int env, int& nG, int& nP, int& q_head, int* status,
+                          uint32_t& gen_state) {
+  if (p.gen) {                                       // the ideal is drawn here (gen_binomial): no queue, no host
+    const int npoly = (int)ldc(p.gen + 2), ncp = (int)ldc(p.gen + 4);
+    const uint32_t gflags = ldc(p.gen + 3);
+    const GenLanes GL = gen_lanes(p.gen);
+    uint32_t x = (uint32_t)uni((int)gen_state);
+    for (;;) {
+      const uint32_t x_start = x;
+      nG = 0; nP = 0;
+      for (int f = 0; f < npoly; f++) {
+        BTerm<W> t0, t1;
+        t0.c = 1;
+        if (!gen_binomial<W>(x, p.gen, GL, gflags, ncp, t0.m, t1.m, t1.c)) { *status = BBX_ST_GEN_FAIL; gen_state = x; return false; }
+        if (!bin_add_poly<W>(e, p, L, nG, nP, t0, t1, (int)m_deg(t0.m), status)) { gen_state = x_start; return false; }   // (a spill redoes this draw)
+      }
+      if (nP != 0) { gen_state = x; return true; }   // buchberger.cpp:313-314: redraw while the pair set is empty
+    }
+  }
   for (;;) {
     const uint32_t* slot;
     if (p.q.fixed) slot = p.q.words;
@@ -234,6 +252,7 @@ __device__ __forceinline__ void binom_body(const BbxParams& p, char* smem) {
   long long total_steps = ghdr->total_steps, total_adds = ghdr->total_additions, alg_bytes = ghdr->alg_bytes;
   const uint32_t agent_seed = (uint32_t)uni((int)ghdr->agent_seed);
   uint32_t std_rng = (uint32_t)uni((int)ghdr->std_rng);
+  uint32_t gen_state = ghdr->gen_rng;
   int budget = uni(ghdr->budget), rollout_pos = uni(ghdr->rollout_pos);
   int done_last = uni(ghdr->done_last);
   if (status == BBX_ST_STARVED || status == BBX_ST_SPILL) status = BBX_ST_OK;
@@ -256,7 +275,7 @@ __device__ __forceinline__ void binom_body(const BbxParams& p, char* smem) {
   for (;;) {
     if (status != BBX_ST_OK) break;
     if (need_reset) {
-      if (!bin_reset<W>(e, p, L, env, nG, nP, q_head, &status)) {
+      if (!bin_reset<W>(e, p, L, env, nG, nP, q_head, &status, gen_state)) {
         if (STAGED && (status == BBX_ST_G_FULL || status == BBX_ST_P_FULL)) { status = BBX_ST_SPILL; nG = 0; nP = 0; }
         break;
       }
@@ -406,6 +425,7 @@ __device__ __forceinline__ void binom_body(const BbxParams& p, char* smem) {
     BbxHdr* h = ghdr;
     h->nG = nG; h->nP = nP; h->arena_used = 0; h->status = status; h->need_reset = need_reset;
     h->q_head = q_head; h->t = t_agent; h->std_rng = std_rng; h->episode_steps = episode_steps; h->total_steps = total_steps;
+    h->gen_rng = gen_state;
     h->total_additions = total_adds; h->episodes = episodes; h->zero_reductions = zero_red; h->steps_done = steps_done;
     h->budget = budget; h->rollout_pos = rollout_pos; h->done_last = done_last; h->alg_bytes = alg_bytes;
     h->vret = vret; h->vdisc = vdisc;

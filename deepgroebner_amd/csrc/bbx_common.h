@@ -42,6 +42,7 @@ enum {
   BBX_ST_STARVED = 6,       // ideal queue empty: the environment waits for the host to refill
   BBX_ST_BAD_ACTION = 7,    // action index outside [0, |P|)
   BBX_ST_RUNAWAY = 9,       // a reduction exceeded 2^24 rounds (corrupt state guard; never seen in practice)
+  BBX_ST_GEN_FAIL = 10,     // the ideal generator failed (no two distinct monomials after 1000 trials: the reference throws)
   BBX_ST_SPILL = 8,         // transient: the state outgrew the LDS-resident class; the HBM-resident pass of the
                             // same launch sequence continues this environment
 };
@@ -59,7 +60,9 @@ struct BbxHdr {             // 128 bytes
   uint32_t std_rng;         // state of the minstd_rand0 engine behind the reference's seeded Random selection (buchberger.cpp:200-206)
   int64_t alg_bytes;        // algorithmic bytes moved so far (SURVEY.md 8d formula), for the roofline figure
   double vret, vdisc;       // value() rollouts: discounted return so far and the current discount (buchberger.cpp:248-252)
-  int32_t reserved[6];
+  uint32_t gen_rng;         // state of this environment's ideal generator engine (minstd_rand0) when ideals are drawn
+                            // on the device (BbxParams.gen != null); the host-side generators then stay unused
+  int32_t reserved[5];
 };
 
 struct BbxLayout {
@@ -125,10 +128,22 @@ struct BbxParams {
   int32_t accounting;       // 1: count algorithmic bytes per step (BbxHdr.alg_bytes); the lean fast kernel omits it
   int32_t pass;             // 0: primary launch; 1: follow-up launch serving only environments with work left
   const uint16_t* inv_table; // [32003] inverses in GF(32003) (L2-resident), binomial class
+  const uint32_t* gen;      // device-side generator table (BBX_GEN_* layout below) or null: ideals come from the queue
   int32_t* lite;            // [B][4] {status, q_head, budget, |P|}: what the host polls after a launch, or null
   BbxTraceRec* trace;       // [B, trace_stride] or null
   int32_t trace_stride;
 };
+
+// Device-side ideal generation (RandomBinomialIdealGenerator, ideals.cpp:156-201): one immutable table per batch, words:
+//   [0] n  [1] d  [2] s  [3] flags (1 homogeneous, 2 pure)  [4] #cumulative probabilities (0: degree is always 0)  [5] W
+//   [BBX_GEN_CP + 2 i]      cumulative probability i of the degree distribution (double, 64 entries, padded with +inf)
+//   [BBX_GEN_DEG + 8 i]     per degree i: offset of its monomials (in monomials), their number, the two constants of
+//                           libstdc++'s uniform_int_distribution(0, number - 1) — scaling, past — and floor(2^32 / scaling)
+//   [BBX_GEN_MONO + W j]    monomial j, packed (with degree slot), in the reference's enumeration order (ideals.cpp:39-64)
+#define BBX_GEN_CP 8
+#define BBX_GEN_DEG (BBX_GEN_CP + 128)
+#define BBX_GEN_MONO (BBX_GEN_DEG + 512)
+#define BBX_GEN_MAXDEG 63
 
 // position-keyed commutative hash used for parity traces (same definition in oracle/trace.py)
 static inline

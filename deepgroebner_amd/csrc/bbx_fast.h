@@ -33,6 +33,7 @@ struct BbxFastParams {
   int32_t B, nsteps, obs_rows, trace_stride, k, nvars, lim_G, lim_P;
   int32_t agent, auto_reset, set_budget, pass, obs_every_step, obs_fill, rewards_mode;
   int32_t* lite;                                      // [B][4] {status, q_head, budget, |P|} for the host, or null
+  const uint32_t* gen;                                // device-side ideal generator table or null (ideals come from the queue)
   unsigned long long* prof;                           // diagnostic build only: [B][8] cycle sums per phase
 };
 
@@ -111,6 +112,7 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
   int nG = uni(ghdr->nG), nP = uni(ghdr->nP);
   int status = uni(ghdr->status), need_reset = uni(ghdr->need_reset), q_head = uni(ghdr->q_head);
   int t_agent = uni(ghdr->t);
+  uint32_t gen_state = ghdr->gen_rng;                  // (a vector register: only the reset touches it)
   const uint32_t agent_seed = (uint32_t)uni((int)ghdr->agent_seed);
   int budget = uni(ghdr->budget), rollout_pos = uni(ghdr->rollout_pos), done_last = uni(ghdr->done_last);
   if (status == BBX_ST_STARVED || status == BBX_ST_SPILL) status = BBX_ST_OK;
@@ -357,6 +359,27 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
     if (need_reset) {                                      // BuchbergerEnv::reset from the next queued ideal(s)
       bool ok = true;
       const FColdParams cq = f_cold_params();
+      const uint32_t* gtab = cq->gen;
+      if (gtab) {                                          // draw the ideal here (see gen_binomial): no queue, no host
+        const int npoly = (int)ldc(gtab + 2), ncp = (int)ldc(gtab + 4);
+        const uint32_t gflags = ldc(gtab + 3);
+        const GenLanes GL = gen_lanes(gtab);
+        uint32_t x = (uint32_t)uni((int)gen_state);
+        for (;;) {
+          const uint32_t x_start = x;
+          nG = 0; nP = 0;
+          S.slmA.w[0] = S.slmA.w[1] = S.slmB.w[0] = S.slmB.w[1] = FSENT;
+          for (int fidx = 0; fidx < npoly; fidx++) {
+            if (nG + 1 > limG || nP + nG > limP) { status = BBX_ST_SPILL; ok = false; x = x_start; break; }   // redone from the same draw
+            BTerm<2> t0, t1;
+            t0.c = 1;
+            if (!gen_binomial<2>(x, gtab, GL, gflags, ncp, t0.m, t1.m, t1.c)) { status = BBX_ST_GEN_FAIL; ok = false; break; }
+            add_poly(t0, t1, (int)m_deg(t0.m), -1);
+          }
+          if (!ok || nP != 0) break;                       // buchberger.cpp:313-314: redraw while the pair set is empty
+        }
+        gen_state = x;
+      } else {
       const uint32_t q_slot_words = cq->q_slot_words, q_fixed = cq->q_fixed;
       for (;;) {
         const uint32_t* slot;
@@ -396,7 +419,8 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
         if (!q_fixed) q_head++;
         if (nP != 0 || q_fixed) break;                   // buchberger.cpp:313-314: redraw while the pair set is empty
       }
-      if (!ok) { if (status == BBX_ST_SPILL) { nG = 0; nP = 0; } break; }
+      }
+      if (!ok) { if (status != BBX_ST_STARVED) { nG = 0; nP = 0; } break; }
       need_reset = 0;
     }
     FSTAMP(0);                                             // 0: loop top / reset
@@ -583,6 +607,7 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
     rollout_pos = (cz->set_budget ? 0 : h->rollout_pos) + steps_done;
     h->nG = nG; h->nP = nP; h->arena_used = 0; h->status = status; h->need_reset = need_reset;
     h->q_head = q_head; h->t = t_agent; h->total_steps += steps_done; h->total_additions += adds;
+    h->gen_rng = gen_state;
     h->episodes += episodes; h->zero_reductions += zero_red; h->steps_done = steps_done;
     h->budget = budget; h->rollout_pos = rollout_pos; h->done_last = done_last; h->alg_bytes += bytes_total;
     if (cz->lite) *(int4*)(cz->lite + 4 * (size_t)env) = make_int4(status, q_head, budget, nP);

@@ -49,6 +49,9 @@ class IdealGen {
   virtual bool fixed() const { return false; }
   virtual int max_terms_hint() const = 0;                // upper bound on terms per generator (slot sizing)
   virtual int npolys() const = 0;
+  // the table a kernel needs to draw this generator's ideals itself (layout: BBX_GEN_* in bbx_common.h), W = words per
+  // packed monomial; false: this generator only runs on the host
+  virtual bool device_table(int W, std::vector<uint32_t>* out) const { (void)W; (void)out; return false; }
 };
 
 std::vector<HPoly> cyclic(int n);                         // ideals.cpp:16-36

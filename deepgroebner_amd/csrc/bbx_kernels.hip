@@ -1104,6 +1104,82 @@ __global__ __launch_bounds__(256) void bbx_step_prof_kernel(BbxParams p, unsigne
   step_body<W, false, false, true>(p, smem, prof);
 }
 
+// ------------------------------------------------------------------ ideal generation on the device
+// The reference draws every new ideal from std::default_random_engine (minstd_rand0) through libstdc++ 11's
+// uniform_int_distribution / discrete_distribution (generate_canonical<double, 53>: two engine draws) — restated here
+// from the same published algorithms as the host generators (bbx_ideals.cpp), operation for operation, so that a
+// seeded environment sees the same ideals wherever they are drawn.  Everything is wave-uniform: scalar registers, scalar
+// loads from the immutable table.  Doubles: plain IEEE operations, no contraction.
+__device__ __forceinline__ uint32_t gen_next(uint32_t& x) {                 // x <- 16807 x mod (2^31 - 1)
+  const uint64_t pr = (uint64_t)x * 16807u;
+  uint32_t s = (uint32_t)(pr & 0x7fffffffu) + (uint32_t)(pr >> 31);        // 2^31 = 1 (mod 2^31 - 1)
+  if (s >= 2147483647u) s -= 2147483647u;
+  x = s;
+  return s;
+}
+// ret / scaling for ret < 2^31 with magic = floor(2^32 / scaling): the estimate is at most one too small
+__device__ __forceinline__ uint32_t gen_div(uint32_t ret, uint32_t scaling, uint32_t magic) {
+  uint32_t q = (uint32_t)(((uint64_t)ret * magic) >> 32);
+  if (ret - q * scaling >= scaling) q++;
+  return q;
+}
+__device__ __forceinline__ uint32_t gen_uniform(uint32_t& x, uint32_t scaling, uint32_t past, uint32_t magic) {   // uniform_int_dist.h, downscaling
+  uint32_t ret;
+  do ret = gen_next(x) - 1u; while (ret >= past);
+  return gen_div(ret, scaling, magic);
+}
+__device__ __forceinline__ double gen_canonical(uint32_t& x) {             // random.tcc generate_canonical, k = 2
+#pragma clang fp contract(off)
+  const double R = 2147483646.0;
+  double sum = (double)(gen_next(x) - 1u);
+  sum = sum + (double)(gen_next(x) - 1u) * R;
+  double ret = sum / (R * R);
+  if (ret >= 1.0) ret = 0x1.fffffffffffffp-1;                               // nextafter(1, 0)
+  return ret;
+}
+// The small tables live one entry per lane for the duration of a reset (two coalesced loads): the cumulative
+// probabilities, so that std::lower_bound is a compare + ballot + popcount, and the per-degree rows, fetched with
+// v_readlane.  Only the chosen monomials themselves are loaded (scalar loads) while drawing.
+struct GenLanes { double cp; uint32_t off, scaling, past, magic; };
+__device__ __forceinline__ GenLanes gen_lanes(const uint32_t* g) {
+  const int lane = lane_id();
+  GenLanes r;
+  r.cp = *(const double*)(g + BBX_GEN_CP + 2 * lane);                       // +inf beyond the last entry
+  const uint4 row = *(const uint4*)(g + BBX_GEN_DEG + 8 * lane);
+  r.off = row.x; r.scaling = row.z; r.past = row.w; r.magic = g[BBX_GEN_DEG + 8 * lane + 4];
+  return r;
+}
+__device__ __forceinline__ int gen_degree(uint32_t& x, const GenLanes& L, int ncp) {   // discrete_distribution::operator()
+  if (ncp == 0) return 0;
+  const double pr = gen_canonical(x);
+  return __popcll(ballot64(L.cp < pr));                                     // std::lower_bound(cp, cp + ncp, pr) - cp
+}
+template <int W>
+__device__ __forceinline__ Mono<W> gen_choice(uint32_t& x, const uint32_t* g, const GenLanes& L, int d) {   // choice(bases[d], rng), ideals.h:68-73
+  const uint32_t scaling = (uint32_t)__builtin_amdgcn_readlane((int)L.scaling, d), past = (uint32_t)__builtin_amdgcn_readlane((int)L.past, d);
+  const uint32_t magic = (uint32_t)__builtin_amdgcn_readlane((int)L.magic, d), off = (uint32_t)__builtin_amdgcn_readlane((int)L.off, d);
+  const uint32_t j = off + gen_uniform(x, scaling, past, magic);
+  Mono<W> m;
+#pragma unroll
+  for (int i = 0; i < W; i++) m.w[i] = ldc(g + BBX_GEN_MONO + (size_t)j * W + i);
+  return m;
+}
+// one generator of the ideal: {1 * bigger monomial, c * smaller monomial} (ideals.cpp:168-201); false after 1000 trials
+template <int W>
+__device__ __forceinline__ bool gen_binomial(uint32_t& x, const uint32_t* g, const GenLanes& L, uint32_t flags, int ncp,
+                                             Mono<W>& lead, Mono<W>& tail, uint32_t& c) {
+  c = (flags & 2u) ? BBX_P - 1u : 1u + gen_uniform(x, 67104u, 2147462208u, 64004u);   // uniform_int_distribution(1, P - 1); 2^32 / 67104 = 64004
+  int d1, d2;
+  if (flags & 1u) d1 = d2 = gen_degree(x, L, ncp);
+  else { d1 = gen_degree(x, L, ncp); d2 = gen_degree(x, L, ncp); }
+  for (int trials = 0; trials < 1000; trials++) {
+    const Mono<W> m1 = gen_choice<W>(x, g, L, d1), m2 = gen_choice<W>(x, g, L, d2);
+    if (m_gt(m2, m1)) { lead = m2; tail = m1; return true; }
+    if (m_gt(m1, m2)) { lead = m1; tail = m2; return true; }
+  }
+  return false;
+}
+
 #include "bbx_binom.h"
 #include "bbx_fast.h"
 
@@ -1293,6 +1369,7 @@ static int launch_fast(const BbxParams* p, int blocks, int threads, int envs_per
   f.agent = p->agent; f.auto_reset = p->auto_reset; f.set_budget = p->set_budget; f.pass = p->pass;
   f.obs_every_step = p->obs_every_step; f.obs_fill = p->obs_fill; f.rewards_mode = p->rewards_mode;
   f.lite = p->lite;
+  f.gen = p->gen;
   const size_t lds = (size_t)envs_per_block * FLDS_BYTES;
   static unsigned long long* d_prof = nullptr;
   if (getenv("BBX_PROF") && !p->trace) {          // diagnostic: per-phase cycle sums, printed by bbx_prof_dump()
