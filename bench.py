@@ -157,7 +157,7 @@ def main():
             "metric": "env steps/sec (polynomial additions) on 3-20-10-weighted, batch=4096, 1/2/4/8 GPU",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": Wm,
             "ms_per_step": elapsed * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u16 exponents / u32 GF(32003)", "data": "synthetic",
+            "dtype": "u16 exponents / u32 GF(32003)", "data": "synthetic (random binomial ideals drawn on the device from per-environment seeds, inside the timed region)",
             "config": {"workload": "%s k=%d batch=%d/GPU random-hash agent auto-reset" % (args.dist, K_LEADS, B),
                        "global_batch": B * world, "steps_per_launch": chunk, "parallelism": "env-sharded x%d, no collectives" % world},
             "additions_per_s": additions / elapsed,

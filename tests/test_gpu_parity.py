@@ -320,6 +320,31 @@ def test_observation_width_sweep(dist):
             assert r == o.step(a)
 
 
+@pytest.mark.parametrize("dist", ["3-20-10-weighted", "3-20-10-uniform-consts", "3-8-6-maximum-pure-homog", "5-10-5-uniform",
+                                  "7-4-4-weighted-homog"])
+def test_device_drawn_ideals_equal_host_drawn(dist, monkeypatch):
+    """Binomial distributions are drawn inside the kernels (minstd_rand0 + libstdc++'s distributions restated on the
+    device); BBX_HOST_GEN=1 selects the host generators + ideal queue instead.  Same seeds, same rollout: identical
+    counters and final states, episode after episode (each reset consumes the next ideal of the stream)."""
+    from deepgroebner_amd import VecLeadMonomialsEnv
+    B, T = 6, (6000 if dist.startswith("5-") else 400)
+    envs = []
+    for host in (False, True):
+        if host:
+            monkeypatch.setenv("BBX_HOST_GEN", "1")
+        env = VecLeadMonomialsEnv(dist, batch=B, k=1)
+        env.seed(np.arange(B) * 7 + 3); env.seed_agent(np.arange(B) + 50); env.reset()
+        env.rollout("random", T, auto_reset=True)
+        envs.append(env)
+    a, b = envs
+    sa, sb = a.stats(), b.stats()
+    assert (sa[:, 2] >= 2).all(), "too few episodes to say anything about later ideals of the stream"
+    assert np.array_equal(sa[:, :5], sb[:, :5]) and np.array_equal(sa[:, 7], sb[:, 7])
+    for e in range(B):
+        ba, pa, oa = a.state(e); bb, pb, ob = b.state(e)
+        assert np.array_equal(_state_words(ba, pa, oa), _state_words(bb, pb, ob)), e
+
+
 def test_generator_failure_surfaces_when_the_ideal_is_needed():
     """1-variable binomials: the generator soon fails to draw two distinct monomials (the reference throws,
     ideals.cpp:190-192).  Ideals are drawn ahead of time here (a ring of 8 per environment), but the error must appear
