@@ -500,21 +500,24 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
         const uint32_t tcg = sx & 0xffffu, invg = sx >> 16;
         const uint32_t q0 = h0a - lg0, q1 = h0b - lg1;               // LT h / LT f
         const uint32_t c = mulmod(h0c, invg);
-        const uint32_t bc = negmod(mulmod(c, tcg));                  // 0 when f has no tail
-        const uint32_t b0 = tg0 + q0, b1 = tg1 + q1;
         const int fs = (int)(sy & 0xffffu) + (int)(q1 >> 16);
         hsug = fs > hsug ? fs : hsug;
         if (hsug > 65535) break;                                     // reported below; nothing has been modified
-        // h1 + b  (polynomials.cpp:148-177 on single optional terms)
-        const uint64_t kx = (((uint64_t)h1b << 32) | h1a) ^ 0x0000FFFFFFFFFFFFull;
-        const uint64_t ky = (((uint64_t)b1 << 32) | b0) ^ 0x0000FFFFFFFFFFFFull;
-        uint32_t n0c, n0a, n0b, n1c, n1a, n1b;
-        if (bc == 0) { n0c = h1c; n0a = h1a; n0b = h1b; n1c = 0; n1a = 0; n1b = 0; }
-        else if (h1c == 0 || ky > kx) { n0c = bc; n0a = b0; n0b = b1; n1c = h1c; n1a = h1a; n1b = h1b; }
-        else if (kx > ky) { n0c = h1c; n0a = h1a; n0b = h1b; n1c = bc; n1a = b0; n1b = b1; }
-        else { n0c = addmod(h1c, bc); n0a = h1a; n0b = h1b; n1c = 0; n1a = 0; n1b = 0; }   // a zero sum drops the term
-        if (ACCT) bytes += 8 * (found + 1) + 12 * (tcg ? 2 : 1) + 12 * (hn + (n0c ? 1 : 0) + (n1c ? 1 : 0));
-        h0c = n0c; h0a = n0a; h0b = n0b; h1c = n1c; h1a = n1a; h1b = n1b;
+        // the new term b = -(c tc) (tail f * q) takes the place of the cancelled lead term; then (b, h1) are put in
+        // order (polynomials.cpp:148-177 on single optional terms) — in the common case nothing moves
+        h0c = negmod(mulmod(c, tcg));                                // 0 when f has no tail
+        h0a = tg0 + q0; h0b = tg1 + q1;
+        if (ACCT) bytes += 8 * (found + 1) + 12 * (tcg ? 2 : 1) + 12 * hn;
+        if (h0c == 0) { h0c = h1c; h0a = h1a; h0b = h1b; h1c = 0; }
+        else if (h1c != 0) {
+          const uint64_t kx = (((uint64_t)h1b << 32) | h1a) ^ 0x0000FFFFFFFFFFFFull;
+          const uint64_t ky = (((uint64_t)h0b << 32) | h0a) ^ 0x0000FFFFFFFFFFFFull;
+          if (kx > ky) {                                             // the old tail leads: exchange
+            const uint32_t tc_ = h0c, ta_ = h0a, tb_ = h0b;
+            h0c = h1c; h0a = h1a; h0b = h1b; h1c = tc_; h1a = ta_; h1b = tb_;
+          } else if (kx == ky) { h0c = addmod(h0c, h1c); h1c = 0; }  // a zero sum drops the term (h becomes 0)
+        }
+        if (ACCT) bytes += 12 * ((h0c ? 1 : 0) + (h1c ? 1 : 0));
         nred++;                                        // (terminates: the lead monomial strictly decreases)
       } else {                                                       // r <- r + LT h ; h <- h - LT h
         if (ACCT) bytes += 8 * nG + 12 * (2 * hn - 1);
