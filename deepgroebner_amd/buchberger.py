@@ -116,15 +116,29 @@ class VecLeadMonomialsEnv:
     def _step_obs(self, actions, auto_reset):
         """One library call: the step (actions None: none) and the ragged observation block -> (flat [sum rows, cols],
         offsets [batch + 1]), fresh copies of the handle's pinned buffers."""
-        obs_p, off_p = C.POINTER(C.c_int32)(), C.POINTER(C.c_int32)()
-        _ffi.check(_ffi.lib().bbx_step_obs(self._h, _ffi.ptr(actions), int(auto_reset), _ffi.ptr(self._rewards),
-                                           _ffi.ptr(self._dones), _ffi.ptr(self.rows), C.byref(obs_p), C.byref(off_p)))
-        off = np.ctypeslib.as_array(off_p, shape=(self.batch + 1,)).copy()
+        io = self.__dict__.get("_io")
+        if io is None:                                       # ctypes plumbing built once per handle
+            io = self._io = {"obs": C.POINTER(C.c_int32)(), "off": C.POINTER(C.c_int32)(), "views": {},
+                             "act": np.zeros(self.batch, dtype=np.int32), "fn": _ffi.lib().bbx_step_obs}
+            io["args"] = (_ffi.ptr(self._rewards), _ffi.ptr(self._dones), _ffi.ptr(self.rows), C.byref(io["obs"]), C.byref(io["off"]))
+            io["pact"] = _ffi.ptr(io["act"])
+        if actions is not None:
+            io["act"][...] = actions
+        _ffi.check(io["fn"](self._h, io["pact"] if actions is not None else None, int(auto_reset), *io["args"]))
+
+        def view(ptr):                                       # numpy view of a pinned buffer, cached by its address
+            addr = C.cast(ptr, C.c_void_p).value
+            v = io["views"].get(addr)
+            if v is None:
+                if len(io["views"]) > 8:
+                    io["views"].clear()
+                v = io["views"][addr] = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_int32 * (1 << 28))).contents)
+            return v
+        off = view(io["off"])[:self.batch + 1].copy()
         total = int(off[-1])
         if total == 0:
             return np.zeros((0, self.cols), dtype=np.int32), off
-        flat = np.ctypeslib.as_array(obs_p, shape=(total * self.cols,)).copy().reshape(total, self.cols)
-        return flat, off
+        return view(io["obs"])[:total * self.cols].copy().reshape(total, self.cols), off
 
     def _as_list(self, flat, off):
         return [flat] if self.batch == 1 else np.split(flat, off[1:-1])
@@ -137,15 +151,13 @@ class VecLeadMonomialsEnv:
     def step(self, actions, auto_reset=False):
         """auto_reset=True: finished environments start their next episode inside the same call (VecEnv style).
         Returns (list of per-environment int32 [rows_e, cols] matrices, rewards, dones, infos)."""
-        a = np.ascontiguousarray(np.broadcast_to(np.asarray(actions, dtype=np.int32), (self.batch,)))
-        flat, off = self._step_obs(a, auto_reset)
+        flat, off = self._step_obs(actions, auto_reset)
         return self._as_list(flat, off), self._rewards.copy(), self._dones.astype(bool), [{} for _ in range(self.batch)]
 
     def step_ragged(self, actions, auto_reset=False):
         """step() for vectorised consumers: (flat int32 [sum rows, cols], offsets int32 [batch + 1], rewards, dones);
         environment e owns flat[offsets[e]:offsets[e + 1]]."""
-        a = np.ascontiguousarray(np.broadcast_to(np.asarray(actions, dtype=np.int32), (self.batch,)))
-        flat, off = self._step_obs(a, auto_reset)
+        flat, off = self._step_obs(actions, auto_reset)
         return flat, off, self._rewards.copy(), self._dones.astype(bool)
 
     def rollout(self, agent="random", nsteps=1, auto_reset=True):

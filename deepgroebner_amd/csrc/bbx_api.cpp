@@ -107,6 +107,11 @@ struct bbx_batch {
   char* d_out = nullptr; int32_t* d_lite = nullptr; double* d_rewards = nullptr; int32_t* d_rows = nullptr; uint8_t* d_dones = nullptr;
   char* h_io = nullptr; size_t io_bytes = 0;      // pinned mirror of d_out
   int32_t* h_act = nullptr;                       // pinned staging of host actions
+  // small batches (the single-environment drop-in): the kernels read the actions from and write their outputs and the
+  // observation straight into pinned host memory — no copy calls on the latency path, one stream synchronisation per step
+  bool zero_copy = false, zc_active = false;
+  char* zc_io_dev = nullptr; int32_t* zc_act_dev = nullptr;     // device-side addresses of h_io / h_act
+  int32_t* h_zobs = nullptr; int32_t* zc_obs_dev = nullptr; size_t zobs_rows_cap = 0;
   // ragged observations (bbx_step_obs): device offsets [B+1] + packed rows, and their pinned mirror handed to the caller
   int32_t* d_obs_off = nullptr; int32_t* d_obs_packed = nullptr; int32_t* h_obs = nullptr; size_t obs_packed_cap = 0;
   uint32_t* h_stage = nullptr; uint32_t* d_stage = nullptr; size_t stage_words = 0;   // queue refill staging (pinned / device)
@@ -339,14 +344,19 @@ int alloc_io(bbx_batch* b, int batch) {
   HIPCHK(hipHostMalloc((void**)&b->h_io, b->io_bytes, hipHostMallocDefault));
   HIPCHK(hipHostMalloc((void**)&b->h_act, (size_t)batch * sizeof(int32_t), hipHostMallocDefault));
   memset(b->h_io, 0, b->io_bytes);
+  b->zero_copy = batch <= 8 && !getenv("BBX_NO_ZERO_COPY");
+  if (b->zero_copy) {
+    HIPCHK(hipHostGetDevicePointer((void**)&b->zc_io_dev, b->h_io, 0));
+    HIPCHK(hipHostGetDevicePointer((void**)&b->zc_act_dev, b->h_act, 0));
+  }
   return BBX_OK;
 }
 
 // fetch the block the kernels of the last launch left behind (status words and the host-API outputs) in one copy
 int read_lite(bbx_batch* b, hipStream_t stream) {
   b->h_lite.resize((size_t)b->B * 4);
-  HIPCHK(hipMemcpyAsync(b->h_io, b->d_out, b->io_bytes, hipMemcpyDeviceToHost, stream));
-  HIPCHK(hipStreamSynchronize(stream));
+  if (!b->zc_active) HIPCHK(hipMemcpyAsync(b->h_io, b->d_out, b->io_bytes, hipMemcpyDeviceToHost, stream));
+  HIPCHK(hipStreamSynchronize(stream));              // (zero-copy launches wrote h_io themselves)
   memcpy(b->h_lite.data(), b->h_io, (size_t)b->B * 16);
   for (int e = 0; e < b->B; e++) b->h_head[e] = b->h_lite[(size_t)e * 4 + 1];
   return BBX_OK;
@@ -396,6 +406,14 @@ int launch(bbx_batch* b, BbxParams& p, hipStream_t stream) {
   b->last_stream = stream;
   b->in_flight = true;
   return enqueue(b, p, false, stream);
+}
+
+// zero-copy launches: outputs and status words go straight to the pinned host block
+void zc_outputs(bbx_batch* b, BbxParams* p) {
+  p->lite = (int32_t*)b->zc_io_dev;
+  p->rewards = (double*)(b->zc_io_dev + (size_t)b->B * 16);
+  p->rows = (int32_t*)(b->zc_io_dev + (size_t)b->B * 24);
+  p->dones = (uint8_t*)(b->zc_io_dev + (size_t)b->B * 28);
 }
 
 // the outputs of a host-API launch: already on the host (finish() fetched the whole block)
@@ -608,6 +626,7 @@ void bbx_destroy(bbx_batch* b) {
   if (b->h_stage) (void)hipHostFree(b->h_stage);
   if (b->d_stage) (void)hipFree(b->d_stage);
   if (b->d_gen) (void)hipFree(b->d_gen);
+  if (b->h_zobs) (void)hipHostFree(b->h_zobs);
   if (b->h_obs) (void)hipHostFree(b->h_obs);
   if (b->d_obs_off) (void)hipFree(b->d_obs_off);
   if (b->d_obs_packed) (void)hipFree(b->d_obs_packed);
@@ -753,13 +772,16 @@ static int step_host(bbx_batch* b, const int32_t* actions, double* rewards, uint
   if (!b || !actions) return fail(BBX_E_ARG, "null argument");
   HIPCHK(hipSetDevice(b->device));
   memcpy(b->h_act, actions, (size_t)b->B * sizeof(int32_t));
-  HIPCHK(hipMemcpyAsync(b->d_actions, b->h_act, (size_t)b->B * sizeof(int32_t), hipMemcpyHostToDevice, 0));
   BbxParams p; fill_params(b, &p);
-  p.nsteps = 1; p.set_budget = 1; p.agent = BBX_AGENT_EXTERNAL; p.auto_reset = auto_reset; p.actions = b->d_actions;
-  p.rewards = b->d_rewards; p.dones = b->d_dones; p.rows = b->d_rows;
+  p.nsteps = 1; p.set_budget = 1; p.agent = BBX_AGENT_EXTERNAL; p.auto_reset = auto_reset;
+  if (b->zero_copy) { p.actions = b->zc_act_dev; zc_outputs(b, &p); b->zc_active = true; }
+  else {
+    HIPCHK(hipMemcpyAsync(b->d_actions, b->h_act, (size_t)b->B * sizeof(int32_t), hipMemcpyHostToDevice, 0));
+    p.actions = b->d_actions; p.rewards = b->d_rewards; p.dones = b->d_dones; p.rows = b->d_rows;
+  }
   int rc = launch(b, p, 0);
-  if (rc) return rc;
-  rc = finish(b, 0);
+  if (!rc) rc = finish(b, 0);
+  b->zc_active = false;
   if (rc) return rc;
   return copy_out(b, rewards, dones, rows);
 }
@@ -787,32 +809,55 @@ int bbx_step_obs(bbx_batch* b, const int32_t* actions, int auto_reset, double* r
   if (!b || !obs || !offsets) return fail(BBX_E_ARG, "null argument");
   HIPCHK(hipSetDevice(b->device));
   const int cols = 2 * b->nvars * b->k;
-  int rc = ensure_obs_block(b, b->obs_rows_cap ? (int)b->obs_rows_cap : 128);
-  if (rc) return rc;
-  if (!b->d_obs_off) HIPCHK(hipMalloc((void**)&b->d_obs_off, ((size_t)b->B + 1) * sizeof(int32_t)));
+  const bool zc = b->zero_copy;
+  int rc;
+  if (zc) {
+    if (!b->h_zobs) {
+      b->zobs_rows_cap = 128;
+      HIPCHK(hipHostMalloc((void**)&b->h_zobs, (size_t)b->B * b->zobs_rows_cap * cols * sizeof(int32_t), hipHostMallocDefault));
+      HIPCHK(hipHostGetDevicePointer((void**)&b->zc_obs_dev, b->h_zobs, 0));
+    }
+  } else {
+    rc = ensure_obs_block(b, b->obs_rows_cap ? (int)b->obs_rows_cap : 128);
+    if (rc) return rc;
+    if (!b->d_obs_off) HIPCHK(hipMalloc((void**)&b->d_obs_off, ((size_t)b->B + 1) * sizeof(int32_t)));
+  }
   BbxParams p; fill_params(b, &p);
   p.set_budget = 1; p.agent = BBX_AGENT_EXTERNAL; p.auto_reset = auto_reset ? 1 : 0;
-  p.rewards = b->d_rewards; p.dones = b->d_dones; p.rows = b->d_rows;
+  if (zc) zc_outputs(b, &p); else { p.rewards = b->d_rewards; p.dones = b->d_dones; p.rows = b->d_rows; }
   if (actions) {
     memcpy(b->h_act, actions, (size_t)b->B * sizeof(int32_t));
-    HIPCHK(hipMemcpyAsync(b->d_actions, b->h_act, (size_t)b->B * sizeof(int32_t), hipMemcpyHostToDevice, 0));
-    p.nsteps = 1; p.actions = b->d_actions;
+    if (zc) p.actions = b->zc_act_dev;
+    else {
+      HIPCHK(hipMemcpyAsync(b->d_actions, b->h_act, (size_t)b->B * sizeof(int32_t), hipMemcpyHostToDevice, 0));
+      p.actions = b->d_actions;
+    }
+    p.nsteps = 1;
   } else p.nsteps = 0;                                      // observation of the current state only
   for (int attempt = 0;; attempt++) {
-    p.obs = b->d_obs; p.obs_rows = (int)b->obs_rows_cap; p.obs_fill = 0; p.obs_every_step = 0;
+    const size_t cap = zc ? b->zobs_rows_cap : b->obs_rows_cap;
+    p.obs = zc ? b->zc_obs_dev : b->d_obs; p.obs_rows = (int)cap; p.obs_fill = 0; p.obs_every_step = 0;
     if (attempt) { p.nsteps = 0; p.actions = nullptr; }     // the step is done: only rewrite the observation
+    b->zc_active = zc;
     rc = launch(b, p, 0);
-    if (rc) return rc;
-    rc = finish(b, 0);
+    if (!rc) rc = finish(b, 0);
+    b->zc_active = false;
     if (rc) return rc;
     if (!attempt) copy_out(b, rewards, dones, rows);
     int maxr = 0; size_t total = 0;
     for (int e = 0; e < b->B; e++) { const int r = b->h_lite[(size_t)e * 4 + 3]; maxr = r > maxr ? r : maxr; total += (size_t)r; }
-    if ((size_t)maxr > b->obs_rows_cap) {                   // some pair set outgrew the block: enlarge it and write again
-      int cap = (int)b->obs_rows_cap;
-      while (cap < maxr) cap *= 2;
-      rc = ensure_obs_block(b, cap);
-      if (rc) return rc;
+    if ((size_t)maxr > cap) {                               // some pair set outgrew the block: enlarge it and write again
+      size_t ncap = cap;
+      while (ncap < (size_t)maxr) ncap *= 2;
+      if (zc) {
+        (void)hipHostFree(b->h_zobs); b->h_zobs = nullptr;
+        HIPCHK(hipHostMalloc((void**)&b->h_zobs, (size_t)b->B * ncap * cols * sizeof(int32_t), hipHostMallocDefault));
+        HIPCHK(hipHostGetDevicePointer((void**)&b->zc_obs_dev, b->h_zobs, 0));
+        b->zobs_rows_cap = ncap;
+      } else {
+        rc = ensure_obs_block(b, (int)ncap);
+        if (rc) return rc;
+      }
       continue;
     }
     const size_t need = (total ? total : 1) * (size_t)cols + (size_t)b->B + 1;
@@ -820,7 +865,7 @@ int bbx_step_obs(bbx_batch* b, const int32_t* actions, int auto_reset, double* r
       if (b->d_obs_packed) (void)hipFree(b->d_obs_packed);
       if (b->h_obs) (void)hipHostFree(b->h_obs);
       b->d_obs_packed = nullptr; b->h_obs = nullptr; b->obs_packed_cap = 0;
-      HIPCHK(hipMalloc((void**)&b->d_obs_packed, need * 2 * sizeof(int32_t)));
+      if (!zc) HIPCHK(hipMalloc((void**)&b->d_obs_packed, need * 2 * sizeof(int32_t)));
       HIPCHK(hipHostMalloc((void**)&b->h_obs, need * 2 * sizeof(int32_t), hipHostMallocDefault));
       b->obs_packed_cap = need * 2;
     }
@@ -828,7 +873,11 @@ int bbx_step_obs(bbx_batch* b, const int32_t* actions, int auto_reset, double* r
     // just fetched (the device computes the same ones for its pack kernel)
     b->h_obs[0] = 0;
     for (int e = 0; e < b->B; e++) b->h_obs[e + 1] = b->h_obs[e] + b->h_lite[(size_t)e * 4 + 3];
-    if (total) {
+    if (total && zc) {                                      // the padded block is already in host memory: squeeze it here
+      for (int e = 0; e < b->B; e++)
+        memcpy(b->h_obs + b->B + 1 + (size_t)b->h_obs[e] * cols, b->h_zobs + (size_t)e * cap * cols,
+               (size_t)(b->h_obs[e + 1] - b->h_obs[e]) * cols * sizeof(int32_t));
+    } else if (total) {
       const int32_t* src = b->d_obs;                         // one environment: its padded block IS the ragged one
       if (b->B > 1) {
         int lrc = bbx_launch_obs_pack(b->d_obs, (int)b->obs_rows_cap, cols, b->d_rows, b->B, b->d_obs_off, b->d_obs_packed, 0);

@@ -14,3 +14,13 @@ while n < 3000:
         s = env.reset()
 t1 = time.perf_counter()
 print("single-environment drop-in: %.1f us per step+observation, %.0f steps/s" % ((t1 - t0) / n * 1e6, n / (t1 - t0)))
+import ctypes as C
+from deepgroebner_amd import _ffi
+L = _ffi.lib(); v = env._vec
+act = np.zeros(1, dtype=np.int32); obs_p, off_p = C.POINTER(C.c_int32)(), C.POINTER(C.c_int32)()
+args = (v._h, _ffi.ptr(act), 1, _ffi.ptr(v._rewards), _ffi.ptr(v._dones), _ffi.ptr(v.rows), C.byref(obs_p), C.byref(off_p))
+t0 = time.perf_counter()
+for _ in range(3000):
+    L.bbx_step_obs(*args)
+t1 = time.perf_counter()
+print("  of which the library call itself (bbx_step_obs, auto-reset): %.1f us" % ((t1 - t0) / 3000 * 1e6))
