@@ -24,3 +24,12 @@ for _ in range(3000):
     L.bbx_step_obs(*args)
 t1 = time.perf_counter()
 print("  of which the library call itself (bbx_step_obs, auto-reset): %.1f us" % ((t1 - t0) / 3000 * 1e6))
+env = CLeadMonomialsEnv("3-20-10-weighted", k=2); env.seed(123); env.reset()
+n = 0; t0 = time.perf_counter()
+while n < 300:
+    val = env.value("degree", 0.99)
+    s, r, d, _ = env.step(0); n += 1
+    if d:
+        env.reset()
+t1 = time.perf_counter()
+print("value('degree') + step, as pg.py:461-465 calls them with --value_model degree: %.1f us per step" % ((t1 - t0) / n * 1e6))
