@@ -1,5 +1,5 @@
 """Throughput of the other BASELINE configs (not the contract bench line): steps/s on one GPU next to the
-compiled reference on a sample of the same environments.  usage: bench_configs.py DIST BATCH STEPS [K_LEADS] [CPU_ENVS] [OBS_ROWS]"""
+compiled reference on a sample of the same environments.  usage: bench_configs.py DIST BATCH STEPS [K_LEADS] [CPU_ENVS] [OBS_ROWS] [WIDE_WAVES]"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -11,6 +11,8 @@ dist, B, T = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 k = int(sys.argv[4]) if len(sys.argv) > 4 else 2
 cpu_envs = int(sys.argv[5]) if len(sys.argv) > 5 else 4
 caps = {"queue_slots": max(8, T // 8 + 8)}
+if len(sys.argv) > 7:
+    caps["wide_waves"] = int(sys.argv[7])
 torch.cuda.init()
 env = VecLeadMonomialsEnv(dist, batch=B, k=k, caps=caps)
 env.seed(np.arange(B) + 1000); env.seed_agent(np.arange(B)); env.reset()
