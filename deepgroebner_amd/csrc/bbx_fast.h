@@ -54,6 +54,12 @@ __device__ __forceinline__ uint32_t f_wave_min(uint32_t x) {
 __device__ __forceinline__ uint32_t f_fetch(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_ds_bpermute(l << 2, (int)v); }
 __device__ __forceinline__ M2 f_fetch(const M2& v, int l) { M2 r; r.w[0] = f_fetch(v.w[0], l); r.w[1] = f_fetch(v.w[1], l); return r; }
 __device__ __forceinline__ uint2 f_fetch(const uint2& v, int l) { return make_uint2(f_fetch(v.x, l), f_fetch(v.y, l)); }
+// lane bit of a wave-uniform 64-bit mask as a per-lane predicate (the mask IS an exec-style lane mask: no shifts), and
+// the number of set bits below the lane (v_mbcnt pair on the scalar mask)
+__device__ __forceinline__ bool f_lane_in(uint64_t mask) { return __builtin_amdgcn_inverse_ballot_w64(mask); }
+__device__ __forceinline__ int f_prefix(uint64_t mask) {
+  return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
 __device__ __forceinline__ uint64_t f_u64(const M2& m) { return ((uint64_t)m.w[1] << 32) | m.w[0]; }
 __device__ __forceinline__ uint64_t f_lowmask(int n) { return n >= 64 ? ~0ull : ((1ull << n) - 1ull); }   // n in [0,64]
 
@@ -276,7 +282,7 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
       const uint32_t dA = LA.w[1] >> 16, dB = LB.w[1] >> 16;
       uint64_t candA = validA, candB = validB;
       while (candA | candB) {
-        const bool inA = (candA >> lane) & 1, inB = (candB >> lane) & 1;
+        const bool inA = f_lane_in(candA), inB = f_lane_in(candB);
         uint32_t dm = inA ? dA : 0xFFFFFFFFu;
         if (candB) { const uint32_t t = inB ? dB : 0xFFFFFFFFu; dm = t < dm ? t : dm; }
         const uint32_t dmin = f_wave_min(dm);
@@ -310,16 +316,16 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
       const bool eqj = ((a0 ^ c0) | ((a1 ^ c1) & 0xffffu)) == 0;
       const bool keep = valid && k != skip && !(fdiv && !eqi && !eqj);
       const uint64_t mask = ballot64(keep);
-      if (keep) pairs[w + prefix_of(mask, lane)] = pr;
+      if (keep) pairs[w + f_prefix(mask)] = pr;
       w += __popcll(mask);
     }
     nP = w;
     {
       // (92) ascending i, appended behind the surviving old pairs (98)
-      if ((emitA >> lane) & 1) pairs[nP + prefix_of(emitA, lane)] = (uint32_t)lane | ((uint32_t)g << 16);
+      if (f_lane_in(emitA)) pairs[nP + f_prefix(emitA)] = (uint32_t)lane | ((uint32_t)g << 16);
       nP += __popcll(emitA);
       if (emitB) {
-        if ((emitB >> lane) & 1) pairs[nP + prefix_of(emitB, lane)] = (uint32_t)(lane + 64) | ((uint32_t)g << 16);
+        if (f_lane_in(emitB)) pairs[nP + f_prefix(emitB)] = (uint32_t)(lane + 64) | ((uint32_t)g << 16);
         nP += __popcll(emitB);
       }
     }
