@@ -39,7 +39,7 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
 }
-__device__ __forceinline__ uint64_t ballot64(bool p) { return __ballot(p); }
+__device__ __forceinline__ uint64_t ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }   // (not __ballot: that one materialises the predicate in a VGPR first)
 __device__ __forceinline__ int prefix_of(uint64_t mask, int lane) { return __popcll(mask & ((1ull << lane) - 1ull)); }
 __device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
 // Load from memory that no kernel writes (the ideal queue: filled by the host between launches) through the constant
