@@ -332,10 +332,16 @@ __device__ int merge_tile(const PView<W>& A, const PView<W>& B, int i0, int j0, 
     const int q = lane + u * WAVE;
     const bool isa = q < nat;
     const int src = q < nt ? (isa ? i0 + q : j0 + q - nat) : 0;
-    const Mono<W> ma = A.m[isa ? src : 0], mb = B.m[isa ? 0 : src];
-    const uint32_t ca = A.c[isa ? src : 0], cb = B.c[isa ? 0 : src];
-    mine[u] = isa ? m_mul(ma, A.shift) : m_mul(mb, B.shift);
-    mc[u] = isa ? mulmod(ca, A.scale) : mulmod(cb, B.scale);
+    // one load per lane from whichever polynomial the position belongs to (not one from each with a dummy index)
+    const Mono<W>* pm = isa ? A.m + src : B.m + src;
+    const uint16_t* pc = isa ? A.c + src : B.c + src;
+    const Mono<W> mx = *pm;
+    const uint32_t cx = *pc;
+    Mono<W> sh; uint32_t sc = isa ? A.scale : B.scale;
+#pragma unroll
+    for (int i = 0; i < W; i++) sh.w[i] = isa ? A.shift.w[i] : B.shift.w[i];
+    mine[u] = m_mul(mx, sh);
+    mc[u] = mulmod(cx, sc);
     lo2[u] = 0;
   }
 #pragma unroll
