@@ -263,7 +263,8 @@ __device__ int wave_merge(const PView<W>& A, const PView<W>& B, Mono<W>* tm, uin
 // are searched at once, one per lane), each tile's two contiguous input ranges are streamed into LDS with coalesced
 // loads, ranks are computed against LDS, holes (cancelled or combined terms) are squeezed out with ballots and the
 // tile is appended to the output — no staging pass through memory.
-constexpr int MT = 256;                                   // virtual positions per tile
+constexpr int MT = 184;                                   // virtual positions per tile: MT + 8 = 3 x 64, i.e. exactly three
+                                                          // terms per lane (256 left a mostly empty fifth round per lane)
 template <int W> __host__ __device__ constexpr int merge_lds_bytes() { return 2 * (MT + 8) * (4 * W + 2); }
 
 // merge-path partition: lane l returns (i, j), i + j = d = (t0 + l) * MT (clamped), such that A[0..i) and B[0..j) are
@@ -420,7 +421,7 @@ __device__ int wave_merge_tiled(const PView<W>& A, const PView<W>& B, char* lds,
 // of a workgroup (the leader) runs the ordinary step code; the other waves park at a workgroup barrier and are woken
 // for every long merge: tiles are dealt round-robin to all waves, each wave squeezes its tiles into the staging
 // buffer, then (second barrier) copies them to their final offsets, then (third barrier) the leader goes on alone.
-constexpr int COOP_MAXT = 510;                             // tiles per cooperative merge (130k terms at MT = 256)
+constexpr int COOP_MAXT = 510;                             // tiles per cooperative merge (94k terms at MT = 184)
 struct CoopCmd {
   int cmd;                                                 // 1 = merge, 2 = exit
   int ntiles, ocap, overflow;
