@@ -378,6 +378,7 @@ int finish(bbx_batch* b, hipStream_t stream) {
         b->in_flight = false;
         return fail(BBX_E_GENERATOR, "%s", msg.c_str());
       }
+      if (st == BBX_ST_GEN_ZERO) { b->in_flight = false; return fail(BBX_E_GENERATOR, "random polynomial cancelled to zero (undefined in the reference)"); }
       if (st == BBX_ST_GEN_FAIL) { b->in_flight = false; return fail(BBX_E_GENERATOR, "failed to generate two distinct random monomials after 1000 trials"); }
       if (st == BBX_ST_STARVED || st == BBX_ST_SPILL) again = true;
       else if (st == BBX_ST_BAD_ACTION) return fail(BBX_E_ACTION, "environment %d: %s", e, status_name(st));
@@ -529,9 +530,9 @@ int create_common(std::unique_ptr<bbx::IdealGen> proto, int nvars_obs, int elimi
   }
   int lrc = bbx_launch_init(b->d_recs, b->L.rec_bytes, batch, nullptr, 0);
   if (lrc) return fail(BBX_E_DEVICE, "init launch failed: %s", hipGetErrorString((hipError_t)lrc));
-  // binomial distributions: draw the ideals on the device (same seeded streams; see gen_binomial in bbx_kernels.hip).
-  // Not with sort_input (the generators would have to be sorted first), ideal lists, or the general class.
-  if (!b->fixed && !list && b->binom && !sort_input && !getenv("BBX_HOST_GEN")) {
+  // random distributions: draw the ideals on the device (same seeded streams; see gen_binomial / gen_polynomial in
+  // bbx_kernels.hip).  Not with sort_input (the generators would have to be sorted first) or ideal lists.
+  if (!b->fixed && !list && !sort_input && !getenv("BBX_HOST_GEN")) {
     std::vector<uint32_t> table;
     if (b->gens[0]->device_table(b->W, &table)) {
       HIPCHK(hipMalloc((void**)&b->d_gen, table.size() * sizeof(uint32_t)));

@@ -43,6 +43,7 @@ enum {
   BBX_ST_BAD_ACTION = 7,    // action index outside [0, |P|)
   BBX_ST_RUNAWAY = 9,       // a reduction exceeded 2^24 rounds (corrupt state guard; never seen in practice)
   BBX_ST_GEN_FAIL = 10,     // the ideal generator failed (no two distinct monomials after 1000 trials: the reference throws)
+  BBX_ST_GEN_ZERO = 11,     // a random polynomial cancelled to zero (undefined in the reference)
   BBX_ST_SPILL = 8,         // transient: the state outgrew the LDS-resident class; the HBM-resident pass of the
                             // same launch sequence continues this environment
 };
@@ -135,7 +136,8 @@ struct BbxParams {
 };
 
 // Device-side ideal generation (RandomBinomialIdealGenerator, ideals.cpp:156-201): one immutable table per batch, words:
-//   [0] n  [1] d  [2] s  [3] flags (1 homogeneous, 2 pure)  [4] #cumulative probabilities (0: degree is always 0)  [5] W
+//   [0] n  [1] d  [2] s  [3] flags (1 homogeneous, 2 pure, 4 polynomial distribution = RandomIdealGenerator, ideals.cpp:203-231)
+//   [4] #cumulative probabilities (0: degree is always 0)  [5] W  [6..7] exp(-lambda) of the polynomial distribution (double)
 //   [BBX_GEN_CP + 2 i]      cumulative probability i of the degree distribution (double, 64 entries, padded with +inf)
 //   [BBX_GEN_DEG + 8 i]     per degree i: offset of its monomials (in monomials), their number, the two constants of
 //                           libstdc++'s uniform_int_distribution(0, number - 1) — scaling, past — and floor(2^32 / scaling)

@@ -292,6 +292,40 @@ class RandomBase : public IdealGen {
   int nvars() const override { return n_; }
   int npolys() const override { return s_; }
  protected:
+  bool base_table(int W, std::vector<uint32_t>* out, uint32_t kind_flags, double lm_thr) const {
+    const int d = (int)bases_->size() - 1, slots = 2 * W;
+    if (d > BBX_GEN_MAXDEG || n_ > slots - 1 || degree_.cp.size() > 64) return false;
+    size_t total = 0;
+    for (auto& B : *bases_) total += B.size();
+    if (total > (size_t)1 << 22) return false;
+    std::vector<uint32_t>& t = *out;
+    t.assign(BBX_GEN_MONO + total * W, 0u);
+    t[0] = (uint32_t)n_; t[1] = (uint32_t)d; t[2] = (uint32_t)s_; t[3] = (homogeneous_ ? 1u : 0u) | kind_flags;
+    memcpy(&t[6], &lm_thr, 8);
+    t[4] = (uint32_t)degree_.cp.size(); t[5] = (uint32_t)W;
+    for (size_t i = 0; i < 64; i++) {
+      const double v = i < degree_.cp.size() ? degree_.cp[i] : HUGE_VAL;
+      memcpy(&t[BBX_GEN_CP + 2 * i], &v, 8);
+    }
+    size_t at = 0;
+    for (int i = 0; i <= d; i++) {
+      const auto& B = (*bases_)[i];
+      // uniform_int_distribution<int>(0, len - 1) on minstd_rand0: scaling = (2^31 - 3) / len, past = len * scaling
+      const uint64_t urngrange = kRngMax - kRngMin, len = B.size();
+      const uint64_t scaling = urngrange / len, past = len * scaling;
+      t[BBX_GEN_DEG + 8 * i] = (uint32_t)at; t[BBX_GEN_DEG + 8 * i + 1] = (uint32_t)len;
+      t[BBX_GEN_DEG + 8 * i + 2] = (uint32_t)scaling; t[BBX_GEN_DEG + 8 * i + 3] = (uint32_t)past;
+      t[BBX_GEN_DEG + 8 * i + 4] = (uint32_t)((1ull << 32) / scaling);
+      for (auto& e : B) {
+        uint32_t s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int v = 0; v < n_; v++) s[v] = (uint32_t)e[v];
+        s[slots - 1] = (uint32_t)i;
+        for (int w = 0; w < W; w++) t[BBX_GEN_MONO + at * W + w] = s[2 * w] | (s[2 * w + 1] << 16);
+        at++;
+      }
+    }
+    return true;
+  }
   HTerm choice(int d, int c) {            // choice(): fresh uniform_int_distribution(0, len-1), ideals.h:68-73
     const auto& B = (*bases_)[d];
     return make_term(c, B[uniform_int(rng_, 0, (int)B.size() - 1)]);
@@ -332,39 +366,7 @@ class BinomialGen : public RandomBase {   // ideals.cpp:156-201
   }
   std::unique_ptr<IdealGen> clone() const override { return std::make_unique<BinomialGen>(*this); }
   int max_terms_hint() const override { return 2; }
-  bool device_table(int W, std::vector<uint32_t>* out) const override {
-    const int d = (int)bases_->size() - 1, slots = 2 * W;
-    if (d > BBX_GEN_MAXDEG || n_ > slots - 1 || degree_.cp.size() > 64) return false;
-    size_t total = 0;
-    for (auto& B : *bases_) total += B.size();
-    if (total > (size_t)1 << 22) return false;
-    std::vector<uint32_t>& t = *out;
-    t.assign(BBX_GEN_MONO + total * W, 0u);
-    t[0] = (uint32_t)n_; t[1] = (uint32_t)d; t[2] = (uint32_t)s_; t[3] = (homogeneous_ ? 1u : 0u) | (pure_ ? 2u : 0u);
-    t[4] = (uint32_t)degree_.cp.size(); t[5] = (uint32_t)W;
-    for (size_t i = 0; i < 64; i++) {
-      const double v = i < degree_.cp.size() ? degree_.cp[i] : HUGE_VAL;
-      memcpy(&t[BBX_GEN_CP + 2 * i], &v, 8);
-    }
-    size_t at = 0;
-    for (int i = 0; i <= d; i++) {
-      const auto& B = (*bases_)[i];
-      // uniform_int_distribution<int>(0, len - 1) on minstd_rand0: scaling = (2^31 - 3) / len, past = len * scaling
-      const uint64_t urngrange = kRngMax - kRngMin, len = B.size();
-      const uint64_t scaling = urngrange / len, past = len * scaling;
-      t[BBX_GEN_DEG + 8 * i] = (uint32_t)at; t[BBX_GEN_DEG + 8 * i + 1] = (uint32_t)len;
-      t[BBX_GEN_DEG + 8 * i + 2] = (uint32_t)scaling; t[BBX_GEN_DEG + 8 * i + 3] = (uint32_t)past;
-      t[BBX_GEN_DEG + 8 * i + 4] = (uint32_t)((1ull << 32) / scaling);
-      for (auto& e : B) {
-        uint32_t s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int v = 0; v < n_; v++) s[v] = (uint32_t)e[v];
-        s[slots - 1] = (uint32_t)i;
-        for (int w = 0; w < W; w++) t[BBX_GEN_MONO + at * W + w] = s[2 * w] | (s[2 * w + 1] << 16);
-        at++;
-      }
-    }
-    return true;
-  }
+  bool device_table(int W, std::vector<uint32_t>* out) const override { return base_table(W, out, pure_ ? 2u : 0u, 0.0); }
  private:
   bool pure_;
 };
@@ -396,6 +398,7 @@ class RandomGen : public RandomBase {     // ideals.cpp:203-231
   }
   std::unique_ptr<IdealGen> clone() const override { return std::make_unique<RandomGen>(*this); }
   int max_terms_hint() const override { return 64; }
+  bool device_table(int W, std::vector<uint32_t>* out) const override { return lam_ < 12.0 && base_table(W, out, 4u, lm_thr_); }
  private:
   double lam_, lm_thr_;
 };

@@ -510,6 +510,91 @@ __device__ void coop_helper_loop(CoopCmd* cc, char* lds_tile, int wave, int nwav
   }
 }
 
+// ------------------------------------------------------------------ ideal generation on the device
+// The reference draws every new ideal from std::default_random_engine (minstd_rand0) through libstdc++ 11's
+// uniform_int_distribution / discrete_distribution (generate_canonical<double, 53>: two engine draws) — restated here
+// from the same published algorithms as the host generators (bbx_ideals.cpp), operation for operation, so that a
+// seeded environment sees the same ideals wherever they are drawn.  Everything is wave-uniform: scalar registers, scalar
+// loads from the immutable table.  Doubles: plain IEEE operations, no contraction.
+__device__ __forceinline__ uint32_t gen_next(uint32_t& x) {                 // x <- 16807 x mod (2^31 - 1)
+  const uint64_t pr = (uint64_t)x * 16807u;
+  uint32_t s = (uint32_t)(pr & 0x7fffffffu) + (uint32_t)(pr >> 31);        // 2^31 = 1 (mod 2^31 - 1)
+  if (s >= 2147483647u) s -= 2147483647u;
+  x = s;
+  return s;
+}
+// ret / scaling for ret < 2^31 with magic = floor(2^32 / scaling): the estimate is at most one too small
+__device__ __forceinline__ uint32_t gen_div(uint32_t ret, uint32_t scaling, uint32_t magic) {
+  uint32_t q = (uint32_t)(((uint64_t)ret * magic) >> 32);
+  if (ret - q * scaling >= scaling) q++;
+  return q;
+}
+__device__ __forceinline__ uint32_t gen_uniform(uint32_t& x, uint32_t scaling, uint32_t past, uint32_t magic) {   // uniform_int_dist.h, downscaling
+  uint32_t ret;
+  do ret = gen_next(x) - 1u; while (ret >= past);
+  return gen_div(ret, scaling, magic);
+}
+__device__ __forceinline__ double gen_canonical(uint32_t& x) {             // random.tcc generate_canonical, k = 2
+#pragma clang fp contract(off)
+  const double R = 2147483646.0;
+  double sum = (double)(gen_next(x) - 1u);
+  sum = sum + (double)(gen_next(x) - 1u) * R;
+  double ret = sum / (R * R);
+  if (ret >= 1.0) ret = 0x1.fffffffffffffp-1;                               // nextafter(1, 0)
+  return ret;
+}
+// The small tables live one entry per lane for the duration of a reset (two coalesced loads): the cumulative
+// probabilities, so that std::lower_bound is a compare + ballot + popcount, and the per-degree rows, fetched with
+// v_readlane.  Only the chosen monomials themselves are loaded (scalar loads) while drawing.
+struct GenLanes { double cp; uint32_t off, scaling, past, magic; };
+__device__ __forceinline__ GenLanes gen_lanes(const uint32_t* g) {
+  const int lane = lane_id();
+  GenLanes r;
+  r.cp = *(const double*)(g + BBX_GEN_CP + 2 * lane);                       // +inf beyond the last entry
+  const uint4 row = *(const uint4*)(g + BBX_GEN_DEG + 8 * lane);
+  r.off = row.x; r.scaling = row.z; r.past = row.w; r.magic = g[BBX_GEN_DEG + 8 * lane + 4];
+  return r;
+}
+__device__ __forceinline__ int gen_degree(uint32_t& x, const GenLanes& L, int ncp) {   // discrete_distribution::operator()
+  if (ncp == 0) return 0;
+  const double pr = gen_canonical(x);
+  return __popcll(ballot64(L.cp < pr));                                     // std::lower_bound(cp, cp + ncp, pr) - cp
+}
+template <int W>
+__device__ __forceinline__ Mono<W> gen_choice(uint32_t& x, const uint32_t* g, const GenLanes& L, int d) {   // choice(bases[d], rng), ideals.h:68-73
+  const uint32_t scaling = (uint32_t)__builtin_amdgcn_readlane((int)L.scaling, d), past = (uint32_t)__builtin_amdgcn_readlane((int)L.past, d);
+  const uint32_t magic = (uint32_t)__builtin_amdgcn_readlane((int)L.magic, d), off = (uint32_t)__builtin_amdgcn_readlane((int)L.off, d);
+  const uint32_t j = off + gen_uniform(x, scaling, past, magic);
+  Mono<W> m;
+#pragma unroll
+  for (int i = 0; i < W; i++) m.w[i] = ldc(g + BBX_GEN_MONO + (size_t)j * W + i);
+  return m;
+}
+// one generator of the ideal: {1 * bigger monomial, c * smaller monomial} (ideals.cpp:168-201); false after 1000 trials
+template <int W>
+__device__ __forceinline__ bool gen_binomial(uint32_t& x, const uint32_t* g, const GenLanes& L, uint32_t flags, int ncp,
+                                             Mono<W>& lead, Mono<W>& tail, uint32_t& c) {
+  c = (flags & 2u) ? BBX_P - 1u : 1u + gen_uniform(x, 67104u, 2147462208u, 64004u);   // uniform_int_distribution(1, P - 1); 2^32 / 67104 = 64004
+  int d1, d2;
+  if (flags & 1u) d1 = d2 = gen_degree(x, L, ncp);
+  else { d1 = gen_degree(x, L, ncp); d2 = gen_degree(x, L, ncp); }
+  for (int trials = 0; trials < 1000; trials++) {
+    const Mono<W> m1 = gen_choice<W>(x, g, L, d1), m2 = gen_choice<W>(x, g, L, d2);
+    if (m_gt(m2, m1)) { lead = m2; tail = m1; return true; }
+    if (m_gt(m1, m2)) { lead = m1; tail = m2; return true; }
+  }
+  return false;
+}
+
+// poisson_distribution<int>(lambda)(rng) for lambda < 12 (random.tcc): multiply canonical draws until below exp(-lambda)
+__device__ __forceinline__ int gen_poisson(uint32_t& x, double lm_thr) {
+#pragma clang fp contract(off)
+  int k = 0;
+  double prod = 1.0;
+  do { prod = prod * gen_canonical(x); k += 1; } while (prod > lm_thr);
+  return k - 1;
+}
+
 // ------------------------------------------------------------------ update()   buchberger.cpp:52-99
 // Adds the polynomial whose lead monomial is lmf as G[m] (the caller has already stored its terms and
 // metadata) and updates the pair set.  Returns false on capacity overflow.
@@ -660,23 +745,107 @@ __device__ bool wave_add_poly(Env<W>& e, const BbxLayout& L, int& nG, int& nP, i
 
 // BuchbergerEnv::reset (buchberger.cpp:299-315) from the next host-generated ideal(s) of the queue.
 // Returns false if the queue ran dry (status STARVED) or on overflow.
+// One generator of a random ideal, drawn on the device, as a sorted polynomial in the scratch arrays (sm, sc):
+//  * binomial distributions: {1 * bigger monomial, c * smaller} (gen_binomial);
+//  * polynomial distributions (ideals.cpp:203-231): 2 + Poisson terms c * monomial summed with Polynomial operator+, then
+//    scaled by 1/LC.  The sum over single terms is order-independent (coefficients add mod P per distinct monomial, a
+//    monomial whose total is 0 disappears), so it is formed in one go: lane j holds term j, every lane adds up the
+//    coefficients of the terms equal to its own, the first lane of each class with a non-zero total keeps it, and the
+//    rank among the kept ones (count of greater monomials) is the position.  sugar = the largest degree DRAWN, cancelled
+//    terms included (operator+ takes the max of the operands' sugars).
+// Returns the number of terms (0: failure, *status set).
 template <int W>
-__device__ bool wave_reset(Env<W>& e, const BbxParams& p, const BbxLayout& L, int env, int& nG, int& nP, int& arena_used, int& q_head, int* status) {
+__device__ int gen_polynomial(uint32_t& x, const uint32_t* g, const GenLanes& GL, uint32_t flags, int ncp, double lm_thr,
+                              Mono<W>* sm, uint16_t* sc, int maxT, int* sugar, int* status) {
   const int lane = lane_id();
+  if (!(flags & 4u)) {
+    Mono<W> lead, tail; uint32_t c;
+    if (!gen_binomial<W>(x, g, GL, flags, ncp, lead, tail, c)) { *status = BBX_ST_GEN_FAIL; return 0; }
+    if (lane == 0) { sm[0] = lead; sc[0] = 1; sm[1] = tail; sc[1] = (uint16_t)c; }
+    *sugar = (int)m_deg(lead);
+    wave_sync();
+    return 2;
+  }
+  const int terms = 2 + gen_poisson(x, lm_thr);
+  if (terms > WAVE || terms > maxT) { *status = BBX_ST_POLY_TOO_LONG; return 0; }
+  int d = gen_degree(x, GL, ncp);
+  Mono<W> mine = m_zero<W>(); uint32_t myc = 0;
+  int maxdeg = 0;
+  for (int j = 0; j < terms; j++) {
+    const uint32_t c = 1u + gen_uniform(x, 67104u, 2147462208u, 64004u);
+    const Mono<W> m = gen_choice<W>(x, g, GL, d);
+    if (lane == j) { mine = m; myc = c; }
+    maxdeg = d > maxdeg ? d : maxdeg;
+    if (!(flags & 1u)) d = gen_degree(x, GL, ncp);
+  }
+  uint32_t total = 0; int first = lane;
+  for (int k = 0; k < terms; k++) {
+    Mono<W> mk;
+#pragma unroll
+    for (int i = 0; i < W; i++) mk.w[i] = (uint32_t)__builtin_amdgcn_readlane((int)mine.w[i], k);
+    const uint32_t ck = (uint32_t)__builtin_amdgcn_readlane((int)myc, k);
+    if (m_eq(mk, mine)) { total = addmod(total, ck); first = k < first ? k : first; }
+  }
+  const bool keep = lane < terms && first == lane && total != 0;
+  const uint64_t km = ballot64(keep);
+  int rank = 0;
+  for (int k = 0; k < terms; k++) {
+    if (!((km >> k) & 1ull)) continue;
+    Mono<W> mk;
+#pragma unroll
+    for (int i = 0; i < W; i++) mk.w[i] = (uint32_t)__builtin_amdgcn_readlane((int)mine.w[i], k);
+    if (m_gt(mk, mine)) rank++;
+  }
+  const int n = __popcll(km);
+  if (n == 0) { *status = BBX_ST_GEN_ZERO; return 0; }
+  // 1 / LC: the leading term is the kept one of rank 0
+  const uint64_t lead_mask = ballot64(keep && rank == 0);
+  const uint32_t lc = (uint32_t)__builtin_amdgcn_readlane((int)total, __builtin_ctzll(lead_mask));
+  const uint32_t inv = invmod(lc);
+  if (keep) { sm[rank] = mine; sc[rank] = (uint16_t)mulmod(total, inv); }
+  *sugar = maxdeg;
+  wave_sync();
+  return n;
+}
+
+// BuchbergerEnv::reset (buchberger.cpp:299-315) from ideals drawn on the device (p.gen) or the next host-generated
+// ideal(s) of the queue.  Returns false if the queue ran dry (status STARVED), the generator failed or on overflow.
+template <int W>
+__device__ bool wave_reset(Env<W>& e, const BbxParams& p, const BbxLayout& L, int env, int& nG, int& nP, int& arena_used, int& q_head, int* status,
+                           uint32_t& gen_state) {
+  const int lane = lane_id();
+  if (p.gen) {
+    const int npoly = (int)ldc(p.gen + 2), ncp = (int)ldc(p.gen + 4);
+    const uint32_t gflags = ldc(p.gen + 3);
+    const double lm_thr = __builtin_bit_cast(double, ((uint64_t)ldc(p.gen + 7) << 32) | ldc(p.gen + 6));
+    const GenLanes GL = gen_lanes(p.gen);
+    uint32_t x = (uint32_t)uni((int)gen_state);
+    for (;;) {
+      const uint32_t x_start = x;
+      nG = 0; nP = 0; arena_used = 0;
+      for (int f = 0; f < npoly; f++) {
+        int sugar = 0;
+        const int n = gen_polynomial<W>(x, p.gen, GL, gflags, ncp, lm_thr, e.hm, e.hc, (int)L.maxT, &sugar, status);
+        if (n == 0) { gen_state = x; return false; }
+        if (!wave_add_poly<W>(e, L, nG, nP, arena_used, e.hm, e.hc, n, sugar, p.elim, p.sort_reducers, status)) { gen_state = x_start; return false; }
+      }
+      if (nP != 0) { gen_state = x; return true; }   // 313-314: redraw while the pair set is empty
+    }
+  }
   for (;;) {
     const uint32_t* slot;
     if (p.q.fixed) slot = p.q.words;
     else {
-      int tail = p.q.tail[env];
+      const int tail = ldc(p.q.tail + env);
       if (q_head >= tail) { *status = BBX_ST_STARVED; return false; }
       slot = p.q.words + (size_t)env * p.q.env_stride + (size_t)(q_head % (int)p.q.nslots) * p.q.slot_words;
     }
     nG = 0; nP = 0; arena_used = 0;
-    const int npoly = (int)slot[0];
+    const int npoly = (int)ldc(slot);
     const uint32_t* w = slot + 1;
     Mono<W>* sm = e.hm; uint16_t* sc = e.hc;   // stage each generator's terms in scratch
     for (int f = 0; f < npoly; f++) {
-      const int n = (int)w[0], sugar = (int)w[1];
+      const int n = (int)ldc(w), sugar = (int)ldc(w + 1);
       w += 2;
       if (n > (int)L.maxT) { *status = BBX_ST_POLY_TOO_LONG; return false; }
       for (int t = lane; t < n; t += WAVE) {
@@ -849,6 +1018,7 @@ __device__ __forceinline__ void step_body(const BbxParams& p, char* smem, unsign
   long long total_steps = ghdr->total_steps, total_adds = ghdr->total_additions, alg_bytes = ghdr->alg_bytes;
   const uint32_t agent_seed = uni((int)ghdr->agent_seed);
   uint32_t std_rng = (uint32_t)uni((int)ghdr->std_rng);
+  uint32_t gen_state = ghdr->gen_rng;
   int budget = uni(ghdr->budget), rollout_pos = uni(ghdr->rollout_pos);
   int done_last = uni(ghdr->done_last);
   if (status == BBX_ST_STARVED || status == BBX_ST_SPILL) status = BBX_ST_OK;   // transient states: try again
@@ -887,7 +1057,7 @@ __device__ __forceinline__ void step_body(const BbxParams& p, char* smem, unsign
   for (;;) {
     if (status != BBX_ST_OK) break;
     if (need_reset) {                           // also serves a reset left pending by the last step
-      if (!wave_reset<W>(e, p, L, env, nG, nP, arena_used, q_head, &status)) {
+      if (!wave_reset<W>(e, p, L, env, nG, nP, arena_used, q_head, &status, gen_state)) {
         // the reset restarts from the same queued ideal: in the LDS class a capacity miss is only a spill
         if (STAGED && (status == BBX_ST_G_FULL || status == BBX_ST_P_FULL || status == BBX_ST_ARENA_FULL)) {
           status = BBX_ST_SPILL; nG = 0; nP = 0; arena_used = 0;
@@ -1051,7 +1221,7 @@ __device__ __forceinline__ void step_body(const BbxParams& p, char* smem, unsign
   if (lane == 0) {
     BbxHdr* h = ghdr;
     h->nG = nG; h->nP = nP; h->arena_used = arena_used; h->status = status; h->need_reset = need_reset;
-    h->q_head = q_head; h->t = t_agent; h->std_rng = std_rng; h->episode_steps = episode_steps; h->total_steps = total_steps;
+    h->q_head = q_head; h->t = t_agent; h->std_rng = std_rng; h->gen_rng = gen_state; h->episode_steps = episode_steps; h->total_steps = total_steps;
     h->total_additions = total_adds; h->episodes = episodes; h->zero_reductions = zero_red; h->steps_done = steps_done;
     h->budget = budget; h->rollout_pos = rollout_pos; h->done_last = done_last; h->alg_bytes = alg_bytes;
     h->vret = vret; h->vdisc = vdisc;
@@ -1109,82 +1279,6 @@ template <int W>
 __global__ __launch_bounds__(256) void bbx_step_prof_kernel(BbxParams p, unsigned long long* prof) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   step_body<W, false, false, true>(p, smem, prof);
-}
-
-// ------------------------------------------------------------------ ideal generation on the device
-// The reference draws every new ideal from std::default_random_engine (minstd_rand0) through libstdc++ 11's
-// uniform_int_distribution / discrete_distribution (generate_canonical<double, 53>: two engine draws) — restated here
-// from the same published algorithms as the host generators (bbx_ideals.cpp), operation for operation, so that a
-// seeded environment sees the same ideals wherever they are drawn.  Everything is wave-uniform: scalar registers, scalar
-// loads from the immutable table.  Doubles: plain IEEE operations, no contraction.
-__device__ __forceinline__ uint32_t gen_next(uint32_t& x) {                 // x <- 16807 x mod (2^31 - 1)
-  const uint64_t pr = (uint64_t)x * 16807u;
-  uint32_t s = (uint32_t)(pr & 0x7fffffffu) + (uint32_t)(pr >> 31);        // 2^31 = 1 (mod 2^31 - 1)
-  if (s >= 2147483647u) s -= 2147483647u;
-  x = s;
-  return s;
-}
-// ret / scaling for ret < 2^31 with magic = floor(2^32 / scaling): the estimate is at most one too small
-__device__ __forceinline__ uint32_t gen_div(uint32_t ret, uint32_t scaling, uint32_t magic) {
-  uint32_t q = (uint32_t)(((uint64_t)ret * magic) >> 32);
-  if (ret - q * scaling >= scaling) q++;
-  return q;
-}
-__device__ __forceinline__ uint32_t gen_uniform(uint32_t& x, uint32_t scaling, uint32_t past, uint32_t magic) {   // uniform_int_dist.h, downscaling
-  uint32_t ret;
-  do ret = gen_next(x) - 1u; while (ret >= past);
-  return gen_div(ret, scaling, magic);
-}
-__device__ __forceinline__ double gen_canonical(uint32_t& x) {             // random.tcc generate_canonical, k = 2
-#pragma clang fp contract(off)
-  const double R = 2147483646.0;
-  double sum = (double)(gen_next(x) - 1u);
-  sum = sum + (double)(gen_next(x) - 1u) * R;
-  double ret = sum / (R * R);
-  if (ret >= 1.0) ret = 0x1.fffffffffffffp-1;                               // nextafter(1, 0)
-  return ret;
-}
-// The small tables live one entry per lane for the duration of a reset (two coalesced loads): the cumulative
-// probabilities, so that std::lower_bound is a compare + ballot + popcount, and the per-degree rows, fetched with
-// v_readlane.  Only the chosen monomials themselves are loaded (scalar loads) while drawing.
-struct GenLanes { double cp; uint32_t off, scaling, past, magic; };
-__device__ __forceinline__ GenLanes gen_lanes(const uint32_t* g) {
-  const int lane = lane_id();
-  GenLanes r;
-  r.cp = *(const double*)(g + BBX_GEN_CP + 2 * lane);                       // +inf beyond the last entry
-  const uint4 row = *(const uint4*)(g + BBX_GEN_DEG + 8 * lane);
-  r.off = row.x; r.scaling = row.z; r.past = row.w; r.magic = g[BBX_GEN_DEG + 8 * lane + 4];
-  return r;
-}
-__device__ __forceinline__ int gen_degree(uint32_t& x, const GenLanes& L, int ncp) {   // discrete_distribution::operator()
-  if (ncp == 0) return 0;
-  const double pr = gen_canonical(x);
-  return __popcll(ballot64(L.cp < pr));                                     // std::lower_bound(cp, cp + ncp, pr) - cp
-}
-template <int W>
-__device__ __forceinline__ Mono<W> gen_choice(uint32_t& x, const uint32_t* g, const GenLanes& L, int d) {   // choice(bases[d], rng), ideals.h:68-73
-  const uint32_t scaling = (uint32_t)__builtin_amdgcn_readlane((int)L.scaling, d), past = (uint32_t)__builtin_amdgcn_readlane((int)L.past, d);
-  const uint32_t magic = (uint32_t)__builtin_amdgcn_readlane((int)L.magic, d), off = (uint32_t)__builtin_amdgcn_readlane((int)L.off, d);
-  const uint32_t j = off + gen_uniform(x, scaling, past, magic);
-  Mono<W> m;
-#pragma unroll
-  for (int i = 0; i < W; i++) m.w[i] = ldc(g + BBX_GEN_MONO + (size_t)j * W + i);
-  return m;
-}
-// one generator of the ideal: {1 * bigger monomial, c * smaller monomial} (ideals.cpp:168-201); false after 1000 trials
-template <int W>
-__device__ __forceinline__ bool gen_binomial(uint32_t& x, const uint32_t* g, const GenLanes& L, uint32_t flags, int ncp,
-                                             Mono<W>& lead, Mono<W>& tail, uint32_t& c) {
-  c = (flags & 2u) ? BBX_P - 1u : 1u + gen_uniform(x, 67104u, 2147462208u, 64004u);   // uniform_int_distribution(1, P - 1); 2^32 / 67104 = 64004
-  int d1, d2;
-  if (flags & 1u) d1 = d2 = gen_degree(x, L, ncp);
-  else { d1 = gen_degree(x, L, ncp); d2 = gen_degree(x, L, ncp); }
-  for (int trials = 0; trials < 1000; trials++) {
-    const Mono<W> m1 = gen_choice<W>(x, g, L, d1), m2 = gen_choice<W>(x, g, L, d2);
-    if (m_gt(m2, m1)) { lead = m2; tail = m1; return true; }
-    if (m_gt(m1, m2)) { lead = m1; tail = m2; return true; }
-  }
-  return false;
 }
 
 #include "bbx_binom.h"

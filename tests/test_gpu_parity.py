@@ -321,10 +321,11 @@ def test_observation_width_sweep(dist):
 
 
 @pytest.mark.parametrize("dist", ["3-20-10-weighted", "3-20-10-uniform-consts", "3-8-6-maximum-pure-homog", "5-10-5-uniform",
-                                  "7-4-4-weighted-homog"])
+                                  "7-4-4-weighted-homog", "3-6-5-0.5-uniform", "4-4-4-1.5-weighted-consts", "3-5-4-2.0-maximum-homog"])
 def test_device_drawn_ideals_equal_host_drawn(dist, monkeypatch):
-    """Binomial distributions are drawn inside the kernels (minstd_rand0 + libstdc++'s distributions restated on the
-    device); BBX_HOST_GEN=1 selects the host generators + ideal queue instead.  Same seeds, same rollout: identical
+    """Random distributions — binomial and polynomial (Poisson term counts, sums of single terms, 1/LC scaling) — are
+    drawn inside the kernels (minstd_rand0 + libstdc++'s distributions restated on the device); BBX_HOST_GEN=1 selects the
+    host generators + ideal queue instead.  Same seeds, same rollout: identical
     counters and final states, episode after episode (each reset consumes the next ideal of the stream)."""
     from deepgroebner_amd import VecLeadMonomialsEnv
     B, T = 6, (6000 if dist.startswith("5-") else 400)
