@@ -182,7 +182,7 @@ def cpu_baseline(args, env, st_final, steps_per_env, B):
     from oracle import ffi
     kind = "reference" if ffi.available("ref") else "port"
     lib = ffi.load("ref" if kind == "reference" else "bo")
-    n = args.cpu_sample_envs or max(1, min(B, int(1.5e6 // max(1, steps_per_env))))
+    n = args.cpu_sample_envs or max(1, min(B, int(4.5e6 // max(1, steps_per_env))))   # ~10-12 s of one host core
     res = lib.bench_random(args.dist, K_LEADS, n, steps_per_env, 1000, 0)
     dev_adds = int(st_final[:n, 1].sum())
     return {"value": res["steps"] / res["seconds"], "unit": "env-steps/s", "cores": 1, "kind": kind,
