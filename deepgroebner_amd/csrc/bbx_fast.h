@@ -257,7 +257,10 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
   // (buchberger.cpp:52-99 + 321-326).  The caller has checked the capacities.
   // `skip` >= 0: the pair at that index has just been selected and is removed by the same compaction pass
   // (P.erase(remove(action)), buchberger.cpp:319) instead of a separate shift of the list
-  auto add_poly = [&](const BTerm<2>& t0, const BTerm<2>& t1, int sugar, int skip) {
+  // `small` (a std::integral_constant): the caller guarantees |G| < 64 (resets of ideals with at most 64 generators), so
+  // everything about the second half of the reducer / basis registers compiles away
+  auto add_poly = [&](const BTerm<2>& t0, const BTerm<2>& t1, int sugar, int skip, auto small) {
+    constexpr bool SMALL = decltype(small)::value;
     const int g = nG;                                     // == m of update()
     // 1/LC comes from a table in HBM/L2: issue the load now, consume it at the very end (the pair update below
     // does not need it), so its latency overlaps the Gebauer-Moeller work
@@ -276,7 +279,7 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
     uint64_t emitA = 0, emitB = 0;
     {
       const M2 lA = lm[lane], lB = lm[lane + 64];          // basis order; lanes >= g hold garbage (masked by valid)
-      const uint64_t validA = f_lowmask(g < 64 ? g : 64), validB = g > 64 ? f_lowmask(g - 64) : 0ull;
+      const uint64_t validA = f_lowmask((SMALL || g < 64) ? g : 64), validB = (!SMALL && g > 64) ? f_lowmask(g - 64) : 0ull;
       const M2 LA = m_lcm(lA, f), LB = m_lcm(lB, f);
       const uint64_t cpA = ballot64(m_coprime(lA, f)) & validA, cpB = validB ? (ballot64(m_coprime(lB, f)) & validB) : 0ull;
       const uint32_t dA = LA.w[1] >> 16, dB = LB.w[1] >> 16;
@@ -332,15 +335,15 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
     // sorted reducer insert: std::upper_bound by lead monomial (buchberger.cpp:323-324); sentinels compare greater
     {
       int pos = __popcll(ballot64(!m_gt(S.slmA, f)));
-      if (g >= 64) pos += __popcll(ballot64(!m_gt(S.slmB, f)));
+      if (!SMALL && g >= 64) pos += __popcll(ballot64(!m_gt(S.slmB, f)));
       const uint32_t inv = inv_raw;
       if (lane == 0) gi[g] = make_uint2(t0.c | (t1.c << 16), inv | ((uint32_t)sugar << 16));
       const uint2 ns = make_uint2(t1.c | (inv << 16), (uint32_t)sugar | ((uint32_t)g << 16));
-      if (pos < 64) {
+      if (SMALL || pos < 64) {
         const uint32_t c0 = f_insert(S.slmA.w[0], f.w[0], pos, lane), c1 = f_insert(S.slmA.w[1], f.w[1], pos, lane);
         const uint32_t c2 = f_insert(S.stmA.w[0], tail.w[0], pos, lane), c3 = f_insert(S.stmA.w[1], tail.w[1], pos, lane);
         const uint32_t c4 = f_insert(S.sinA.x, ns.x, pos, lane), c5 = f_insert(S.sinA.y, ns.y, pos, lane);
-        if (g >= 64) {
+        if (!SMALL && g >= 64) {
           f_shift_in(S.slmB.w[0], c0, lane); f_shift_in(S.slmB.w[1], c1, lane);
           f_shift_in(S.stmB.w[0], c2, lane); f_shift_in(S.stmB.w[1], c3, lane);
           f_shift_in(S.sinB.x, c4, lane); f_shift_in(S.sinB.y, c5, lane);
@@ -380,7 +383,8 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
             BTerm<2> t0, t1;
             t0.c = 1;
             if (!gen_binomial<2>(x, gtab, GL, gflags, ncp, t0.m, t1.m, t1.c)) { status = BBX_ST_GEN_FAIL; ok = false; break; }
-            add_poly(t0, t1, (int)m_deg(t0.m), -1);
+            if (npoly <= 64) add_poly(t0, t1, (int)m_deg(t0.m), -1, std::true_type{});
+            else add_poly(t0, t1, (int)m_deg(t0.m), -1, std::false_type{});
           }
           if (!ok || nP != 0) break;                       // buchberger.cpp:313-314: redraw while the pair set is empty
         }
@@ -418,7 +422,7 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
           t0.c = qword(at + 2); t0.m.w[0] = qword(at + 3); t0.m.w[1] = qword(at + 4);
           t1.c = 0; t1.m = m_zero<2>();
           if (nt == 2) { t1.c = qword(at + 5); t1.m.w[0] = qword(at + 6); t1.m.w[1] = qword(at + 7); }
-          add_poly(t0, t1, sugar, -1);
+          add_poly(t0, t1, sugar, -1, std::false_type{});
           at += 2 + nt * 3;
         }
         if (!ok) break;
@@ -553,7 +557,7 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
       nP -= 1;
       zero_red++;
     } else {
-      add_poly(r0, r1, rsug, action);
+      add_poly(r0, r1, rsug, action, std::false_type{});
       if (ACCT) bytes += 12 * (r1.c ? 2 : 1) + 8 * nG_before + 8 * (nP_before + nP);
     }
     FSTAMP(4);                                             // 4: add_poly (pair update, insert)

@@ -21,6 +21,7 @@
 //    classes: 3-variable binomial ideals need ~6 KB); otherwise the record is worked on in HBM/L2.
 //  * no inter-workgroup communication at all: environments are independent.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 #include <cstdio>
 #include <cstdlib>
