@@ -557,7 +557,8 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
       nP -= 1;
       zero_red++;
     } else {
-      add_poly(r0, r1, rsug, action, std::false_type{});
+      if (nG < 64) add_poly(r0, r1, rsug, action, std::true_type{});   // (the common case; basis means are ~35)
+      else add_poly(r0, r1, rsug, action, std::false_type{});
       if (ACCT) bytes += 12 * (r1.c ? 2 : 1) + 8 * nG_before + 8 * (nP_before + nP);
     }
     FSTAMP(4);                                             // 4: add_poly (pair update, insert)
