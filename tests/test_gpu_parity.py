@@ -650,6 +650,56 @@ def test_cyclic7_degree_agent_to_completion():
     assert len(G) == w["basis_size"] == 209 and int(fnv64(flat_ideal(G))) == w["basis_hash"]
 
 
+def test_interleaved_handles_and_copies():
+    """Several handles alive at once (single environments on the zero-copy path, a batch on the copy path, copies of
+    both made mid-episode), stepped in turn: each follows its own oracle; a copy continues like its source did."""
+    from deepgroebner_amd import CLeadMonomialsEnv, VecLeadMonomialsEnv
+    bo = ffi.load("bo")
+    a = CLeadMonomialsEnv("3-20-10-weighted", k=2); a.seed(1)
+    b = CLeadMonomialsEnv("5-10-5-uniform", k=1); b.seed(2)
+    v = VecLeadMonomialsEnv("3-20-10-weighted", batch=12, k=2); v.seed(np.arange(12) + 30)
+    oa = bo.env("3-20-10-weighted"); oa.seed(1); oa.reset()
+    ob = bo.env("5-10-5-uniform"); ob.seed(2); ob.reset()
+    ov = []
+    for e in range(12):
+        o = bo.env("3-20-10-weighted"); o.seed(30 + e); o.reset(); ov.append(o)
+    sa, sb, sv = a.reset(), b.reset(), v.reset()
+    copies = None
+    for t in range(90):
+        assert np.array_equal(sa, oa.obs(2)) and np.array_equal(sb, ob.obs(1))
+        for e in range(12):
+            assert np.array_equal(sv[e], ov[e].obs(2))
+        if t == 40:
+            copies = (a.copy(), v.copy(), [o.copy() for o in [oa] + ov])
+        if len(sa) == 0:
+            oa.reset(); sa = a.reset(); continue
+        sa, ra, _, _ = a.step(t % len(sa)); assert ra == oa.step(t % oa.nP)
+        if len(sb):
+            sb, rb, _, _ = b.step(0); assert rb == ob.step(0)
+        acts = np.array([t % max(o.nP, 1) for o in ov], dtype=np.int32)
+        sv, rv, dv, _ = v.step(acts, auto_reset=True)
+        for e, o in enumerate(ov):
+            assert rv[e] == o.step(int(acts[e]))
+            if o.nP == 0:
+                o.reset()
+    ca, cv, oc = copies
+    s = ca._vec._step_obs(None, False)[0]
+    assert np.array_equal(s, oc[0].obs(2))
+    for t in range(30):
+        if oc[0].nP == 0:
+            break
+        s, r, _, _ = ca.step(0); assert r == oc[0].step(0) and np.array_equal(s, oc[0].obs(2))
+    acts = np.zeros(12, dtype=np.int32)
+    for t in range(30):
+        svv, rv, dv, _ = cv.step(acts, auto_reset=True)
+        for e in range(12):
+            o = oc[1 + e]
+            assert rv[e] == o.step(0)
+            if o.nP == 0:
+                o.reset()
+            assert np.array_equal(svv[e], o.obs(2))
+
+
 def test_in_batch_clones_for_tree_search():
     """env.copy() per search node (mcts.py:89,96,147) as an in-batch clone: the clone continues exactly like its
     source, including the ideals it will draw after a reset, and then diverges under different actions."""
