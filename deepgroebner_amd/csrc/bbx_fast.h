@@ -13,6 +13,11 @@
 // An environment that outgrows |G| <= 128 / |P| <= 256 leaves a consistent record behind (BBX_ST_SPILL) and is
 // continued by the HBM-resident binomial kernel (bbx_binom.h) launched right behind on the same stream.
 //
+// What makes it fast: everything a wave decides about its environment is wave-uniform and is
+// kept provably so for the compiler (scalar branches, the reduction loop on scalar registers); the launch shape that
+// is benchmarked and the common |G| < 64 case have their own instantiations without the general cases' code; new
+// ideals are drawn right here at reset (gen_binomial in bbx_kernels.hip).
+//
 // Gebauer-Moeller new pairs without the std::map walk (buchberger.cpp:78-91): the lcms L_i = lcm(LM G_i, LM f) that
 // survive are exactly those minimal under divisibility.  They are peeled by increasing degree: all candidates of
 // minimal degree are minimal (a proper divisor has strictly smaller degree); each such bucket of equal lcms emits the
@@ -49,11 +54,6 @@ __device__ __forceinline__ uint32_t f_wave_min(uint32_t x) {
 #undef FDPPMIN
   return f_readlane(x, 63);
 }
-// fetch element l of a register array INTO A VGPR (ds_bpermute: LDS crossbar, no LDS memory): the arithmetic that
-// follows then runs on the under-used vector ALUs instead of the scalar unit all 16 waves of a CU share
-__device__ __forceinline__ uint32_t f_fetch(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_ds_bpermute(l << 2, (int)v); }
-__device__ __forceinline__ M2 f_fetch(const M2& v, int l) { M2 r; r.w[0] = f_fetch(v.w[0], l); r.w[1] = f_fetch(v.w[1], l); return r; }
-__device__ __forceinline__ uint2 f_fetch(const uint2& v, int l) { return make_uint2(f_fetch(v.x, l), f_fetch(v.y, l)); }
 // lane bit of a wave-uniform 64-bit mask as a per-lane predicate (the mask IS an exec-style lane mask: no shifts), and
 // the number of set bits below the lane (v_mbcnt pair on the scalar mask)
 __device__ __forceinline__ bool f_lane_in(uint64_t mask) { return __builtin_amdgcn_inverse_ballot_w64(mask); }
