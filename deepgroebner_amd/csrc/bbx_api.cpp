@@ -493,7 +493,12 @@ int create_common(std::unique_ptr<bbx::IdealGen> proto, int nvars_obs, int elimi
     return fail(BBX_E_ARG, "capacities out of range");
   b->L = b->binom ? make_layout_binom(b->W, c.max_basis, c.max_pairs)
                   : make_layout(b->W, c.max_basis, c.max_pairs, c.arena_terms, c.max_poly_terms);
-  b->nslots = b->fixed ? 1 : (uint32_t)c.queue_slots;
+  // random distributions: the ideals are drawn on the device (same seeded streams; see gen_binomial / gen_polynomial in
+  // bbx_kernels.hip) and the ideal queue shrinks to one unused slot.  Not with sort_input (the generators would have to
+  // be sorted first) or ideal lists.
+  std::vector<uint32_t> gen_table;
+  if (!b->fixed && !list && !sort_input && !getenv("BBX_HOST_GEN")) proto->device_table(b->W, &gen_table);
+  b->nslots = (b->fixed || !gen_table.empty()) ? 1 : (uint32_t)c.queue_slots;
   b->slot_words = 1 + (uint32_t)proto->npolys() * (2 + (uint32_t)std::min(proto->max_terms_hint(), c.max_poly_terms) * (1 + b->W));
   b->slot_words = (b->slot_words + 3u) & ~3u;
 
@@ -530,20 +535,15 @@ int create_common(std::unique_ptr<bbx::IdealGen> proto, int nvars_obs, int elimi
   }
   int lrc = bbx_launch_init(b->d_recs, b->L.rec_bytes, batch, nullptr, 0);
   if (lrc) return fail(BBX_E_DEVICE, "init launch failed: %s", hipGetErrorString((hipError_t)lrc));
-  // random distributions: draw the ideals on the device (same seeded streams; see gen_binomial / gen_polynomial in
-  // bbx_kernels.hip).  Not with sort_input (the generators would have to be sorted first) or ideal lists.
-  if (!b->fixed && !list && !sort_input && !getenv("BBX_HOST_GEN")) {
-    std::vector<uint32_t> table;
-    if (b->gens[0]->device_table(b->W, &table)) {
-      HIPCHK(hipMalloc((void**)&b->d_gen, table.size() * sizeof(uint32_t)));
-      HIPCHK(hipMemcpy(b->d_gen, table.data(), table.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-      b->device_gen = true; b->gen_words = table.size();
-      std::vector<long long> seeds(batch);
-      for (int e = 0; e < batch; e++) seeds[e] = 5489 + e;          // the default seeding of the host generators above
-      HIPCHK(hipDeviceSynchronize());
-      int rc = write_gen_states(b.get(), seeds);
-      if (rc) return rc;
-    }
+  if (!gen_table.empty()) {
+    HIPCHK(hipMalloc((void**)&b->d_gen, gen_table.size() * sizeof(uint32_t)));
+    HIPCHK(hipMemcpy(b->d_gen, gen_table.data(), gen_table.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    b->device_gen = true; b->gen_words = gen_table.size();
+    std::vector<long long> seeds(batch);
+    for (int e = 0; e < batch; e++) seeds[e] = 5489 + e;            // the default seeding of the host generators above
+    HIPCHK(hipDeviceSynchronize());
+    int rc = write_gen_states(b.get(), seeds);
+    if (rc) return rc;
   }
   lrc = bbx_launch_mark_reset(b->d_recs, b->L.rec_bytes, batch, nullptr, 0);
   if (lrc) return fail(BBX_E_DEVICE, "init launch failed: %s", hipGetErrorString((hipError_t)lrc));
