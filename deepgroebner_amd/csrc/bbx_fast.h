@@ -48,6 +48,9 @@ __device__ __forceinline__ uint2 f_readlane(const uint2& v, int l) { return make
 __device__ __forceinline__ uint32_t f_wave_shr(uint32_t v) {           // lane i <- lane i-1 (lane 0 undefined: fixed by caller)
   return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xF, 0xF, false);
 }
+__device__ __forceinline__ uint32_t f_wave_shl(uint32_t v) {           // lane i <- lane i+1 (lane 63 undefined: fixed by caller)
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xF, 0xF, false);
+}
 __device__ __forceinline__ uint32_t f_wave_min(uint32_t x) {
 #define FDPPMIN(ctrl, rmask) { uint32_t y_ = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)x, ctrl, rmask, 0xF, false); x = y_ < x ? y_ : x; }
   FDPPMIN(0x111, 0xF) FDPPMIN(0x112, 0xF) FDPPMIN(0x114, 0xF) FDPPMIN(0x118, 0xF) FDPPMIN(0x142, 0xA) FDPPMIN(0x143, 0xC)
@@ -155,6 +158,9 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
       wave_sync();
     }
   }
+  // the first 64 pairs also live in a register (lane k <-> pairs[k]; LDS stays the complete copy): the selected pair is
+  // a v_readlane, removing it a DPP shift, and the Gebauer-Moeller filter starts its gathers without a pair load
+  uint32_t PA = pairs[lane];
 
   // the random agent's hashes for 64 consecutive steps at a time, one per lane (recomputed every 64 steps)
   uint32_t hv = bbx_agent_hash32(agent_seed, (uint32_t)((t_agent & ~63) + lane));
@@ -273,7 +279,7 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
     // The gathers of the first 64 pairs are issued here and consumed behind the register-only peel below, which
     // hides their two dependent LDS round trips.
     const int nP_old = nP;
-    const uint32_t pr_first = lane < nP_old ? pairs[lane] : 0u;
+    const uint32_t pr_first = lane < nP_old ? PA : 0u;
     const M2 li_first = lm[pr_first & 0xffffu], lj_first = lm[pr_first >> 16];
     // (78-91) new pairs (i, g): minimal lcms by degree peeling
     uint64_t emitA = 0, emitB = 0;
@@ -357,6 +363,7 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
     }
     nG = g + 1;
     wave_sync();
+    PA = pairs[lane];                                      // (consumed by the next step: the read has a whole phase to land)
   };
 
   for (;;) {
@@ -452,7 +459,7 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
       action = (int)(f_wave_min(best) & 0xffffu);
     }
     if (action < 0 || action >= nP) { status = BBX_ST_BAD_ACTION; break; }
-    const uint32_t pr = (uint32_t)uni((int)pairs[action]);
+    const uint32_t pr = action < 64 ? f_readlane(PA, action) : (uint32_t)uni((int)pairs[action]);
     const int gi_ = pr & 0xffffu, gj_ = pr >> 16;            // the pair leaves P below, fused with the update's compaction
     FSTAMP(1);                                             // 1: agent + pair removal
     // ---- S-polynomial (buchberger.cpp:18-21): the lead terms cancel, the scaled tails remain ------------------------
@@ -546,13 +553,21 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
     // ---- basis / pair-set update (buchberger.cpp:321-327) ------------------------------------------------------------
     const int nG_before = nG, nP_before = nP - 1;
     if (r0.c == 0) {                                       // zero reduction: only P.erase(remove(action)), stable
-      for (int base = action; base < nP - 1; base += WAVE) {
-        const int k = base + lane;
-        uint32_t v = 0;
-        if (k < nP - 1) v = pairs[k + 1];
-        wave_sync();
-        if (k < nP - 1) pairs[k] = v;
-        wave_sync();
+      if (nP <= 64) {                                      // all in the register copy: shift it, store the moved part
+        const uint32_t sh = f_wave_shl(PA);
+        const bool moved = lane >= action && lane < nP - 1;
+        PA = lane >= action ? sh : PA;
+        if (moved) pairs[lane] = PA;
+      } else {
+        for (int base = action; base < nP - 1; base += WAVE) {
+          const int k = base + lane;
+          uint32_t v = 0;
+          if (k < nP - 1) v = pairs[k + 1];
+          wave_sync();
+          if (k < nP - 1) pairs[k] = v;
+          wave_sync();
+        }
+        PA = pairs[lane];
       }
       nP -= 1;
       zero_red++;
