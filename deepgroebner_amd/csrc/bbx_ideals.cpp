@@ -25,7 +25,6 @@ bool mono_gt(const HTerm& a, const HTerm& b) {
   }
   return false;
 }
-static bool mono_eq(const HTerm& a, const HTerm& b) { return a.e == b.e; }
 
 static HTerm make_term(int c, const std::array<int, kN>& e) {
   HTerm t; t.c = coef_norm(c); t.e = e; t.deg = 0;
