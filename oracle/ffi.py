@@ -10,6 +10,7 @@ cpu_baseline leg may import this module; the product never does.
 import ctypes as C
 import os
 import subprocess
+import sys
 
 import numpy as np
 
@@ -28,7 +29,7 @@ DIST = {"uniform": 0, "weighted": 1, "maximum": 2}
 
 def build():
     """(Re)build both checkers; the reference one only where /root/reference exists."""
-    subprocess.check_call(["make", "-s", "-C", HERE, "all"])
+    subprocess.check_call(["make", "-s", "-C", HERE, "all"], stdout=sys.stderr)
 
 
 def available(kind):
