@@ -4,19 +4,29 @@
 One "step" = one pass of the hot path over the whole batch: every environment of the batch performs
 one BuchbergerEnv step (pair selection by the built-in counter-hash random agent, S-polynomial,
 full reduction over GF(32003), Gebauer-Moeller update, lead-monomial observation of the new state;
-finished episodes draw their next pre-generated ideal on the device).  Workload = BASELINE.json
-configs[1]: 3-20-10-weighted, batch 4096 per GPU, k=2, random-selection agent.  Inputs (seeded
-ideals) are resident in HBM before the timed region starts.
+finished episodes draw their next ideal on the device).  Workload = BASELINE.json configs[1]:
+3-20-10-weighted, batch 4096 per GPU, k=2, random-selection agent.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` and
-`cpu_baseline` objects.
+Measurement protocol (so that the line means the same at --steps 20 and at --steps 1024):
+  * pre-roll: every environment runs `preroll_steps` (>= 256) untimed steps first, so that the batch is in its steady
+    state (a mix of episode phases) rather than all environments in their first episode;
+  * W warm-up steps (one launch), then one calibration launch of K steps;
+  * timed region: R back-to-back launches of K steps each (`repeats`; R is chosen so that the region lasts >= 50 ms),
+    enqueued asynchronously on one stream, bracketed by barrier + synchronize on both sides; `ms_per_step` is the
+    region's wall time / (R*K), `value` = batch * R * K / wall time (max over ranks);
+  * `roofline.kernel_ms_per_launch` = HIP-event time of the region on the launch stream / R.
+
+Prints ONE JSON line on rank 0 with `roofline` and `cpu_baseline` objects.  With --gpus N > 1 and no launcher
+environment, the ranks are started here as fresh child processes (before anything touches the GPU).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,49 +37,69 @@ DIST = "3-20-10-weighted"
 BATCH = 4096          # environments per GPU
 K_LEADS = 2
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
+PREROLL = 256
+MIN_REGION_MS = 60.0
+PMC_PROFILE = os.path.join("profiles", "r02_pmc_fast_kernel.json")
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1024)
     ap.add_argument("--warmup", type=int, default=64)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--dist", default=DIST)
-    ap.add_argument("--chunk", type=int, default=0, help="steps per kernel launch (0 = all K in one launch)")
+    ap.add_argument("--repeats", type=int, default=0, help="launches of K steps in the timed region (0 = enough for >= 50 ms)")
+    ap.add_argument("--preroll", type=int, default=PREROLL)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--ablate-obs", action="store_true", help="diagnostic only: do not write per-step observations")
+    ap.add_argument("--generic-kernel", action="store_true",
+                    help="diagnostic: pad the observation with -1 (obs_fill), which selects bbx_fast_kernel<false,false> "
+                         "instead of the compile-time specialised headline variant")
     ap.add_argument("--cpu-sample-envs", type=int, default=0)
-    args = ap.parse_args()
+    return ap.parse_args()
 
-    import numpy as np
-    import torch
 
-    import __graft_entry__ as graft
+def spawn_ranks(args):
+    """--gpus N without a launcher: start N fresh ranks (torch.distributed.run) and relay rank 0's line."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
+def main():
+    args = parse_args()
+    if args.gpus < 1 or args.steps < 1 or args.warmup < 0:
+        raise SystemExit("--gpus and --steps must be positive, --warmup non-negative")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))               # nothing has touched the GPU in this process
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    if rank == 0:
-        graft.build()
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch one rank per GPU" % (args.gpus, world))
+
+    import numpy as np
+    import torch
+    import __graft_entry__ as graft
+
+    dist = None
     if world > 1:
+        # environments never exchange data: the process group only carries the barrier and a few host scalars,
+        # so it is a CPU (gloo) group — no collective on the data path, no RCCL
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("gloo")
+    if local_rank == 0:
+        graft.build()
+    if world > 1:
         dist.barrier()
-    else:
-        torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(local_rank)
     from deepgroebner_amd import VecLeadMonomialsEnv
+    from deepgroebner_amd.shard import plan
 
     K, Wm, B = args.steps, args.warmup, args.batch
-    chunk = args.chunk if args.chunk > 0 else max(K, 1)
-    # enough pre-generated ideals per environment for warmup + timed steps (mean episode ~60 steps;
-    # the library refills and resumes if an environment still runs dry, so this only affects speed)
-    slots = (K + Wm) // 4 + 16
-    env = VecLeadMonomialsEnv(args.dist, batch=B, k=K_LEADS, device=local_rank, caps={"queue_slots": slots})
-    from deepgroebner_amd.shard import plan
+    env = VecLeadMonomialsEnv(args.dist, batch=B, k=K_LEADS, device=local_rank)
     pl = plan(rank, world, B)                         # contiguous block of global environment ids
     env.seed(pl["ideal_seeds"])
     env.seed_agent(pl["agent_seeds"])
@@ -77,104 +107,125 @@ def main():
 
     stream = torch.cuda.current_stream()
     cols = env.cols
-    obs_rows = 128
+    obs_rows = 256                                    # the fast class holds |P| <= 256: no observation row is ever cut
     d_obs = torch.empty((B, obs_rows, cols), dtype=torch.int32, device="cuda")
     d_rew = torch.empty(B, dtype=torch.float64, device="cuda")
     d_done = torch.empty(B, dtype=torch.uint8, device="cuda")
     d_rows = torch.empty(B, dtype=torch.int32, device="cuda")
+    chain = not os.environ.get("BBX_HOST_GEN")        # device-drawn ideals: launches need no host service in between
 
-    def run(nsteps):
-        done = 0
-        while done < nsteps:
-            n = min(chunk, nsteps - done)
-            env.rollout_device("random", n, True, stream.cuda_stream, d_rew, d_done, d_rows, d_obs, obs_rows, False, not args.ablate_obs)
+    def launch(nsteps):
+        env.rollout_device("random", nsteps, True, stream.cuda_stream, d_rew, d_done, d_rows, d_obs, obs_rows,
+                           args.generic_kernel, True)
+        if not chain:
             env.sync()
-            done += n
 
+    env.accounting(False)                             # lean kernel (no per-step byte counting) from here on
+    launch(max(args.preroll, 0) or 1); env.sync()     # steady state
     if Wm > 0:
-        run(Wm)
-    env.prefetch()                                  # inputs for the timed region resident in HBM
+        launch(Wm); env.sync()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    launch(K); env.sync(); torch.cuda.synchronize()  # calibration launch (also untimed warm-up of this launch shape)
+    t_launch = time.perf_counter() - t0
+    R = args.repeats if args.repeats > 0 else int(min(4096, max(3, MIN_REGION_MS * 1e-3 / max(t_launch, 1e-6) + 1)))
+    if world > 1:
+        r_all = [None] * world
+        dist.all_gather_object(r_all, R)
+        R = max(r_all)
     st0 = env.stats()
-    twin = env.copy()                               # same state, same queued ideals: used after the timed region
-    env.accounting(False)                           # timed run: lean kernel (no per-step byte counting)
-    env.timing(True)
+    twin = env.copy()                               # same state, same generator state: replayed after the timed region
+
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record(stream)
-    run(K)
+    for _ in range(R):
+        launch(K)
     ev1.record(stream)
+    env.sync()
     torch.cuda.synchronize()
+    t1 = time.perf_counter()
     if world > 1:
         dist.barrier()
-    t1 = time.perf_counter()
     elapsed = t1 - t0
-    region_ms = ev0.elapsed_time(ev1)
-    kernel_ms, nlaunch = env.timing(False)       # HIP events around each step-kernel launch, on its stream
+    region_ms = ev0.elapsed_time(ev1)               # HIP events on the stream the kernels were launched on
     st1 = env.stats()
     d = st1 - st0
     steps_done = int(d[:, 0].sum())
-    assert steps_done == K * B, "every environment must have executed exactly K steps (%d != %d)" % (steps_done, K * B)
+    assert steps_done == R * K * B, "every environment must have executed exactly R*K steps (%d != %d)" % (steps_done, R * K * B)
     assert (st1[:, 4] == 0).all(), "an environment reported an error status"
+    assert int(d_rows.max().item()) <= obs_rows
     additions = int(d[:, 1].sum())
-    # algorithmic bytes of exactly these K steps: replay them on the twin with the accounting kernel (untimed)
+    # algorithmic bytes of exactly these steps: replay them on the twin with the accounting kernel (untimed)
     twin.accounting(True)
-    twin.rollout("random", K, auto_reset=True)
-    dt = twin.stats() - st0
-    assert np.array_equal(dt[:, :2], d[:, :2]) and np.array_equal(twin.stats()[:, 7], st1[:, 7]), "accounting replay diverged"
+    for _ in range(R):
+        twin.rollout("random", K, auto_reset=True)
+    st_twin = twin.stats()
+    dt = st_twin - st0
+    assert np.array_equal(dt[:, :2], d[:, :2]) and np.array_equal(st_twin[:, 7], st1[:, 7]), "accounting replay diverged"
     alg_bytes = int(dt[:, 6].sum())
     del twin
 
     if world > 1:
-        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed, region_ms], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, kernel_ms = float(t[0]), float(t[1])
-        s = torch.tensor([steps_done, additions, alg_bytes], dtype=torch.int64, device="cuda")
+        elapsed, region_ms = float(t[0]), float(t[1])
+        s = torch.tensor([steps_done, additions, alg_bytes], dtype=torch.int64)
         dist.all_reduce(s, op=dist.ReduceOp.SUM)
         steps_done, additions, alg_bytes = int(s[0]), int(s[1]), int(s[2])
 
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args, env, st1, K + Wm, B)
+        cpu = cpu_baseline(args, st1, int(st1[0, 0]), B)
 
-    traffic, traffic_src = None, None
-    if rank == 0:
-        # HBM bytes of one launch from rocprofv3 PMC passes (scripts/profile_bench.sh; separate --pmc runs, FETCH_SIZE
-        # doubled per MI355X_MICROARCH.md): only valid for the workload it was collected on
-        pf = os.path.join(ROOT, "profiles", "r01_pmc_fast_kernel.json")
-        if os.path.exists(pf) and args.dist == DIST and B == BATCH and K == 1024 and chunk == 1024 and not args.ablate_obs:
-            traffic = json.load(open(pf)).get("hbm_traffic_bytes_per_launch")
-            traffic_src = "profiles/r01_pmc_fast_kernel.json"
     if rank == 0:
         value = steps_done / elapsed
+        kernel = "bbx_fast_headline_kernel" if not args.generic_kernel else "bbx_fast_kernel<false,false>"
         # the dominant (only) kernel: per launch, algorithmic bytes of ONE GPU / its HIP-event duration
-        per_launch_bytes = alg_bytes / world / nlaunch
-        per_launch_s = kernel_ms * 1e-3 / nlaunch
+        per_launch_bytes = alg_bytes / world / R
+        per_launch_s = region_ms * 1e-3 / R
         achieved = per_launch_bytes / per_launch_s / 1e9
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None, "traffic_unit": "bytes/launch", "traffic_source": None,
+                "note": "achieved = ALGORITHMIC bytes (SURVEY 8d formula) / launch time: a nominal figure — the state is "
+                        "register/LDS resident, the measured HBM traffic (`traffic`) is a fraction of a percent of it, and "
+                        "the kernel is bound by per-wave instruction issue (see `issue_bound`)",
+                "alg_bytes_per_launch": per_launch_bytes, "alg_bytes_per_env_step": alg_bytes / steps_done,
+                "kernel": kernel, "kernel_ms_per_launch": region_ms / R, "launches": R, "timed_region_ms": region_ms}
+        pf = os.path.join(ROOT, PMC_PROFILE)
+        if os.path.exists(pf) and args.dist == DIST and B == BATCH and not args.generic_kernel:
+            prof = json.load(open(pf))
+            tr = prof.get("hbm_traffic")
+            if tr:   # PMC passes at two launch lengths: traffic = fixed part (records in/out, observation block) + per-step part
+                roof["traffic"] = tr["fixed_bytes_per_launch"] + tr["bytes_per_batch_step"] * K
+                roof["traffic_source"] = PMC_PROFILE + " (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, separate passes, FETCH doubled)"
+            ib = prof.get("issue_bound")
+            if ib:   # second bound: scalar-pipe instructions per cycle per CU against the one scalar unit of a CU
+                roof["issue_bound"] = dict(ib, source=PMC_PROFILE)
         out = {
             "metric": "env steps/sec (polynomial additions) on 3-20-10-weighted, batch=4096, 1/2/4/8 GPU",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": Wm,
-            "ms_per_step": elapsed * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u16 exponents / u32 GF(32003)", "data": "synthetic (random binomial ideals drawn on the device from per-environment seeds, inside the timed region)",
-            "config": {"workload": "%s k=%d batch=%d/GPU random-hash agent auto-reset" % (args.dist, K_LEADS, B),
-                       "global_batch": B * world, "steps_per_launch": chunk, "parallelism": "env-sharded x%d, no collectives" % world},
+            "ms_per_step": elapsed * 1e3 / (R * K), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u16 exponents / u32 GF(32003)",
+            "data": "synthetic (random binomial ideals drawn on the device from per-environment seeds, inside the timed region)",
+            "repeats": R, "preroll_steps": max(args.preroll, 0) or 1, "timed_steps": R * K, "elapsed_s": elapsed,
+            "config": {"workload": "%s k=%d batch=%d/GPU random-hash agent auto-reset, observation written every step" % (args.dist, K_LEADS, B),
+                       "global_batch": B * world, "steps_per_launch": K, "parallelism": "env-sharded x%d, no collectives" % world},
             "additions_per_s": additions / elapsed,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes/launch",
-                         "traffic_source": traffic_src, "alg_bytes_per_launch": per_launch_bytes,
-                         "kernel": "bbx_fast_headline_kernel" if not args.ablate_obs else "bbx_fast_kernel<false,false>", "alg_bytes_per_env_step": alg_bytes / steps_done,
-                         "kernel_ms_per_launch": kernel_ms / nlaunch, "launches": nlaunch, "timed_region_ms": region_ms},
+            "roofline": roof,
             "cpu_baseline": cpu,
         }
         print(json.dumps(out))
+        sys.stdout.flush()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def cpu_baseline(args, env, st_final, steps_per_env, B):
+def cpu_baseline(args, st_final, steps_per_env, B):
     """Time the reference C++ itself (oracle/_ref, kind 'reference') — or our C restatement when the
     prebuilt reference library did not travel (kind 'port') — single-threaded on the host, on a
     bounded sample of the SAME workload: the first n environments (same ideal seeds, same agent
@@ -186,7 +237,7 @@ def cpu_baseline(args, env, st_final, steps_per_env, B):
     res = lib.bench_random(args.dist, K_LEADS, n, steps_per_env, 1000, 0)
     dev_adds = int(st_final[:n, 1].sum())
     return {"value": res["steps"] / res["seconds"], "unit": "env-steps/s", "cores": 1, "kind": kind,
-            "sample": "envs 0..%d of the same batch x %d steps (warmup+timed), %d steps, %.1f s" % (n - 1, steps_per_env, res["steps"], res["seconds"]),
+            "sample": "envs 0..%d of the same batch x %d steps each (pre-roll + warm-up + timed), %d steps, %.1f s" % (n - 1, steps_per_env, res["steps"], res["seconds"]),
             "additions_match_device": bool(res["additions"] == dev_adds)}
 
 

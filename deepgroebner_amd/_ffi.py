@@ -28,7 +28,7 @@ class BbxError(RuntimeError):
 class Caps(C.Structure):
     _fields_ = [("max_basis", C.c_int32), ("max_pairs", C.c_int32), ("arena_terms", C.c_int32),
                 ("max_poly_terms", C.c_int32), ("queue_slots", C.c_int32), ("lds_max_basis", C.c_int32),
-                ("wide_waves", C.c_int32), ("general_class", C.c_int32)]
+                ("wide_waves", C.c_int32), ("general_class", C.c_int32), ("wide_lds_terms", C.c_int32)]
 
 
 class TraceRec(C.Structure):

@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <random>
 #include <string>
 #include <vector>
 
@@ -134,7 +135,26 @@ struct bbx_batch {
   bool in_flight = false;
   int staged = 0, fast = 0, envs_per_block = 4;
   int wide = 0;                       // > 0: waves per environment of the wide (one workgroup per environment) class
+  int wide_terms = 0;                 // forced LDS capacity of the wide class (caps.wide_lds_terms), 0 = automatic
+  bool obs_external = false;          // the launch in flight writes observations into a caller-owned block: rows cut for
+                                      // lack of space are an error the caller must hear about (bbx_sync)
+  bbx_batch() = default;
+  bbx_batch(const bbx_batch&) = delete;
+  bbx_batch& operator=(const bbx_batch&) = delete;
+  ~bbx_batch();                       // frees every device / pinned allocation (also on half-built handles)
 };
+
+bbx_batch::~bbx_batch() {
+  if (!d_recs && !d_q && !d_out && !d_inv && !h_io) return;   // nothing was ever allocated
+  (void)hipSetDevice(device);
+  (void)hipDeviceSynchronize();
+  for (auto& ev : ev_open) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+  void* dev[] = {d_recs, d_q, d_tail, d_out, d_actions, d_mask, d_seeds, d_obs, d_trace, d_hdr, d_inv,
+                 d_vrecs, d_vhdr, d_vsrc, d_vseeds, d_vvals, d_stage, d_gen, d_obs_off, d_obs_packed};
+  for (void* q : dev) if (q) (void)hipFree(q);
+  void* pinned[] = {h_io, h_act, h_stage, h_zobs, h_obs};
+  for (void* q : pinned) if (q) (void)hipHostFree(q);
+}
 
 namespace {
 
@@ -282,6 +302,7 @@ void fill_params(bbx_batch* b, BbxParams* p) {
   p->accounting = b->accounting ? 1 : 0;
   p->lite = b->d_lite;
   p->gen = b->device_gen ? b->d_gen : nullptr;
+  p->wide_hc = b->wide_terms;
 }
 
 // enqueue the kernels of one logical launch: the LDS-staged pass (when the class allows) followed by the
@@ -362,50 +383,63 @@ int read_lite(bbx_batch* b, hipStream_t stream) {
   return BBX_OK;
 }
 
-// wait for the launch in flight; serve environments that ran out of queued ideals; surface errors
+// wait for the launch in flight; serve environments that ran out of queued ideals or outgrew the LDS class; surface
+// errors.  Whatever happens, the handle is left with nothing in flight: an error is reported once, not re-raised by
+// every later call, and environments that only needed service (STARVED / SPILL) have been served before the first
+// error of another environment is returned.
 int finish(bbx_batch* b, hipStream_t stream) {
+  int err = BBX_OK;
+  auto note = [&err](int code) { if (err == BBX_OK) err = code; };
   for (int round = 0;; round++) {
     int rc = read_lite(b, stream);
-    if (rc) return rc;
+    if (rc) { b->in_flight = false; return rc; }
     rc = collect_events(b);
-    if (rc) return rc;
+    if (rc) { b->in_flight = false; return rc; }
     bool again = false;
     for (int e = 0; e < b->B; e++) {
-      int st = b->h_lite[(size_t)e * 4];
+      const int st = b->h_lite[(size_t)e * 4] & 0xffff;
       if (st == BBX_ST_STARVED && !b->gen_error.empty() && !b->gen_error[e].empty() && b->h_tail[e] - b->h_head[e] <= 0) {
-        const std::string msg = b->gen_error[e];       // the draw this environment is waiting for is the one that failed
-        b->gen_error[e].clear();
-        b->in_flight = false;
-        return fail(BBX_E_GENERATOR, "%s", msg.c_str());
+        if (err == BBX_OK) {
+          const std::string msg = b->gen_error[e];       // the draw this environment is waiting for is the one that failed
+          b->gen_error[e].clear();
+          note(fail(BBX_E_GENERATOR, "%s", msg.c_str()));
+        }
+        continue;
       }
-      if (st == BBX_ST_GEN_ZERO) { b->in_flight = false; return fail(BBX_E_GENERATOR, "random polynomial cancelled to zero (undefined in the reference)"); }
-      if (st == BBX_ST_GEN_FAIL) { b->in_flight = false; return fail(BBX_E_GENERATOR, "failed to generate two distinct random monomials after 1000 trials"); }
-      if (st == BBX_ST_STARVED || st == BBX_ST_SPILL) again = true;
-      else if (st == BBX_ST_BAD_ACTION) return fail(BBX_E_ACTION, "environment %d: %s", e, status_name(st));
-      else if (st != BBX_ST_OK) {
+      if (st == BBX_ST_GEN_ZERO) { if (err == BBX_OK) note(fail(BBX_E_GENERATOR, "random polynomial cancelled to zero (undefined in the reference)")); }
+      else if (st == BBX_ST_GEN_FAIL) { if (err == BBX_OK) note(fail(BBX_E_GENERATOR, "failed to generate two distinct random monomials after 1000 trials")); }
+      else if (st == BBX_ST_STARVED || st == BBX_ST_SPILL) again = true;
+      else if (st == BBX_ST_BAD_ACTION) { if (err == BBX_OK) note(fail(BBX_E_ACTION, "environment %d: %s", e, status_name(st))); }
+      else if (st != BBX_ST_OK && err == BBX_OK) {
         rc = read_headers(b, stream);
-        if (rc) return rc;
-        return fail(BBX_E_CAPACITY, "environment %d: %s (|G|=%d |P|=%d terms=%d)", e, status_name(st),
-                    b->h_hdr[e].nG, b->h_hdr[e].nP, b->h_hdr[e].arena_used);
+        if (rc) { b->in_flight = false; return rc; }
+        note(fail(BBX_E_CAPACITY, "environment %d: %s (|G|=%d |P|=%d terms=%d)", e, status_name(st),
+                  b->h_hdr[e].nG, b->h_hdr[e].nP, b->h_hdr[e].arena_used));
       }
     }
     if (!again) break;
-    if (round > 100000) return fail(BBX_E_GENERATOR, "ideal queue starvation did not resolve");
+    if (round > 100000) { note(fail(BBX_E_GENERATOR, "ideal queue starvation did not resolve")); break; }
     rc = fill_queues(b, 1, stream);
-    if (rc) return rc;
+    if (rc) { b->in_flight = false; return rc; }
     rc = enqueue(b, b->last, true, stream);   // continue the rollout where each environment stopped
-    if (rc) return rc;
+    if (rc) { b->in_flight = false; return rc; }
   }
   b->in_flight = false;
-  return BBX_OK;
+  if (err == BBX_OK && b->obs_external)
+    for (int e = 0; e < b->B; e++)
+      if (b->h_lite[(size_t)e * 4] & BBX_LITE_OBS_TRUNC)
+        return fail(BBX_E_CAPACITY, "environment %d: an observation had more rows than the caller's block holds (obs_rows = %d); "
+                                    "the extra rows were not written", e, b->last.obs_rows);
+  return err;
 }
 
-int launch(bbx_batch* b, BbxParams& p, hipStream_t stream) {
+int launch(bbx_batch* b, BbxParams& p, hipStream_t stream, bool obs_external = false) {
   int rc = fill_queues(b, 1, stream);
   if (rc) return rc;
   b->last = p;
   b->last_stream = stream;
   b->in_flight = true;
+  b->obs_external = obs_external;
   return enqueue(b, p, false, stream);
 }
 
@@ -474,9 +508,14 @@ int create_common(std::unique_ptr<bbx::IdealGen> proto, int nvars_obs, int elimi
     if (!c.arena_terms) c.arena_terms = 1 << 18; if (!c.max_poly_terms) c.max_poly_terms = 4096;
   }
   if (!c.queue_slots) c.queue_slots = 8;
+  // every array of a record starts 16-byte aligned; the hand-tuned kernel derives the array offsets of the 8-byte
+  // monomial layout from the basis capacity alone (bbx_fast.h F_HBM_PTRS), which is exact for even capacities
+  if (c.max_basis & 1) c.max_basis += c.max_basis < 65535 ? 1 : -1;
   b->binom = binomial && !c.general_class && !getenv("BBX_NO_BINOM");
   // long-polynomial environments (fixed ideals such as cyclic-n) in small batches: one workgroup per environment
-  if ((b->fixed || list) && !getenv("BBX_NO_WIDE")) b->wide = c.wide_waves > 0 ? std::min(8, c.wide_waves) : (c.wide_waves < 0 ? 0 : (batch <= 2048 ? 8 : 0));
+  if ((b->fixed || list) && !getenv("BBX_NO_WIDE")) b->wide = c.wide_waves > 0 ? std::min(8, c.wide_waves) : (c.wide_waves < 0 ? 0 : (batch <= 4096 ? 8 : 0));
+  if (c.wide_lds_terms < 0 || c.wide_lds_terms > 4096) return fail(BBX_E_ARG, "wide_lds_terms out of range");
+  b->wide_terms = c.wide_lds_terms;
   // LDS-resident class: small binomial environments work out of LDS for the whole launch; anything that
   // outgrows it continues in the HBM-resident pass of the same launch sequence
   b->staged = 0;
@@ -502,11 +541,17 @@ int create_common(std::unique_ptr<bbx::IdealGen> proto, int nvars_obs, int elimi
   b->slot_words = 1 + (uint32_t)proto->npolys() * (2 + (uint32_t)std::min(proto->max_terms_hint(), c.max_poly_terms) * (1 + b->W));
   b->slot_words = (b->slot_words + 3u) & ~3u;
 
+  // An unseeded generator of the reference seeds itself from std::random_device (ideals.cpp:163-164, 209-210), so two
+  // environments built without seed() see different ideals; same here: environment e starts from base + e with a
+  // random base per handle (BBX_DEFAULT_SEED pins it for debugging).  bbx_seed makes a run reproducible.
+  long long seed_base;
+  if (const char* sb = getenv("BBX_DEFAULT_SEED")) seed_base = atoll(sb);
+  else { std::random_device rd; seed_base = (long long)(rd() & 0x3fffffffu); }
   if (b->fixed) b->gens.push_back(std::move(proto));
   else {
     for (int e = 0; e < batch; e++) {
       if (list) b->gens.push_back(bbx::make_list(list, e, batch, proto->nvars()));   // environment e: ideals e, e+B, ...
-      else { b->gens.push_back(proto->clone()); b->gens.back()->seed(5489 + e); }
+      else { b->gens.push_back(proto->clone()); b->gens.back()->seed(seed_base + e); }
     }
   }
   const size_t qwords = b->fixed ? b->slot_words : (size_t)batch * b->nslots * b->slot_words;
@@ -540,7 +585,7 @@ int create_common(std::unique_ptr<bbx::IdealGen> proto, int nvars_obs, int elimi
     HIPCHK(hipMemcpy(b->d_gen, gen_table.data(), gen_table.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     b->device_gen = true; b->gen_words = gen_table.size();
     std::vector<long long> seeds(batch);
-    for (int e = 0; e < batch; e++) seeds[e] = 5489 + e;            // the default seeding of the host generators above
+    for (int e = 0; e < batch; e++) seeds[e] = seed_base + e;       // the default seeding of the host generators above
     HIPCHK(hipDeviceSynchronize());
     int rc = write_gen_states(b.get(), seeds);
     if (rc) return rc;
@@ -615,24 +660,7 @@ int bbx_create_ideals(int nideals, const int32_t* npolys, const int32_t* nterms,
                        k, batch, device, caps, out, clist);
 }
 
-void bbx_destroy(bbx_batch* b) {
-  if (!b) return;
-  (void)hipSetDevice(b->device);
-  (void)hipDeviceSynchronize();
-  void* bufs[] = {b->d_recs, b->d_q, b->d_tail, b->d_out, b->d_actions, b->d_mask, b->d_seeds, b->d_obs, b->d_trace, b->d_hdr, b->d_inv,
-                  b->d_vrecs, b->d_vhdr, b->d_vsrc, b->d_vseeds, b->d_vvals};
-  for (void* p : bufs) (void)hipFree(p);
-  if (b->h_io) (void)hipHostFree(b->h_io);
-  if (b->h_act) (void)hipHostFree(b->h_act);
-  if (b->h_stage) (void)hipHostFree(b->h_stage);
-  if (b->d_stage) (void)hipFree(b->d_stage);
-  if (b->d_gen) (void)hipFree(b->d_gen);
-  if (b->h_zobs) (void)hipHostFree(b->h_zobs);
-  if (b->h_obs) (void)hipHostFree(b->h_obs);
-  if (b->d_obs_off) (void)hipFree(b->d_obs_off);
-  if (b->d_obs_packed) (void)hipFree(b->d_obs_packed);
-  delete b;
-}
+void bbx_destroy(bbx_batch* b) { delete b; }
 
 int bbx_copy(const bbx_batch* s, bbx_batch** out) {
   if (!s || !out) return fail(BBX_E_ARG, "null argument");
@@ -643,7 +671,7 @@ int bbx_copy(const bbx_batch* s, bbx_batch** out) {
   b->elim = s->elim; b->rewards = s->rewards; b->sort_input = s->sort_input; b->sort_reducers = s->sort_reducers;
   b->fixed = s->fixed; b->binom = s->binom; b->L = s->L; b->LL = s->LL; b->slot_words = s->slot_words; b->nslots = s->nslots;
   b->h_q = s->h_q; b->h_tail = s->h_tail; b->h_head = s->h_head; b->q_dirty = true;
-  b->wide = s->wide; b->accounting = s->accounting; b->staged = s->staged; b->fast = s->fast; b->envs_per_block = s->envs_per_block;
+  b->wide = s->wide; b->wide_terms = s->wide_terms; b->accounting = s->accounting; b->staged = s->staged; b->fast = s->fast; b->envs_per_block = s->envs_per_block;
   if (s->device_gen) {
     HIPCHK(hipMalloc((void**)&b->d_gen, s->gen_words * sizeof(uint32_t)));
     HIPCHK(hipMemcpy(b->d_gen, s->d_gen, s->gen_words * sizeof(uint32_t), hipMemcpyDeviceToDevice));
@@ -914,18 +942,22 @@ int bbx_step_device(bbx_batch* b, const int32_t* d_actions, double* d_rewards, u
   BbxParams p; fill_params(b, &p);
   p.nsteps = 1; p.set_budget = 1; p.agent = BBX_AGENT_EXTERNAL; p.auto_reset = 0; p.actions = d_actions;
   p.rewards = d_rewards; p.dones = d_dones; p.rows = d_rows; p.obs = d_obs; p.obs_rows = obs_rows; p.obs_fill = obs_fill;
-  return launch(b, p, (hipStream_t)stream);
+  if (d_obs && obs_rows < 1) return fail(BBX_E_ARG, "obs_rows must be positive");
+  if (b->d_trace && b->trace_cap < 1) p.trace = nullptr;
+  return launch(b, p, (hipStream_t)stream, d_obs != nullptr);
 }
 
 int bbx_rollout_device(bbx_batch* b, int agent, int nsteps, int auto_reset, double* d_rewards, uint8_t* d_dones,
                        int32_t* d_rows, int32_t* d_obs, int obs_rows, int obs_fill, int obs_every_step, void* stream) {
   if (!b || nsteps < 0 || agent < BBX_RANDOM_HASH || agent > BBX_RANDOM_STD) return fail(BBX_E_ARG, "bad rollout arguments");
   HIPCHK(hipSetDevice(b->device));
+  if (b->d_trace && nsteps > b->trace_cap) return fail(BBX_E_ARG, "rollout of %d steps exceeds the trace capacity %d", nsteps, b->trace_cap);
+  if (d_obs && obs_rows < 1) return fail(BBX_E_ARG, "obs_rows must be positive");
   BbxParams p; fill_params(b, &p);
   p.obs_every_step = obs_every_step ? 1 : 0;
   p.nsteps = nsteps; p.set_budget = 1; p.agent = agent; p.auto_reset = auto_reset ? 1 : 0;
   p.rewards = d_rewards; p.dones = d_dones; p.rows = d_rows; p.obs = d_obs; p.obs_rows = obs_rows; p.obs_fill = obs_fill;
-  return launch(b, p, (hipStream_t)stream);
+  return launch(b, p, (hipStream_t)stream, d_obs != nullptr);
 }
 
 int bbx_sync(bbx_batch* b) {
@@ -1081,7 +1113,8 @@ int value_rollouts(bbx_batch* b, const std::vector<int32_t>& src, int agent, con
   p.recs = b->d_vrecs; p.B = n; p.nsteps = 1 << 30; p.set_budget = 1; p.agent = agent; p.auto_reset = 0;
   p.value_mode = 1; p.gamma = gamma; p.values = b->d_vvals; p.trace = nullptr; p.accounting = 0;
   p.lite = nullptr;                                           // the clones are not the batch's environments
-  lrc = bbx_launch_step(&p, 0, b->envs_per_block, 0);       // HBM-resident class kernel (no resets, no staging)
+  // HBM-resident class kernel (no resets, no staging); long-polynomial environments: one workgroup per clone
+  lrc = b->wide ? bbx_launch_step(&p, 4, b->wide, 0) : bbx_launch_step(&p, 0, b->envs_per_block, 0);
   if (lrc) return fail(BBX_E_DEVICE, "kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
   lrc = bbx_launch_gather_hdr(b->d_vrecs, b->L.rec_bytes, n, b->d_vhdr, 0);
   if (lrc) return fail(BBX_E_DEVICE, "gather launch failed: %s", hipGetErrorString((hipError_t)lrc));

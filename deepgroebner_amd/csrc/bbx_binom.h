@@ -257,7 +257,8 @@ __device__ __forceinline__ void binom_body(const BbxParams& p, char* smem) {
   int done_last = uni(ghdr->done_last);
   if (status == BBX_ST_STARVED || status == BBX_ST_SPILL) status = BBX_ST_OK;
   double vret = ghdr->vret, vdisc = ghdr->vdisc;
-  if (p.set_budget) { budget = p.nsteps; rollout_pos = 0; done_last = 0; vret = 0.0; vdisc = 1.0; }
+  int obs_trunc = uni(ghdr->obs_trunc);
+  if (p.set_budget) { budget = p.nsteps; rollout_pos = 0; done_last = 0; vret = 0.0; vdisc = 1.0; obs_trunc = 0; }
   if (p.pass == 1 && !(status == BBX_ST_OK && (need_reset || (budget > 0 && nP > 0)))) return;
 
   BEnv<W> ge = benv_view<W>(grec, p.L);
@@ -396,7 +397,7 @@ __device__ __forceinline__ void binom_body(const BbxParams& p, char* smem) {
     total_steps++; total_adds += 1 + nsteps_red; t_agent++; episode_steps++; steps_done++;
     const bool done = nP == 0;
 
-    if (p.obs_every_step && p.obs) bin_obs<W, false>(e, p, env, nP, true, false);
+    if (p.obs_every_step && p.obs) { bin_obs<W, false>(e, p, env, nP, true, false); obs_trunc |= nP > p.obs_rows ? 1 : 0; }
     if (TRACE && tracing) {
       uint64_t oh = bin_obs<W, true>(e, p, env, nP, false, true);
       uint64_t ph = wave_pairs_hash<W, BEnv<W>>(e, nP);
@@ -416,7 +417,7 @@ __device__ __forceinline__ void binom_body(const BbxParams& p, char* smem) {
   }
 
   const bool handoff = status == BBX_ST_SPILL;
-  if (p.obs && status == BBX_ST_OK) bin_obs<W, false>(e, p, env, nP, true, false);
+  if (p.obs && status == BBX_ST_OK) { bin_obs<W, false>(e, p, env, nP, true, false); obs_trunc |= nP > p.obs_rows ? 1 : 0; }
   if (STAGED && staged_in) {
     wave_sync();
     bstage_copy<W>(ge, e, nG, nP);
@@ -428,8 +429,8 @@ __device__ __forceinline__ void binom_body(const BbxParams& p, char* smem) {
     h->gen_rng = gen_state;
     h->total_additions = total_adds; h->episodes = episodes; h->zero_reductions = zero_red; h->steps_done = steps_done;
     h->budget = budget; h->rollout_pos = rollout_pos; h->done_last = done_last; h->alg_bytes = alg_bytes;
-    h->vret = vret; h->vdisc = vdisc;
-    if (p.lite) *(int4*)(p.lite + 4 * (size_t)env) = make_int4(status, q_head, budget, nP);
+    h->vret = vret; h->vdisc = vdisc; h->obs_trunc = obs_trunc;
+    if (p.lite) *(int4*)(p.lite + 4 * (size_t)env) = make_int4(status | (obs_trunc ? BBX_LITE_OBS_TRUNC : 0), q_head, budget, nP);
     if (p.value_mode && p.values) p.values[env] = vret;
     if (!handoff) {
       if (p.rewards && (steps_done > 0 || p.pass == 0)) p.rewards[env] = last_reward;

@@ -48,6 +48,10 @@ enum {
                             // same launch sequence continues this environment
 };
 
+// the status word of the `lite` block ({status, q_head, budget, |P|} per environment, polled by the host after a
+// launch) carries this flag on top of the status code: BbxHdr.obs_trunc != 0
+#define BBX_LITE_OBS_TRUNC 0x10000
+
 struct BbxHdr {             // 128 bytes
   int32_t nG, nP, arena_used, status;
   int32_t need_reset, q_head, t, episode_steps;
@@ -63,7 +67,9 @@ struct BbxHdr {             // 128 bytes
   double vret, vdisc;       // value() rollouts: discounted return so far and the current discount (buchberger.cpp:248-252)
   uint32_t gen_rng;         // state of this environment's ideal generator engine (minstd_rand0) when ideals are drawn
                             // on the device (BbxParams.gen != null); the host-side generators then stay unused
-  int32_t reserved[5];
+  int32_t obs_trunc;        // != 0: during the current rollout an observation had more rows than the caller's block holds
+                            // (rows beyond obs_rows were not written); reported by bbx_sync as BBX_E_CAPACITY
+  int32_t reserved[4];
 };
 
 struct BbxLayout {
@@ -133,6 +139,8 @@ struct BbxParams {
   int32_t* lite;            // [B][4] {status, q_head, budget, |P|}: what the host polls after a launch, or null
   BbxTraceRec* trace;       // [B, trace_stride] or null
   int32_t trace_stride;
+  int32_t wide_hc, wide_fc, wide_rc, wide_sc;   // wide class: LDS capacities (terms) of the polynomial being reduced, the
+                                       // reducer-tail window, the reducer table and the accumulator; wide_hc == 0: chosen by the launcher
 };
 
 // Device-side ideal generation (RandomBinomialIdealGenerator, ideals.cpp:156-201): one immutable table per batch, words:

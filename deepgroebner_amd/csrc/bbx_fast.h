@@ -171,6 +171,7 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
   int trace_pos = rollout_pos;                                        // TRACE only
   long long bytes_total = 0;
   int last_nred = vzero - 1;                           // reward of the last step, kept as its integer reduction count
+  int obs_trunc = vzero;                               // an observation had more rows than the caller's block (rows cut)
   const bool tracing = TRACE && p.trace != nullptr;
   const int n = HL ? 3 : p.nvars, kk = HL ? 2 : p.k;
   const int agent = HL ? BBX_AGENT_HASH : p.agent;
@@ -583,7 +584,7 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
     if ((t_agent & 63) == 0) hv = bbx_agent_hash32(agent_seed, (uint32_t)(t_agent + lane));
     const bool done = nP == 0;
 
-    if (obs_step) { if (obs32) write_obs32(); else write_obs(true, false); }
+    if (obs_step) { if (obs32) write_obs32(); else write_obs(true, false); obs_trunc |= nP > p.obs_rows ? 1 : 0; }
     if (TRACE && tracing) {
       const uint64_t oh = write_obs(false, true);
       uint64_t ph = 0;
@@ -620,7 +621,7 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
   if (PROF && cz->prof && lane == 0) for (int i = 0; i < 8; i++) cz->prof[(size_t)env * 8 + i] = prof_sum[i];
 
   const bool handoff = status == BBX_ST_SPILL;
-  if (p.obs && status == BBX_ST_OK) { if (obs32) write_obs32(); else write_obs(true, false); }
+  if (p.obs && status == BBX_ST_OK) { if (obs32) write_obs32(); else write_obs(true, false); obs_trunc |= nP > p.obs_rows ? 1 : 0; }
   if (staged_in) {                                                   // write the live prefixes back to the HBM record
     wave_sync();
     F_HBM_PTRS(cz)
@@ -639,7 +640,9 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
     h->gen_rng = gen_state;
     h->episodes += episodes; h->zero_reductions += zero_red; h->steps_done = steps_done;
     h->budget = budget; h->rollout_pos = rollout_pos; h->done_last = done_last; h->alg_bytes += bytes_total;
-    if (cz->lite) *(int4*)(cz->lite + 4 * (size_t)env) = make_int4(status, q_head, budget, nP);
+    const int trunc_all = (cz->set_budget ? 0 : h->obs_trunc) | obs_trunc;
+    h->obs_trunc = trunc_all;
+    if (cz->lite) *(int4*)(cz->lite + 4 * (size_t)env) = make_int4(status | (trunc_all ? BBX_LITE_OBS_TRUNC : 0), q_head, budget, nP);
     if (!handoff) {
       double* rw = cz->rewards; uint8_t* dn = cz->dones; int32_t* rws = cz->rows;
       if (rw && (steps_done > 0 || cz->pass == 0))
@@ -659,8 +662,10 @@ __global__ __launch_bounds__(256) void bbx_fast_headline_kernel(BbxFastParams p)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   fast_body<false, false, false, true>(p, smem);
 }
+#ifdef BBX_PROF_BUILD
 // diagnostic build with s_memtime stamps between the phases of a step (never timed, never shipped as a result)
 __global__ __launch_bounds__(256) void bbx_fast_prof_kernel(BbxFastParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   fast_body<false, false, true>(p, smem);
 }
+#endif

@@ -416,101 +416,6 @@ __device__ int wave_merge_tiled(const PView<W>& A, const PView<W>& B, char* lds,
   return nout > ocap ? -1 : nout;
 }
 
-// ------------------------------------------------------------------ cooperative merge: one workgroup per environment
-// Long-polynomial environments (cyclic-n) run few in number (BASELINE: 512), so one wave each leaves most of the chip
-// idle while the merges of one reduction round are embarrassingly parallel across tiles.  In the wide kernel wave 0
-// of a workgroup (the leader) runs the ordinary step code; the other waves park at a workgroup barrier and are woken
-// for every long merge: tiles are dealt round-robin to all waves, each wave squeezes its tiles into the staging
-// buffer, then (second barrier) copies them to their final offsets, then (third barrier) the leader goes on alone.
-constexpr int COOP_MAXT = 510;                             // tiles per cooperative merge (94k terms at MT = 184)
-struct CoopCmd {
-  int cmd;                                                 // 1 = merge, 2 = exit
-  int ntiles, ocap, overflow;
-  int na, nb;
-  uint32_t ascale, bscale;
-  uint32_t ashift[4], bshift[4];
-  const void *am, *ac, *bm, *bc;
-  void *om, *oc, *tm, *tc;
-  int bi[COOP_MAXT + 2], bj[COOP_MAXT + 2], cnt[COOP_MAXT + 2];
-};
-constexpr int coop_cmd_bytes() { return (int)((sizeof(CoopCmd) + 255) / 256 * 256); }
-
-template <int W>
-__device__ void coop_work(CoopCmd* cc, char* lds_tile, int wave, int nwaves, unsigned long long* prof = nullptr) {
-  unsigned long long tq_ = prof ? __builtin_amdgcn_s_memtime() : 0;
-  PView<W> A, B;
-  A.m = (const Mono<W>*)cc->am; A.c = (const uint16_t*)cc->ac; A.n = cc->na; A.scale = cc->ascale;
-  B.m = (const Mono<W>*)cc->bm; B.c = (const uint16_t*)cc->bc; B.n = cc->nb; B.scale = cc->bscale;
-#pragma unroll
-  for (int q = 0; q < W; q++) { A.shift.w[q] = cc->ashift[q]; B.shift.w[q] = cc->bshift[q]; }
-  const int ntiles = cc->ntiles;
-  Mono<W>* tm = (Mono<W>*)cc->tm; uint16_t* tc = (uint16_t*)cc->tc;
-  for (int t = wave; t < ntiles; t += nwaves) {            // phase 1: my tiles, squeezed, into the staging buffer
-    const int c = merge_tile<W>(A, B, cc->bi[t], cc->bj[t], cc->bi[t + 1], cc->bj[t + 1], lds_tile, tm + (size_t)t * MT, tc + (size_t)t * MT, MT);
-    if (lane_id() == 0) cc->cnt[t] = c;
-  }
-  if (prof) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); prof[1] += t_ - tq_; tq_ = t_; }   // my tiles
-  __syncthreads();
-  if (prof) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); prof[2] += t_ - tq_; tq_ = t_; }   // waiting for the others
-  Mono<W>* om = (Mono<W>*)cc->om; uint16_t* oc = (uint16_t*)cc->oc;
-  for (int t = wave; t < ntiles; t += nwaves) {            // phase 2: to the final offsets
-    int off = 0;
-    for (int s = lane_id(); s < t; s += WAVE) off += cc->cnt[s];
-    for (int o = 32; o > 0; o >>= 1) off += __shfl_xor(off, o, WAVE);
-    const int c = cc->cnt[t];
-    if (off + c > cc->ocap) { if (lane_id() == 0) cc->overflow = 1; continue; }
-    for (int q = lane_id(); q < c; q += WAVE) { om[off + q] = tm[(size_t)t * MT + q]; oc[off + q] = tc[(size_t)t * MT + q]; }
-  }
-  __syncthreads();
-  if (prof) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); prof[3] += t_ - tq_; }              // copy + barrier
-}
-
-// leader side; all helper waves are parked at the first barrier of coop_helper_loop
-template <int W>
-__device__ int coop_merge(const PView<W>& A, const PView<W>& B, CoopCmd* cc, char* lds_tile, int nwaves,
-                          Mono<W>* tm, uint16_t* tc, Mono<W>* om, uint16_t* oc, int ocap, unsigned long long* prof = nullptr) {
-  const int lane = lane_id();
-  unsigned long long tq_ = prof ? __builtin_amdgcn_s_memtime() : 0;
-  const int total = A.n + B.n;
-  const int ntiles = (total + MT - 1) / MT;
-  if (ntiles + 1 <= 16) {                                  // few boundaries: 8 lanes each, 8-ary search
-    for (int t0 = 0; t0 <= ntiles; t0 += 8) {
-      int bi, bj;
-      merge_partition8<W>(A, B, t0, bi, bj);
-      if ((lane & 7) == 0 && t0 + (lane >> 3) <= ntiles) { cc->bi[t0 + (lane >> 3)] = bi; cc->bj[t0 + (lane >> 3)] = bj; }
-    }
-  } else {
-    for (int t0 = 0; t0 <= ntiles; t0 += 64) {             // every boundary 0..ntiles, one per lane
-      int bi, bj;
-      merge_partition<W>(A, B, t0, bi, bj);
-      if (t0 + lane <= ntiles) { cc->bi[t0 + lane] = bi; cc->bj[t0 + lane] = bj; }
-    }
-  }
-  if (lane == 0) {
-    cc->cmd = 1; cc->ntiles = ntiles; cc->ocap = ocap; cc->overflow = 0; cc->na = A.n; cc->nb = B.n;
-    cc->ascale = A.scale; cc->bscale = B.scale;
-    for (int q = 0; q < W; q++) { cc->ashift[q] = A.shift.w[q]; cc->bshift[q] = B.shift.w[q]; }
-    cc->am = A.m; cc->ac = A.c; cc->bm = B.m; cc->bc = B.c; cc->om = om; cc->oc = oc; cc->tm = tm; cc->tc = tc;
-  }
-  __syncthreads();                                         // barrier 1: wake the helpers
-  if (prof) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); prof[0] += t_ - tq_; }               // partition + post
-  coop_work<W>(cc, lds_tile, 0, nwaves, prof);             // barriers 2 and 3 inside
-  int nout = 0;
-  for (int s = lane; s < ntiles; s += WAVE) nout += cc->cnt[s];
-  for (int o = 32; o > 0; o >>= 1) nout += __shfl_xor(nout, o, WAVE);
-  nout = uni(nout);
-  return (cc->overflow || nout > ocap) ? -1 : nout;
-}
-
-template <int W>
-__device__ void coop_helper_loop(CoopCmd* cc, char* lds_tile, int wave, int nwaves) {
-  for (;;) {
-    __syncthreads();                                       // barrier 1: wait for a command
-    if (cc->cmd == 2) break;
-    coop_work<W>(cc, lds_tile, wave, nwaves);              // barriers 2 and 3 inside
-  }
-}
-
 // ------------------------------------------------------------------ ideal generation on the device
 // The reference draws every new ideal from std::default_random_engine (minstd_rand0) through libstdc++ 11's
 // uniform_int_distribution / discrete_distribution (generate_canonical<double, 53>: two engine draws) — restated here
@@ -723,13 +628,14 @@ __device__ void wave_insert_reducer(Env<W>& e, int nR, int g, const Mono<W> lmf,
 template <int W>
 __device__ bool wave_add_poly(Env<W>& e, const BbxLayout& L, int& nG, int& nP, int& arena_used,
                               const Mono<W>* sm, const uint16_t* sc, int n, int sugar,
-                              int elim, int sort_reducers, int* status) {
+                              int elim, int sort_reducers, int* status, bool in_place = false) {
   const int lane = lane_id();
   if (nG >= (int)L.maxG) { *status = BBX_ST_G_FULL; return false; }
   if (n > 65535) { *status = BBX_ST_POLY_TOO_LONG; return false; }       // plen[] is 16 bits
   if (arena_used + n > (int)L.arena) { *status = BBX_ST_ARENA_FULL; return false; }
   const int g = nG, off = arena_used;
-  for (int t = lane; t < n; t += WAVE) { e.am[off + t] = sm[t]; e.ac[off + t] = sc[t]; }
+  // in_place: the terms already sit at the arena's end (the wide class builds the remainder there)
+  if (!in_place) for (int t = lane; t < n; t += WAVE) { e.am[off + t] = sm[t]; e.ac[off + t] = sc[t]; }
   const Mono<W> lmf = sm[0];
   const uint32_t lc = sc[0];
   if (lane == 0) {
@@ -998,15 +904,13 @@ __device__ void stage_copy(const Env<W>& dst, const Env<W>& src, int nG, int nP,
 }
 
 template <int W, bool STAGED, bool TRACE, bool PROF = false>
-__device__ __forceinline__ void step_body(const BbxParams& p, char* smem, unsigned long long* prof_out = nullptr,
-                                          CoopCmd* coop = nullptr, int coop_waves = 0) {
+__device__ __forceinline__ void step_body(const BbxParams& p, char* smem, unsigned long long* prof_out = nullptr) {
   const int lane = lane_id();
   unsigned long long ps[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // diagnostic build: cycles per phase
   unsigned long long pl = PROF ? __builtin_amdgcn_s_memtime() : 0;
 #define GSTAMP(slot) do { if (PROF) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); ps[slot] += t_ - pl; pl = t_; } } while (0)
-  // wide kernel (coop != null): one workgroup per environment, this is its leader wave
-  const int wave_in_block = coop ? 0 : uni((int)(threadIdx.x / WAVE));   // provably wave-uniform: record addresses live in SGPRs
-  const int env = coop ? (int)blockIdx.x : (int)(blockIdx.x * (blockDim.x / WAVE) + wave_in_block);
+  const int wave_in_block = uni((int)(threadIdx.x / WAVE));   // provably wave-uniform: record addresses live in SGPRs
+  const int env = (int)(blockIdx.x * (blockDim.x / WAVE) + wave_in_block);
   if (env >= p.B) return;                       // whole wave exits together
   char* grec = p.recs + (size_t)env * p.L.rec_bytes;
   BbxHdr* ghdr = (BbxHdr*)grec;
@@ -1024,7 +928,8 @@ __device__ __forceinline__ void step_body(const BbxParams& p, char* smem, unsign
   int done_last = uni(ghdr->done_last);
   if (status == BBX_ST_STARVED || status == BBX_ST_SPILL) status = BBX_ST_OK;   // transient states: try again
   double vret = ghdr->vret, vdisc = ghdr->vdisc;
-  if (p.set_budget) { budget = p.nsteps; rollout_pos = 0; done_last = 0; vret = 0.0; vdisc = 1.0; }
+  int obs_trunc = uni(ghdr->obs_trunc);
+  if (p.set_budget) { budget = p.nsteps; rollout_pos = 0; done_last = 0; vret = 0.0; vdisc = 1.0; obs_trunc = 0; }
   if (p.pass == 1 && !(status == BBX_ST_OK && (need_reset || (budget > 0 && nP > 0)))) return;  // nothing left to do here
 
   Env<W> ge = env_view<W>(grec, p.L);
@@ -1046,7 +951,7 @@ __device__ __forceinline__ void step_body(const BbxParams& p, char* smem, unsign
   double last_reward = 0.0;
   const bool tracing = TRACE && p.trace != nullptr;   // hashing code exists only in the TRACE instantiations
   // per-wave LDS tile scratch of the merge-path merge (HBM-resident class only; the launcher provides it)
-  char* mlds = (!STAGED && smem != nullptr) ? smem + (coop ? (size_t)coop_cmd_bytes() : (size_t)wave_in_block * merge_lds_bytes<W>()) : nullptr;
+  char* mlds = (!STAGED && smem != nullptr) ? smem + (size_t)wave_in_block * merge_lds_bytes<W>() : nullptr;
 
   // scratch polynomials
   const int maxT = (int)L.maxT;
@@ -1117,8 +1022,7 @@ __device__ __forceinline__ void step_body(const BbxParams& p, char* smem, unsign
       if (A.n + Bv.n > 2 * maxT) { status = BBX_ST_POLY_TOO_LONG; break; }
       GSTAMP(0);                                   // 0: loop top, agent, pair removal
       const bool big = mlds && A.n > 0 && Bv.n > 0 && A.n + Bv.n > 64;
-      if (big && coop && A.n + Bv.n > 2 * MT && A.n + Bv.n <= COOP_MAXT * MT && A.n + Bv.n + MT <= 2 * maxT) hn = coop_merge<W>(A, Bv, coop, mlds, coop_waves, tm, tc, hm, hc, maxT);
-      else hn = big ? wave_merge_tiled<W>(A, Bv, mlds, hm, hc, maxT) : wave_merge<W>(A, Bv, tm, tc, hm, hc, maxT);
+      hn = big ? wave_merge_tiled<W>(A, Bv, mlds, hm, hc, maxT) : wave_merge<W>(A, Bv, tm, tc, hm, hc, maxT);
       if (hn < 0) { status = BBX_ST_POLY_TOO_LONG; break; }
       GSTAMP(1);                                   // 1: S-polynomial merge
       alg_bytes += 12LL * (A.n + Bv.n + 2 + hn);   // both inputs read, S-polynomial written
@@ -1152,9 +1056,7 @@ __device__ __forceinline__ void step_body(const BbxParams& p, char* smem, unsign
         Mono<W>* nm = (hm == hm0) ? hm1 : hm0; uint16_t* nc = (hc == hc0) ? hc1 : hc0;
         GSTAMP(3);                                // 3: reducer fetch / setup
         const bool big = mlds && A.n > 0 && Bv.n > 0 && A.n + Bv.n > 64;
-        int nn;
-        if (big && coop && A.n + Bv.n > 2 * MT && A.n + Bv.n <= COOP_MAXT * MT && A.n + Bv.n + MT <= 2 * maxT) nn = coop_merge<W>(A, Bv, coop, mlds, coop_waves, tm, tc, nm, nc, maxT, PROF ? &ps[6] : nullptr);
-        else nn = big ? wave_merge_tiled<W>(A, Bv, mlds, nm, nc, maxT) : wave_merge<W>(A, Bv, tm, tc, nm, nc, maxT, PROF ? &ps[6] : nullptr);
+        const int nn = big ? wave_merge_tiled<W>(A, Bv, mlds, nm, nc, maxT) : wave_merge<W>(A, Bv, tm, tc, nm, nc, maxT, PROF ? &ps[6] : nullptr);
         if (nn < 0) { status = BBX_ST_POLY_TOO_LONG; overflow = true; break; }
         GSTAMP(4);                                // 4: reduction merges (6/7: their pass 1 / pass 2)
         alg_bytes += 8LL * (found + 1) + 12LL * (Bv.n + 1) + 12LL * (A.n + 1 + nn);
@@ -1189,7 +1091,7 @@ __device__ __forceinline__ void step_body(const BbxParams& p, char* smem, unsign
     const bool done = nP == 0;
 
     // ---- the observation a policy would consume after this step ---------------------------------
-    if (p.obs_every_step && p.obs) wave_obs<W>(e, p, env, nP, true, false);
+    if (p.obs_every_step && p.obs) { wave_obs<W>(e, p, env, nP, true, false); obs_trunc |= nP > p.obs_rows ? 1 : 0; }
     // ---- parity trace (tests): hashes of the post-step observation / pair set / new element ---
     if (TRACE && tracing) {
       uint64_t oh = wave_obs<W, true>(e, p, env, nP, false, true);
@@ -1213,7 +1115,7 @@ __device__ __forceinline__ void step_body(const BbxParams& p, char* smem, unsign
   // an environment that must continue in the follow-up pass reports nothing yet
   const bool handoff = status == BBX_ST_SPILL;
   // ---- observation of the state the caller sees next ------------------------------------------
-  if (p.obs && status == BBX_ST_OK) wave_obs<W>(e, p, env, nP, true, false);
+  if (p.obs && status == BBX_ST_OK) { wave_obs<W>(e, p, env, nP, true, false); obs_trunc |= nP > p.obs_rows ? 1 : 0; }
 
   if (STAGED && staged_in) {
     wave_sync();
@@ -1225,8 +1127,8 @@ __device__ __forceinline__ void step_body(const BbxParams& p, char* smem, unsign
     h->q_head = q_head; h->t = t_agent; h->std_rng = std_rng; h->gen_rng = gen_state; h->episode_steps = episode_steps; h->total_steps = total_steps;
     h->total_additions = total_adds; h->episodes = episodes; h->zero_reductions = zero_red; h->steps_done = steps_done;
     h->budget = budget; h->rollout_pos = rollout_pos; h->done_last = done_last; h->alg_bytes = alg_bytes;
-    h->vret = vret; h->vdisc = vdisc;
-    if (p.lite) *(int4*)(p.lite + 4 * (size_t)env) = make_int4(status, q_head, budget, nP);
+    h->vret = vret; h->vdisc = vdisc; h->obs_trunc = obs_trunc;
+    if (p.lite) *(int4*)(p.lite + 4 * (size_t)env) = make_int4(status | (obs_trunc ? BBX_LITE_OBS_TRUNC : 0), q_head, budget, nP);
     if (p.value_mode && p.values) p.values[env] = vret;
     if (!handoff) {
       if (p.rewards && (steps_done > 0 || p.pass == 0)) p.rewards[env] = last_reward;
@@ -1247,34 +1149,7 @@ template <int W>
 __global__ __launch_bounds__(256) void bbx_aux_kernel(BbxParams p) {
   step_body<W, false, false>(p, nullptr);
 }
-// wide class: one workgroup of NW waves per environment (long polynomials, few environments); LDS =
-// [CoopCmd][NW x merge tile scratch]
-template <int W, bool TRACE>
-__global__ __launch_bounds__(512) void bbx_wide_kernel(BbxParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  CoopCmd* cc = (CoopCmd*)smem;
-  const int wave = uni((int)(threadIdx.x / WAVE)), nwaves = (int)(blockDim.x / WAVE);
-  if (wave == 0) {
-    step_body<W, false, TRACE>(p, smem, nullptr, cc, nwaves);
-    if (lane_id() == 0) cc->cmd = 2;
-    __syncthreads();                                       // release the helpers for good
-  } else {
-    coop_helper_loop<W>(cc, smem + coop_cmd_bytes() + (size_t)wave * merge_lds_bytes<W>(), wave, nwaves);
-  }
-}
-template <int W>
-__global__ __launch_bounds__(512) void bbx_wide_prof_kernel(BbxParams p, unsigned long long* prof) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  CoopCmd* cc = (CoopCmd*)smem;
-  const int wave = uni((int)(threadIdx.x / WAVE)), nwaves = (int)(blockDim.x / WAVE);
-  if (wave == 0) {
-    step_body<W, false, false, true>(p, smem, prof, cc, nwaves);
-    if (lane_id() == 0) cc->cmd = 2;
-    __syncthreads();
-  } else {
-    coop_helper_loop<W>(cc, smem + coop_cmd_bytes() + (size_t)wave * merge_lds_bytes<W>(), wave, nwaves);
-  }
-}
+#ifdef BBX_PROF_BUILD
 // diagnostic build with s_memtime stamps (BBX_PROF=1), never used for reported numbers
 template <int W>
 __global__ __launch_bounds__(256) void bbx_step_prof_kernel(BbxParams p, unsigned long long* prof) {
@@ -1282,8 +1157,11 @@ __global__ __launch_bounds__(256) void bbx_step_prof_kernel(BbxParams p, unsigne
   step_body<W, false, false, true>(p, smem, prof);
 }
 
+#endif
+
 #include "bbx_binom.h"
 #include "bbx_fast.h"
+#include "bbx_wide.h"
 
 // ------------------------------------------------------------------ housekeeping kernels
 // zero the headers and set the per-environment agent seeds
@@ -1412,6 +1290,14 @@ extern "C" int bbx_launch_gather_hdr(const char* recs, uint32_t rec_bytes, int B
   return (int)hipGetLastError();
 }
 
+#ifdef BBX_PROF_BUILD
+extern "C" int bbx_wide_prof_read(unsigned long long* out, int reset) {   // diagnostic build only
+  hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(bbx_wide_prof_acc), 32 * sizeof(unsigned long long));
+  if (e == hipSuccess && reset) { unsigned long long z[32] = {0}; e = hipMemcpyToSymbol(HIP_SYMBOL(bbx_wide_prof_acc), z, sizeof z); }
+  return (int)e;
+}
+#endif
+
 // ------------------------------------------------------------------ host-callable launcher
 // kind: 0 = HBM-resident step kernel, 1 = LDS-staged step kernel, 2 = aux (reset / observation only)
 #define BBX_LAUNCH(KERN) hipLaunchKernelGGL((KERN), dim3(blocks), dim3(threads), lds, stream, *p)
@@ -1432,6 +1318,7 @@ static int launch_w(const BbxParams* p, int kind, int blocks, int threads, size_
     else { if (trace) BBX_LAUNCH((bbx_step_kernel<W, true, true>)); else BBX_LAUNCH((bbx_step_kernel<W, true, false>)); }
     return 0;
   }
+#ifdef BBX_PROF_BUILD   // diagnostic build only (-DBBX_PROF_BUILD): per-phase s_memtime sums, never in the product library
   if (!binom && !trace && getenv("BBX_PROF")) {
     static unsigned long long* d_prof = nullptr;
     if (!d_prof) (void)hipMalloc((void**)&d_prof, (size_t)p->B * 10 * sizeof(unsigned long long));
@@ -1449,6 +1336,7 @@ static int launch_w(const BbxParams* p, int kind, int blocks, int threads, size_
     fprintf(stderr, "\n");
     return 0;
   }
+#endif
   if (binom) { if (trace) BBX_LAUNCH((bbx_binom_kernel<W, false, true>)); else BBX_LAUNCH((bbx_binom_kernel<W, false, false>)); }
   else {
     lds = (size_t)(threads / WAVE) * merge_lds_bytes<W>();          // merge-path tile scratch, one per wave
@@ -1473,6 +1361,7 @@ static int launch_fast(const BbxParams* p, int blocks, int threads, int envs_per
   f.lite = p->lite;
   f.gen = p->gen;
   const size_t lds = (size_t)envs_per_block * FLDS_BYTES;
+#ifdef BBX_PROF_BUILD
   static unsigned long long* d_prof = nullptr;
   if (getenv("BBX_PROF") && !p->trace) {          // diagnostic: per-phase cycle sums, printed by bbx_prof_dump()
     if (!d_prof) (void)hipMalloc((void**)&d_prof, (size_t)p->B * 8 * sizeof(unsigned long long));
@@ -1488,6 +1377,7 @@ static int launch_fast(const BbxParams* p, int blocks, int threads, int envs_per
     fprintf(stderr, "\n");
     return 0;
   }
+#endif
   if (p->trace) hipLaunchKernelGGL((bbx_fast_kernel<true, true>), dim3(blocks), dim3(threads), lds, stream, f);
   else if (p->accounting) hipLaunchKernelGGL((bbx_fast_kernel<false, true>), dim3(blocks), dim3(threads), lds, stream, f);
   else if (f.agent == BBX_AGENT_HASH && f.nvars == 3 && f.k == 2 && f.obs && f.obs_every_step && !f.obs_fill && f.auto_reset)
@@ -1501,32 +1391,33 @@ extern "C" int bbx_launch_step(const BbxParams* p, int kind, int envs_per_block,
   if (kind == 3) { launch_fast(p, blocks, threads, envs_per_block, stream); return (int)hipGetLastError(); }
   if (kind == 4) {                                         // wide: envs_per_block is the number of waves per environment
     const int nw = envs_per_block;
-    const size_t wl = (size_t)coop_cmd_bytes() + (size_t)nw * (p->L.W == 2 ? merge_lds_bytes<2>() : merge_lds_bytes<4>());
-    const bool tr = p->trace != nullptr;
-    const void* fn = p->L.W == 2 ? (tr ? (const void*)bbx_wide_kernel<2, true> : (const void*)bbx_wide_kernel<2, false>)
-                                 : (tr ? (const void*)bbx_wide_kernel<4, true> : (const void*)bbx_wide_kernel<4, false>);
-    hipError_t err = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl);
-    if (err != hipSuccess) return (int)err;
-    if (!tr && getenv("BBX_PROF") && p->L.W == 4) {
-      static unsigned long long* d_prof = nullptr;
-      if (!d_prof) (void)hipMalloc((void**)&d_prof, (size_t)p->B * 10 * sizeof(unsigned long long));
-      (void)hipFuncSetAttribute((const void*)bbx_wide_prof_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl);
-      hipLaunchKernelGGL((bbx_wide_prof_kernel<4>), dim3(p->B), dim3(nw * WAVE), wl, stream, *p, d_prof);
-      (void)hipStreamSynchronize(stream);
-      std::vector<unsigned long long> h((size_t)p->B * 10);
-      (void)hipMemcpy(h.data(), d_prof, h.size() * 8, hipMemcpyDeviceToHost);
-      double s[10] = {0}, tot = 0;
-      for (int e = 0; e < p->B; e++) for (int i = 0; i < 10; i++) s[i] += (double)h[(size_t)e * 10 + i];
-      for (int i = 0; i < 6; i++) tot += s[i];
-      fprintf(stderr, "[bbx prof wide] nsteps=%d kcycles/env:", p->nsteps);
-      for (int i = 0; i < 10; i++) fprintf(stderr, " p%d=%.0f(%.0f%%)", i, s[i] / p->B / 1e3, 100.0 * s[i] / tot);
-      fprintf(stderr, "\n");
-      return 0;
+    BbxParams q = *p;                                      // LDS capacities of the workgroup (terms): forced by the caller or
+    const int W_ = (int)q.L.W;                             // as large as the residency aimed at allows
+    const bool lazy = !q.accounting;                       // lean variant: reducer tails collect in an LDS accumulator
+    if (q.wide_hc > 0) { q.wide_hc = (q.wide_hc + 7) & ~7; q.wide_fc = q.wide_hc; q.wide_rc = q.wide_hc; q.wide_sc = lazy ? q.wide_hc : 0; }
+    else {
+      static int ncu = 0;
+      if (!ncu) { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount; if (ncu <= 0) ncu = 256; }
+      // one workgroup per CU while the batch fits that way (160 KB each), otherwise two per CU (80 KB each)
+      const bool one = q.B <= ncu;
+      const size_t budget = one ? 160u * 1024u : 80u * 1024u;
+      q.wide_fc = one ? 1024 : 512; q.wide_rc = one ? 1024 : 704; q.wide_sc = lazy ? (one ? 1536 : 1024) : 0;
+      const size_t fixed = wide_lds_bytes(W_, 0, q.wide_fc, q.wide_rc, q.wide_sc);
+      q.wide_hc = (int)((budget - fixed) / 20) & ~63;       // a term in LDS: 8-byte sort key + u16 coefficient, two buffers
+      while (wide_lds_bytes(W_, q.wide_hc, q.wide_fc, q.wide_rc, q.wide_sc) > budget) q.wide_hc -= 64;
     }
-    if (p->L.W == 2) { if (tr) hipLaunchKernelGGL((bbx_wide_kernel<2, true>), dim3(p->B), dim3(nw * WAVE), wl, stream, *p);
-                       else hipLaunchKernelGGL((bbx_wide_kernel<2, false>), dim3(p->B), dim3(nw * WAVE), wl, stream, *p); }
-    else { if (tr) hipLaunchKernelGGL((bbx_wide_kernel<4, true>), dim3(p->B), dim3(nw * WAVE), wl, stream, *p);
-           else hipLaunchKernelGGL((bbx_wide_kernel<4, false>), dim3(p->B), dim3(nw * WAVE), wl, stream, *p); }
+    p = &q;
+    const size_t wl = wide_lds_bytes(W_, q.wide_hc, q.wide_fc, q.wide_rc, q.wide_sc);
+    const bool tr = p->trace != nullptr;
+#define BBX_WIDE_LAUNCH(WW, TT, LL) do { \
+      hipError_t err_ = hipFuncSetAttribute((const void*)bbx_wide_kernel<WW, TT, LL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl); \
+      if (err_ != hipSuccess) return (int)err_; \
+      hipLaunchKernelGGL((bbx_wide_kernel<WW, TT, LL>), dim3(p->B), dim3(nw * WAVE), wl, stream, *p); } while (0)
+    if (W_ == 2) { if (tr) { if (lazy) BBX_WIDE_LAUNCH(2, true, true); else BBX_WIDE_LAUNCH(2, true, false); }
+                   else { if (lazy) BBX_WIDE_LAUNCH(2, false, true); else BBX_WIDE_LAUNCH(2, false, false); } }
+    else { if (tr) { if (lazy) BBX_WIDE_LAUNCH(4, true, true); else BBX_WIDE_LAUNCH(4, true, false); }
+           else { if (lazy) BBX_WIDE_LAUNCH(4, false, true); else BBX_WIDE_LAUNCH(4, false, false); } }
+#undef BBX_WIDE_LAUNCH
     return (int)hipGetLastError();
   }
   const size_t lds = kind == 1 ? (size_t)envs_per_block * p->LL.rec_bytes : 0;

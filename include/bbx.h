@@ -52,9 +52,12 @@ typedef struct bbx_caps {
   int32_t lds_max_basis;  /* |G| up to which a small (3-variable binomial) environment is kept LDS-resident
                              for a whole launch; 0 = default (128), negative = never */
   int32_t wide_waves;     /* fixed ideals (long polynomials): waves of the workgroup that serves ONE environment;
-                             0 = default (8 when batch <= 2048, else one wave per environment), negative = never */
+                             0 = default (8 when batch <= 4096, else one wave per environment), negative = never */
   int32_t general_class;  /* non-zero: never use the binomial kernel class (term arena + general merges even for
                              binomial ideals); for testing the general path on the same inputs */
+  int32_t wide_lds_terms; /* wide class (fixed ideals, one workgroup per environment): terms of the polynomial being
+                             reduced kept in LDS (also sizes the reducer window and table); 0 = as much as the LDS
+                             holds.  Longer polynomials continue on HBM-resident buffers, so this only affects speed */
 } bbx_caps;
 
 /* One record per environment per step of a traced rollout (parity tests). */

@@ -40,7 +40,13 @@ def compare_with_trace(env, e, want, T, label):
 # and an LDS class so small that environments keep spilling into the HBM-resident follow-up pass
 RESIDENCY = {"default": None, "hbm": {"lds_max_basis": -1}, "spill": {"lds_max_basis": 16},
              "general": {"general_class": 1}, "general_hbm": {"general_class": 1, "lds_max_basis": -1},
-             "general_spill": {"general_class": 1, "lds_max_basis": 16}}
+             "general_spill": {"general_class": 1, "lds_max_basis": 16},
+             # wide class (fixed ideals): an LDS window so small that reducer tails stream through it in chunks and the
+             # polynomial being reduced keeps moving to the HBM-resident buffers; three waves instead of eight
+             "wide_small": {"wide_lds_terms": 64}, "wide_small_3waves": {"wide_lds_terms": 40, "wide_waves": 3},
+             "wide_off": {"wide_waves": -1},
+             # ..._lean: accounting off = the variant whose reducer tails collect in an LDS accumulator
+             "wide_lean": None, "wide_small_lean": {"wide_lds_terms": 64}, "wide_small_3waves_lean": {"wide_lds_terms": 40, "wide_waves": 3}}
 
 
 @pytest.mark.parametrize("residency", sorted(RESIDENCY))
@@ -49,7 +55,10 @@ def test_golden_trace(name, residency):
     m = meta()["traces"][name]
     binomial = "." not in m["dist"] and not m["dist"].startswith("cyclic")
     three_var = m["dist"].startswith("3-") or m["dist"].startswith("2-")
-    if residency != "default" and not binomial:
+    cyc, wide_res = m["dist"].startswith("cyclic"), residency.startswith("wide")
+    if wide_res != cyc and (wide_res or residency != "default"):
+        pytest.skip("the wide class serves fixed ideals only")
+    if not cyc and residency != "default" and not binomial:
         pytest.skip("kernel classes only differ for binomial distributions")
     if residency in ("spill", "general_spill", "hbm") and not three_var:
         pytest.skip("only <=3-variable binomial distributions have an LDS-resident class")
@@ -57,6 +66,8 @@ def test_golden_trace(name, residency):
     B = m["nenvs"]
     T = len(gold["e0_action"])
     env = make_env(m, B, caps=RESIDENCY[residency])
+    if residency.endswith("_lean"):
+        env.accounting(False)
     env.seed(np.arange(B) + m["seed0"])
     env.seed_agent(np.arange(B) + m["agent_seed0"])
     env.trace_enable(max(T, 1))
@@ -446,15 +457,20 @@ def test_headline_kernel_variant_vs_oracle():
                               _state_words(oracles[e].basis(), oracles[e].pairs(), oracles[e].reducer_order())), e
 
 
-@pytest.mark.parametrize("wide", [0, -1, 3])
-def test_long_polynomials_cyclic7_all_merge_paths(wide):
+@pytest.mark.parametrize("wide,lds_terms,lean", [(0, 0, 0), (-1, 0, 0), (3, 0, 0), (8, 256, 0), (5, 1000, 0),
+                                                 (0, 0, 1), (8, 256, 1), (4, 64, 1), (5, 1000, 1)])
+def test_long_polynomials_cyclic7_all_merge_paths(wide, lds_terms, lean):
     """cyclic-7 far enough into an episode that polynomials have hundreds to thousands of terms: exercises the
-    merge-path tiled merge (one wave) and the cooperative workgroup merge (wide kernel, leader + helper waves)
-    against the oracle: per-step rewards via counters, and the complete final state."""
+    merge-path tiled merge of the general class (one wave per environment, wide = -1) and the wide class (one
+    workgroup per environment: polynomial being reduced in LDS, reducer tails streamed through the LDS window in chunks,
+    polynomials that outgrow LDS continued on the HBM-resident buffers) against the oracle: per-step rewards via
+    counters, and the complete final state."""
     from deepgroebner_amd import VecLeadMonomialsEnv
     bo = ffi.load("bo")
     B, T, k = 3, 110, 2
-    env = VecLeadMonomialsEnv("cyclic-7", batch=B, k=k, caps={"wide_waves": wide, "arena_terms": 1 << 19})
+    env = VecLeadMonomialsEnv("cyclic-7", batch=B, k=k, caps={"wide_waves": wide, "wide_lds_terms": lds_terms, "arena_terms": 1 << 19})
+    if lean:
+        env.accounting(False)            # the variant with the LDS accumulator (no algorithmic-byte counting)
     env.seed_agent(np.arange(B) + 40); env.reset()
     env.rollout("random", T, auto_reset=False)
     st = env.stats()
@@ -641,7 +657,7 @@ def test_cyclic7_degree_agent_to_completion():
     w = meta()["buchberger"]["cyclic-7|degree"]
     env = VecLeadMonomialsEnv("cyclic-7", batch=1, k=1)
     env.reset()
-    assert env.value(0, "degree", 0.99) == w["discounted_return"]
+    assert env.value(0, "degree", 0.99) == w["discounted_return"]       # (value rollouts run the lean variant)
     env.rollout("degree", 1 << 30, auto_reset=False)
     st = env.stats()[0]
     assert [st[3], st[0] - st[3], st[1]] == [w["zero_reductions"], w["nonzero_reductions"], w["polynomial_additions"]]
