@@ -94,12 +94,16 @@ def main():
         graft.build()
     if world > 1:
         dist.barrier()
-    torch.cuda.set_device(local_rank)
+    ndev = torch.cuda.device_count()
+    if ndev < 1:
+        raise SystemExit("no GPU visible: libbbx has no CPU fallback")
+    device = local_rank % ndev                       # (more ranks than GPUs only when rehearsing the launch on a smaller box)
+    torch.cuda.set_device(device)
     from deepgroebner_amd import VecLeadMonomialsEnv
     from deepgroebner_amd.shard import plan
 
     K, Wm, B = args.steps, args.warmup, args.batch
-    env = VecLeadMonomialsEnv(args.dist, batch=B, k=K_LEADS, device=local_rank)
+    env = VecLeadMonomialsEnv(args.dist, batch=B, k=K_LEADS, device=device)
     pl = plan(rank, world, B)                         # contiguous block of global environment ids
     env.seed(pl["ideal_seeds"])
     env.seed_agent(pl["agent_seeds"])
@@ -153,6 +157,16 @@ def main():
     elapsed = t1 - t0
     region_ms = ev0.elapsed_time(ev1)               # HIP events on the stream the kernels were launched on
     st1 = env.stats()
+    # context, outside the timed region: the same kernel in launches of 1024 steps (how a rollout would normally be
+    # issued; launches of few steps end with the waves that met an episode reset)
+    long_launch = None
+    if K < 512 and world == 1:
+        torch.cuda.synchronize()
+        tl0 = time.perf_counter()
+        for _ in range(8):
+            launch(1024)
+        env.sync(); torch.cuda.synchronize()
+        long_launch = {"steps_per_launch": 1024, "launches": 8, "value": 8 * 1024 * B / (time.perf_counter() - tl0), "unit": "env-steps/s"}
     d = st1 - st0
     steps_done = int(d[:, 0].sum())
     assert steps_done == R * K * B, "every environment must have executed exactly R*K steps (%d != %d)" % (steps_done, R * K * B)
@@ -213,8 +227,11 @@ def main():
             "data": "synthetic (random binomial ideals drawn on the device from per-environment seeds, inside the timed region)",
             "repeats": R, "preroll_steps": max(args.preroll, 0) or 1, "timed_steps": R * K, "elapsed_s": elapsed,
             "config": {"workload": "%s k=%d batch=%d/GPU random-hash agent auto-reset, observation written every step" % (args.dist, K_LEADS, B),
-                       "global_batch": B * world, "steps_per_launch": K, "parallelism": "env-sharded x%d, no collectives" % world},
+                       "global_batch": B * world, "steps_per_launch": K, "parallelism": "env-sharded x%d, no collectives" % world,
+                       "devices_visible": ndev},
+            "additions": additions,
             "additions_per_s": additions / elapsed,
+            "long_launch": long_launch,
             "roofline": roof,
             "cpu_baseline": cpu,
         }

@@ -313,6 +313,140 @@ class LeadMonomialsEnv(CLeadMonomialsEnv):
         return self._vec.value(0, "degree", gamma)
 
 
+P_MOD = 32003
+
+
+def _monic(coefs, exps, n):
+    """Terms of a basis element the way the Python reference keeps them: divided by the lead coefficient
+    (f.monic(), buchberger.py:342,363), exponent tuples of the ring's n variables."""
+    inv = pow(int(coefs[0]), -1, P_MOD)
+    return [(int(c) * inv % P_MOD, tuple(int(x) for x in e[:n])) for c, e in zip(coefs, exps)]
+
+
+class BuchbergerEnv:
+    """Drop-in for the reference's pure-Python deepgroebner.buchberger.BuchbergerEnv (buchberger.py:243-394): the
+    low-level surface underneath LeadMonomialsEnv.
+
+        reset() -> (G, P)                          step((i, j)) -> ((G, P), reward, done, {})
+
+    G is the list of basis polynomials in insertion order, each a list of (coefficient, exponent-tuple) terms in
+    descending grevlex order, MONIC like the reference's (the device keeps the C++ path's non-monic elements; the two
+    differ by the unit 1/LC); P is the list of pairs (i, j) in the reference's order.  The state lives
+    on the device: one environment of a libbbx batch.  Only grevlex over GF(32003) exists on the device path."""
+
+    def __init__(self, ideal_dist="3-20-10-uniform", elimination="gebauermoeller", rewards="additions",
+                 sort_input=False, sort_reducers=True, device=0, caps=None):
+        self._vec = VecLeadMonomialsEnv(ideal_dist, 1, elimination, rewards, sort_input, sort_reducers, 1, device, caps, "python")
+        self.elimination, self.rewards = elimination, rewards
+        self.sort_input, self.sort_reducers = sort_input, sort_reducers
+        self.nvars = self._vec.nvars
+        self.G, self.P = [], []
+
+    def _sync(self, fresh):
+        basis, pairs, _ = self._vec.state(0)
+        if fresh:
+            self.G = []
+        for c, e in basis[len(self.G):]:                  # (a step appends at most one element)
+            self.G.append(_monic(c, e, self.nvars))
+        self.P = [(int(i), int(j)) for i, j in pairs]
+
+    def reset(self):
+        """New ideal from the generator (redrawn while its pair set is empty, buchberger.py:353) -> (G, P)."""
+        self._vec.reset()
+        self._sync(True)
+        return self.G, self.P
+
+    def step(self, action):
+        """One S-polynomial reduction of the pair `action` = (i, j), which must be in P (list.remove semantics)."""
+        i, j = action
+        idx = self.P.index((int(i), int(j)))              # ValueError when absent, like self.P.remove(action)
+        _, r, _, _ = self._vec.step(np.array([idx], dtype=np.int32))
+        self._sync(False)
+        return (self.G, self.P), float(r[0]), len(self.P) == 0, {}
+
+    def seed(self, seed=None):
+        if seed is not None:
+            self._vec.seed([seed])
+
+    def value(self, gamma=0.99):
+        return self._vec.value(0, "degree", gamma)
+
+    def copy(self):
+        other = BuchbergerEnv.__new__(BuchbergerEnv)
+        other.__dict__.update(self.__dict__)
+        other._vec = self._vec.copy()
+        other.G, other.P = [list(g) for g in self.G], list(self.P)
+        return other
+
+
+def _grevlex_key(m):
+    """sympy's grevlex monomial key (what R.order(m) returns in buchberger.py:428)."""
+    return (sum(m), tuple(-x for x in reversed(m)))
+
+
+def select(G, P, strategy="normal"):
+    """Select and return a pair from P (reference select, buchberger.py:415-439): the minimum of P under the key
+    (or the tuple of keys, for a list of strategies) 'first' = (j, i), 'normal' = grevlex key of lcm(LM_i, LM_j),
+    'degree' = degree of that lcm, 'random'.  G: term lists as BuchbergerEnv returns them."""
+    assert len(G) > 0, "polynomial list must be nonempty"
+    assert len(P) > 0, "pair set must be nonempty"
+    if isinstance(strategy, str):
+        strategy = [strategy]
+
+    def key(p, s):
+        if s == "first":
+            return p[1], p[0]
+        lcm = tuple(max(a, b) for a, b in zip(G[p[0]][0][1], G[p[1]][0][1]))
+        if s == "normal":
+            return _grevlex_key(lcm)
+        if s == "degree":
+            return sum(lcm)
+        if s == "random":
+            return np.random.rand()
+        raise ValueError("unknown selection strategy")
+
+    return min(P, key=lambda p: tuple(key(p, s) for s in strategy))
+
+
+class BuchbergerAgent:
+    """An agent that follows standard selection strategies on (G, P) states (buchberger.py:397-412)."""
+
+    def __init__(self, selection="normal"):
+        self.strategy = selection
+
+    def act(self, state):
+        G, P = state
+        return select(G, P, strategy=self.strategy)
+
+
+def lead_monomials_vector(f, n, k=2, dtype=np.int32):
+    """Concatenated exponent vectors of the k lead monomials of the term list f in n variables, zero padded
+    (reference lead_monomials_vector, buchberger.py:442-445; the second argument is the ring there, its number of
+    variables here)."""
+    n = getattr(n, "ngens", n)
+    rows = [tuple(e[:n]) + (0,) * (n - len(e[:n])) for _, e in f[:k]]
+    rows += [(0,) * n] * (k - len(rows))
+    return np.array(rows).flatten().astype(dtype)
+
+
+class LeadMonomialsAgent:
+    """An agent that follows standard selection strategies on the lead-monomial matrix (buchberger.py:545-567)."""
+
+    def __init__(self, selection="degree", k=1):
+        self.strategy = selection
+        self.k = k
+
+    def act(self, state):
+        if self.strategy == "first":
+            return 0
+        elif self.strategy == "degree":
+            n = state.shape[1] // (2 * self.k)
+            m = state.shape[1] // 2
+            return np.argmin(np.sum(np.maximum(state[:, :n], state[:, m:m + n]), axis=1))
+        elif self.strategy == "random":
+            return np.random.choice(len(state))
+
+
 def strategy_stats(ideals, strategy="degree", elimination="gebauermoeller", sort_reducers=True, device=0, caps=None,
                    seed=None):
     """Full Buchberger runs of one selection strategy over a list of ideals, all at once on the GPU: the columns

@@ -50,13 +50,14 @@ struct WideCold {
   int episode_steps, episodes, zero_red, steps_done, rollout_pos, done_last, obs_trunc, q_head;
   uint32_t std_rng, gen_state;
 };
-struct WideCtl {                                          // LDS control block (parity double-buffered exchange slots)
-  WideCold st;
-  int bc[16];                                             // values the leader wave publishes to the workgroup
-  int wfound[2][WNWMAX];                                  // per-wave first divisor of a scan chunk
-  int wcount[2][WNWMAX];                                  // per-wave output count of a merge tile
+struct __attribute__((aligned(16))) WideCtl {             // LDS control block (parity double-buffered exchange slots)
+  int wfound[2][WNWMAX];                                  // per-wave first divisor of a scan chunk (absent waves: INT_MAX)
+  int wcount[2][WNWMAX];                                  // per-wave output count of a merge tile (absent waves: 0)
   int wend[2][WNWMAX][2];                                 // per-wave last merge-path boundary of a tile
+  int bc[16];                                             // values the leader wave publishes to the workgroup
+  WideCold st;
 };
+typedef int bbx_i32x4 __attribute__((ext_vector_type(4)));
 __host__ __device__ constexpr int wide_ctl_bytes() { return (int)((sizeof(WideCtl) + 255) / 256 * 256); }
 // LDS bytes of one workgroup: control block, 2*hc + fc terms (8-byte key + u16 coefficient), rc reducer table entries
 __host__ __device__ constexpr size_t wide_lds_bytes(int W, int hc, int fc, int rc, int sc) {
@@ -141,8 +142,11 @@ __device__ __forceinline__ int wide_count_ge(const LdsKeys& A, int n, uint64_t x
 // Polynomial operator+ (polynomials.cpp:148-177) as a workgroup merge-path merge.  Returns the new output count; nothing
 // is stored at or beyond ocap (the caller compares the count with ocap).  Called by ALL threads with uniform arguments.
 template <class AV, class BV, class OV>
-__device__ int wide_merge(const AV& A, int na, const BV& B, int nb, const OV& O, int nout, int ocap, WideCtx& x) {
+__device__ int wide_merge(const AV& A, int na_, const BV& B, int nb_, const OV& O, int nout_, int ocap_, WideCtx& x) {
   typedef typename AV::K K;
+  // uniform by construction; pinned so that the loops and branches on them are scalar
+  const int na = uni(na_), nb = uni(nb_), ocap = uni(ocap_);
+  int nout = uni(nout_);
   const int total = na + nb;
   int ci = 0, cj = 0;                                     // merge-path boundary at the start of the current tile
   for (int base = 0; base < total; base += x.NT * WSEG) {
@@ -199,11 +203,11 @@ __device__ int wide_merge(const AV& A, int na, const BV& B, int nb, const OV& O,
     if (x.lane == 0) x.ctl->wcount[pc][x.wave] = wtot;
     __syncthreads();
     int woff = 0, ttot = 0;
+    {                                                       // all eight counts with two 16-byte reads (slots of absent waves hold 0)
+      const bbx_i32x4 c0 = *(BBX_AS3 bbx_i32x4*)&x.ctl->wcount[pc][0], c1 = *(BBX_AS3 bbx_i32x4*)&x.ctl->wcount[pc][4];
+      const int cw[WNWMAX] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
 #pragma unroll
-    for (int w = 0; w < WNWMAX; w++) {
-      const int cw = w < x.NW ? x.ctl->wcount[pc][w] : 0;
-      woff += w < x.wave ? cw : 0;
-      ttot += cw;
+      for (int w = 0; w < WNWMAX; w++) { woff += w < x.wave ? cw[w] : 0; ttot += cw[w]; }
     }
     int pos = nout + woff + prefix;
 #pragma unroll
@@ -267,7 +271,8 @@ template <int W> struct WideTable {
 // first reducer (reducer order) whose lead monomial divides lmh, or -1: buchberger.cpp:29-33.  The first rcl reducers
 // are tested in LDS, the rest (basis larger than the LDS table) in HBM/L2.
 template <int W>
-__device__ int wide_find_divisor(const WideTable<W>& R, int rcl, const Mono<W>* slm, int nG, const Mono<W>& lmh, WideCtx& x) {
+__device__ int wide_find_divisor(const WideTable<W>& R, int rcl_, const Mono<W>* slm, int nG_, const Mono<W>& lmh, WideCtx& x) {
+  const int rcl = uni(rcl_), nG = uni(nG_);               // (uniform by construction; pinned: scalar loop)
   for (int base = 0; base < nG; base += x.NT) {
     const int k = base + x.tid;
     bool d = false;
@@ -281,10 +286,13 @@ __device__ int wide_find_divisor(const WideTable<W>& R, int rcl, const Mono<W>* 
     const int pf = x.par_found; x.par_found ^= 1;
     if (x.lane == 0) x.ctl->wfound[pf][x.wave] = mine;
     __syncthreads();
-    int found = 0x7fffffff;
-#pragma unroll
-    for (int w = 0; w < WNWMAX; w++) { const int f = w < x.NW ? x.ctl->wfound[pf][w] : 0x7fffffff; found = f < found ? f : found; }
-    found = uni(found);
+    int found;
+    {                                                       // (slots of absent waves hold INT_MAX)
+      const bbx_i32x4 f0 = *(BBX_AS3 bbx_i32x4*)&x.ctl->wfound[pf][0], f1 = *(BBX_AS3 bbx_i32x4*)&x.ctl->wfound[pf][4];
+      const int m0 = f0.x < f0.y ? f0.x : f0.y, m1 = f0.z < f0.w ? f0.z : f0.w, m2 = f1.x < f1.y ? f1.x : f1.y, m3 = f1.z < f1.w ? f1.z : f1.w;
+      const int m4 = m0 < m1 ? m0 : m1, m5 = m2 < m3 ? m2 : m3;
+      found = uni(m4 < m5 ? m4 : m5);
+    }
     if (found != 0x7fffffff) return found;
   }
   return -1;
@@ -337,7 +345,7 @@ __device__ __forceinline__ void wide_body(char* smem) {
   WideCtx x;
   x.ctl = (BBX_AS3 WideCtl*)smem;
   x.tid = (int)threadIdx.x; x.lane = x.tid & (WAVE - 1); x.wave = uni(x.tid / WAVE);
-  x.NT = (int)blockDim.x; x.NW = x.NT / WAVE;
+  x.NT = uni((int)blockDim.x); x.NW = x.NT / WAVE;
   x.par_found = x.par_count = x.par_end = 0;
   const int env = (int)blockIdx.x;
   const bool leader = x.wave == 0;
@@ -381,6 +389,7 @@ __device__ __forceinline__ void wide_body(char* smem) {
       if (p.set_budget) { st->rollout_pos = 0; st->done_last = 0; st->vret = 0.0; st->vdisc = 1.0; st->obs_trunc = 0; }
     }
   }
+  if (x.tid < 2 * WNWMAX) { (&x.ctl->wfound[0][0])[x.tid] = 0x7fffffff; (&x.ctl->wcount[0][0])[x.tid] = 0; }
   __syncthreads();
   bool table_dirty = true;
   int rcl = 0;                                                                // reducers staged in LDS
@@ -715,7 +724,9 @@ __device__ __forceinline__ void wide_body(char* smem) {
       WSTAMP(4);
       // where the scaled reducer tail goes: into the accumulator while it fits there (and exponents fit a byte), else
       // into H — after the accumulator has been emptied into H (its terms are all byte-sized: they were when they went in)
-      const bool to_s = LAZY && fn > 0 && fn <= SC && (W == 2 || hsug <= 255);
+      // — and only while that saves work: a short H (one merge tile with the tail) is rewritten just as cheaply
+      const bool to_s = LAZY && fn > 0 && fn <= SC && (W == 2 || hsug <= 255) &&
+                        (sn - soff > 0 || !in_lds || (hn - hoff) + fn > x.NT * WSEG);
       const bool flush_s = LAZY && sn - soff > 0 && (!to_s || (sn - soff) + fn > SC);
       bool ok = true;
       for (int pass = flush_s ? 0 : 1; pass < 2 && ok; pass++) ok = poly_add(pass == 1 && to_s, pass == 0, foff, fn, shift, scale);

@@ -1224,3 +1224,48 @@ double bo_bench_random(const char* dist, int k, int nenvs, int nsteps, int seed0
   *total_steps = steps; *total_additions = adds; *checksum = cs;
   return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
 }
+
+/* position-keyed commutative word hash (bbx_mix64 of deepgroebner_amd/csrc/bbx_common.h; oracle/trace.py fnv64) */
+static unsigned long long mix64w(unsigned long long idx, unsigned int word) {
+  unsigned long long z = ((idx << 32) | (unsigned long long)word) + 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+/* ONE environment under the counter-hash agent for nsteps steps: what the full-size GPU tests compare every device
+ * environment with.  nobs <= 0: observation width of the environment's own variable count.  out8 = steps, additions,
+ * algorithmic bytes (observation term included), episodes finished, final |G|, final |P|, hash of the final
+ * state as the int32 word stream [per basis element: nterms, (coef, exps[8])...][pairs i, j ...][reducer order]
+ * (tests: fnv64 of _state_words), zero reductions.  Returns 0, or -1 for an unknown distribution. */
+int bo_run_random(const char* dist, int k, int seed, int agent_seed, int nsteps, int auto_reset, int nobs, long long* out8) {
+  env* e = (env*)bo_env_new(dist, ELIM_GM, REW_ADDITIONS, 0, 1);
+  if (!e) return -1;
+  const int n = nobs > 0 ? nobs : e->g->n;
+  long long steps = 0, adds = 0, bytes = 0, episodes = 0, zero = 0;
+  bo_env_seed(e, seed);
+  env_reset(e);
+  for (int t = 0; t < nsteps && e->P.n > 0; t++) {
+    const int action = (int)(((uint64_t)agent_hash((uint32_t)agent_seed, (uint32_t)t) * (uint32_t)e->P.n) >> 32);
+    const int nG0 = e->G.n;
+    const double r = env_step(e, e->P.p[action]);
+    steps++; adds += (long long)(-r);
+    bytes += e->last_bytes + 4LL * e->P.n * 2 * n * k;
+    if (e->G.n == nG0) zero++;
+    if (e->P.n == 0) { episodes++; if (auto_reset) env_reset(e); }
+  }
+  unsigned long long h = 0, at = 0;
+  for (int g = 0; g < e->G.n; g++) {
+    const poly* f = &e->G.p[g];
+    h += mix64w(at++, (unsigned int)f->n);
+    for (int t = 0; t < f->n; t++) {
+      h += mix64w(at++, (unsigned int)f->t[t].c);
+      for (int v = 0; v < BO_N; v++) h += mix64w(at++, (unsigned int)f->t[t].m.e[v]);
+    }
+  }
+  for (int r = 0; r < e->P.n; r++) { h += mix64w(at++, (unsigned int)e->P.p[r].i); h += mix64w(at++, (unsigned int)e->P.p[r].j); }
+  for (int r = 0; r < e->nord; r++) h += mix64w(at++, (unsigned int)e->ord[r]);
+  out8[0] = steps; out8[1] = adds; out8[2] = bytes; out8[3] = episodes; out8[4] = e->G.n; out8[5] = e->P.n;
+  out8[6] = (long long)h; out8[7] = zero;
+  bo_env_free(e);
+  return 0;
+}

@@ -90,6 +90,9 @@ long long bo_env_last_step_bytes(void* e);
 double bo_bench_random(const char* dist, int k, int nenvs, int nsteps, int seed0, int agent_seed0,
                        long long* total_steps, long long* total_additions, unsigned long long* checksum);
 
+/* one environment under the counter-hash agent: counters + final-state hash (full-size GPU parity tests) */
+int bo_run_random(const char* dist, int k, int seed, int agent_seed, int nsteps, int auto_reset, int nobs, long long* out8);
+
 #ifdef __cplusplus
 }
 #endif

@@ -77,6 +77,7 @@ def _sig(lib, pre):
       C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_ulonglong))
     if pre == "bo":
         f("env_last_step_bytes", C.c_longlong, _vp)
+        f("run_random", C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_longlong))
     else:
         f("lme_new", _vp, C.c_char_p, C.c_int, C.c_int, C.c_int); f("lme_free", None, _vp)
         f("lme_copy", _vp, _vp); f("lme_seed", None, _vp, C.c_int); f("lme_reset", None, _vp)
@@ -312,6 +313,23 @@ class Lib:
 
     def env(self, *a, **kw):
         return Env(self, *a, **kw)
+
+    def run_random(self, dist, k, seed, agent_seed, nsteps, auto_reset=True, nobs=0):
+        """One environment under the counter-hash agent (C restatement only): dict of counters + final-state hash.  The call
+        releases the GIL, so a thread pool runs many environments on all host cores."""
+        out = (C.c_longlong * 8)()
+        if self.fn("run_random")(dist.encode(), k, int(seed), int(agent_seed), int(nsteps), int(auto_reset), int(nobs), out) != 0:
+            raise ValueError("bad distribution %r" % (dist,))
+        keys = ("steps", "additions", "bytes", "episodes", "nG", "nP", "state_hash", "zero_reductions")
+        d = dict(zip(keys, [int(v) for v in out]))
+        d["state_hash"] &= (1 << 64) - 1
+        return d
+
+    def run_random_many(self, dist, k, seeds, agent_seeds, nsteps, auto_reset=True, nobs=0, threads=None):
+        from concurrent.futures import ThreadPoolExecutor
+        threads = threads or min(16, os.cpu_count() or 1)
+        with ThreadPoolExecutor(threads) as ex:
+            return list(ex.map(lambda sa: self.run_random(dist, k, sa[0], sa[1], nsteps, auto_reset, nobs), zip(seeds, agent_seeds)))
 
     def bench_random(self, dist, k, nenvs, nsteps, seed0, agent_seed0):
         ts, ta, cs = C.c_longlong(), C.c_longlong(), C.c_ulonglong()

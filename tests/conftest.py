@@ -13,6 +13,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "slow: long CPU case")
 
 
+def pytest_sessionstart(session):
+    """GPU runs: bring torch's HIP runtime up before any test starts child processes (tests/test_multirank_gpu.py) —
+    torch failed to find the GPU when it was first initialised after this process had forked children."""
+    expr = session.config.getoption("markexpr", "") or ""
+    if "gpu" in expr and "not gpu" not in expr:
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.init()
+        except Exception:
+            pass
+
+
 @pytest.fixture(scope="session")
 def bo():
     """Our C restatement of the reference algorithm (oracle/bbx_oracle.c)."""

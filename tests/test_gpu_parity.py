@@ -735,3 +735,72 @@ def test_in_batch_clones_for_tree_search():
     env.step([0, 0, 1 % max(1, env.rows[2]), 0], auto_reset=True)
     with pytest.raises(Exception):
         env.clone_envs([0], [0])
+
+
+# ---- full-size runs of every single-GPU BASELINE config on the kernels that are timed (bench.py / scripts/bench_configs.py):
+# lean (no-accounting) variants through rollout_device with the observation written every step, and the accounting variants
+# for the algorithmic-byte counters.  The oracle runs every environment on all host cores (oracle.ffi run_random_many).
+_ORACLE_RUNS = {}
+
+
+def _full_size(dist, B, T, k, nobs, lean, obs_rows, sample_every, caps=None):
+    import torch
+    from deepgroebner_amd import VecLeadMonomialsEnv
+    bo = ffi.load("bo")
+    key = (dist, B, T, k, nobs)
+    if key not in _ORACLE_RUNS:                       # (shared by the lean / accounting variants of one config)
+        _ORACLE_RUNS[key] = bo.run_random_many(dist, k, range(1000, 1000 + B), range(B), T, True, nobs)
+    want = _ORACLE_RUNS[key]
+    env = VecLeadMonomialsEnv(dist, batch=B, k=k, caps=caps)
+    env.seed(np.arange(B) + 1000); env.seed_agent(np.arange(B)); env.reset()
+    if lean:
+        env.accounting(False)
+    obs = torch.zeros((B, obs_rows, env.cols), dtype=torch.int32, device="cuda")
+    rew = torch.zeros(B, dtype=torch.float64, device="cuda"); done = torch.zeros(B, dtype=torch.uint8, device="cuda")
+    rows = torch.zeros(B, dtype=torch.int32, device="cuda")
+    env.rollout_device("random", T, True, torch.cuda.current_stream().cuda_stream, rew, done, rows, obs, obs_rows, False, True)
+    env.sync(); torch.cuda.synchronize()
+    st = env.stats()
+    assert (st[:, 4] == 0).all()
+    for key, col in (("steps", 0), ("additions", 1), ("episodes", 2), ("zero_reductions", 3), ("nG", 7)):
+        w = np.array([r[key] for r in want])
+        assert np.array_equal(st[:, col], w), (key, int(np.flatnonzero(st[:, col] != w)[0]))
+    if not lean:
+        w = np.array([r["bytes"] for r in want])
+        assert np.array_equal(st[:, 6], w), ("bytes", int(np.flatnonzero(st[:, 6] != w)[0]))
+    assert np.array_equal(rows.cpu().numpy(), np.array([r["nP"] for r in want]))
+    for e in sorted(set(range(0, B, sample_every)) | {B - 1}):
+        basis, pairs, order = env.state(e)
+        assert fnv64(_state_words(basis, pairs, order)) == want[e]["state_hash"], e
+    return env, obs, want
+
+
+def test_full_size_headline_lean_kernel_vs_oracle():
+    """BASELINE configs[1], B=4096 x T=256, on bbx_fast_headline_kernel exactly as bench.py launches it (lean, counter-hash
+    agent, observation every step without fill, auto-reset): all counters of all environments, the final state of every
+    64th, and the observation block left behind."""
+    bo = ffi.load("bo")
+    env, obs, want = _full_size("3-20-10-weighted", 4096, 256, 2, 3, True, 256, 64)
+    for e in (0, 777, 4095):
+        o = bo.env("3-20-10-weighted"); o.seed(1000 + e); o.reset()
+        for t in range(256):
+            o.step(ffi.agent_action(e, t, o.nP))
+            if o.nP == 0:
+                o.reset()
+        assert np.array_equal(obs[e, :o.nP].cpu().numpy(), o.obs(2)), e
+
+
+@pytest.mark.parametrize("lean", [1, 0])
+def test_full_size_5_10_5_uniform_vs_oracle(lean):
+    """BASELINE configs[2]: 5-10-5-uniform, B=4096 x T=2048 (HBM-resident binomial class, 16-byte monomials): step /
+    addition / episode / zero-reduction / basis-size counters of ALL environments (+ the algorithmic bytes on the
+    accounting run), the complete final state of every 64th environment."""
+    _full_size("5-10-5-uniform", 4096, 2048, 2, 5, bool(lean), 2048, 64)
+
+
+@pytest.mark.parametrize("lean", [1, 0])
+def test_full_size_cyclic7_vs_oracle(lean):
+    """BASELINE configs[4]: cyclic-7, B=512 x T=128 on the wide kernel (lean: the accumulator variant that
+    scripts/bench_configs.py times; accounting: the eagerly merged one whose byte counter feeds the roofline): counters of
+    all environments, the complete final state of every 64th."""
+    _full_size("cyclic-7", 512, 128, 2, 6, bool(lean), 1024, 64)
