@@ -56,6 +56,9 @@ def parse_args():
                     help="diagnostic: pad the observation with -1 (obs_fill), which selects bbx_fast_kernel<false,false> "
                          "instead of the compile-time specialised headline variant")
     ap.add_argument("--cpu-sample-envs", type=int, default=0)
+    ap.add_argument("--long-launch", action="store_true",
+                    help="context figure after the timed region: the same kernel in 8 launches of 1024 steps (not with rocprofv3: "
+                         "it would mix two launch lengths into the kernel's average)")
     return ap.parse_args()
 
 
@@ -160,7 +163,7 @@ def main():
     # context, outside the timed region: the same kernel in launches of 1024 steps (how a rollout would normally be
     # issued; launches of few steps end with the waves that met an episode reset)
     long_launch = None
-    if K < 512 and world == 1:
+    if args.long_launch and world == 1:
         torch.cuda.synchronize()
         tl0 = time.perf_counter()
         for _ in range(8):

@@ -228,6 +228,14 @@ class VecLeadMonomialsEnv:
         _ffi.check(_ffi.lib().bbx_rollout_device(self._h, _ffi.AGENTS[agent], int(nsteps), int(auto_reset), dp(rewards), dp(dones),
                                                  dp(rows), dp(obs), int(obs_rows), int(obs_fill), int(obs_every_step), C.c_void_p(int(stream))))
 
+    def step_device(self, actions, rewards=None, dones=None, rows=None, obs=None, obs_rows=0, obs_fill=True, stream=0, auto_reset=True):
+        """One asynchronous vector step with the actions taken from a device buffer (what a device-side policy wrote) and
+        rewards / dones / rows / the -1-padded observation block written to device buffers: no host round trip."""
+        def dp(x):
+            return None if x is None else C.c_void_p(x.data_ptr() if hasattr(x, "data_ptr") else int(x))
+        fn = _ffi.lib().bbx_step_device_autoreset if auto_reset else _ffi.lib().bbx_step_device
+        _ffi.check(fn(self._h, dp(actions), dp(rewards), dp(dones), dp(rows), dp(obs), int(obs_rows), int(obs_fill), C.c_void_p(int(stream))))   # obs_fill: 0 / 1 / 2 (include/bbx.h)
+
     def sync(self):
         _ffi.check(_ffi.lib().bbx_sync(self._h))
 

@@ -26,6 +26,8 @@ extern "C" int bbx_launch_scatter_queue(const uint32_t* stage, int n, uint32_t r
 extern "C" int bbx_launch_obs_pack(const int32_t* padded, int cap, int cols, const int32_t* rows, int B, int32_t* off, int32_t* packed, hipStream_t stream);
 extern "C" int bbx_launch_init(char* recs, uint32_t rec_bytes, int B, const uint32_t* agent_seeds, hipStream_t stream);
 extern "C" int bbx_launch_mark_reset(char* recs, uint32_t rec_bytes, int B, const uint8_t* mask, hipStream_t stream);
+extern "C" int bbx_launch_pmlp_act(const int32_t* obs, const int32_t* rows, int B, int obs_rows, int cols, const float* w1, const float* b1,
+                                   const float* w2, float b2, int hidden, const float* u, int32_t* actions, float* logprobs, hipStream_t stream);
 
 namespace {
 
@@ -136,6 +138,7 @@ struct bbx_batch {
   int staged = 0, fast = 0, envs_per_block = 4;
   int wide = 0;                       // > 0: waves per environment of the wide (one workgroup per environment) class
   int wide_terms = 0;                 // forced LDS capacity of the wide class (caps.wide_lds_terms), 0 = automatic
+  bool device_async = false;          // the launch in flight came through a *_device entry point (no host poll per step)
   bool obs_external = false;          // the launch in flight writes observations into a caller-owned block: rows cut for
                                       // lack of space are an error the caller must hear about (bbx_sync)
   bbx_batch() = default;
@@ -317,7 +320,8 @@ int enqueue(bbx_batch* b, const BbxParams& p0, bool resume, hipStream_t stream) 
     // the HBM-resident pass behind the LDS-resident one serves environments that outgrow the LDS class inside a
     // rollout; a single host-driven step does without it: an environment that spills reports BBX_ST_SPILL and
     // finish() continues it (one launch less on the latency path)
-    if (!b->staged || resume || p.nsteps > 1) kinds[nk++] = 0;
+    // (asynchronous calls on caller buffers always get it: nobody polls their status words between steps)
+    if (!b->staged || resume || p.nsteps > 1 || b->obs_external || b->device_async) kinds[nk++] = 0;
   }
   for (int i = 0; i < nk; i++) {
     if (resume) { p.set_budget = 0; p.pass = 1; }
@@ -433,13 +437,14 @@ int finish(bbx_batch* b, hipStream_t stream) {
   return err;
 }
 
-int launch(bbx_batch* b, BbxParams& p, hipStream_t stream, bool obs_external = false) {
+int launch(bbx_batch* b, BbxParams& p, hipStream_t stream, bool obs_external = false, bool device_async = false) {
   int rc = fill_queues(b, 1, stream);
   if (rc) return rc;
   b->last = p;
   b->last_stream = stream;
   b->in_flight = true;
   b->obs_external = obs_external;
+  b->device_async = device_async;
   return enqueue(b, p, false, stream);
 }
 
@@ -935,16 +940,39 @@ int bbx_rollout(bbx_batch* b, int agent, int nsteps, int auto_reset, double* rew
   return copy_out(b, rewards, dones, rows);
 }
 
-int bbx_step_device(bbx_batch* b, const int32_t* d_actions, double* d_rewards, uint8_t* d_dones, int32_t* d_rows,
-                    int32_t* d_obs, int obs_rows, int obs_fill, void* stream) {
+static int step_device(bbx_batch* b, const int32_t* d_actions, double* d_rewards, uint8_t* d_dones, int32_t* d_rows,
+                       int32_t* d_obs, int obs_rows, int obs_fill, void* stream, int auto_reset) {
   if (!b || !d_actions) return fail(BBX_E_ARG, "null argument");
   HIPCHK(hipSetDevice(b->device));
-  BbxParams p; fill_params(b, &p);
-  p.nsteps = 1; p.set_budget = 1; p.agent = BBX_AGENT_EXTERNAL; p.auto_reset = 0; p.actions = d_actions;
-  p.rewards = d_rewards; p.dones = d_dones; p.rows = d_rows; p.obs = d_obs; p.obs_rows = obs_rows; p.obs_fill = obs_fill;
   if (d_obs && obs_rows < 1) return fail(BBX_E_ARG, "obs_rows must be positive");
+  BbxParams p; fill_params(b, &p);
+  p.nsteps = 1; p.set_budget = 1; p.agent = BBX_AGENT_EXTERNAL; p.auto_reset = auto_reset; p.actions = d_actions;
+  p.rewards = d_rewards; p.dones = d_dones; p.rows = d_rows; p.obs = d_obs; p.obs_rows = obs_rows; p.obs_fill = obs_fill;
   if (b->d_trace && b->trace_cap < 1) p.trace = nullptr;
-  return launch(b, p, (hipStream_t)stream, d_obs != nullptr);
+  return launch(b, p, (hipStream_t)stream, d_obs != nullptr, true);
+}
+
+int bbx_step_device(bbx_batch* b, const int32_t* d_actions, double* d_rewards, uint8_t* d_dones, int32_t* d_rows,
+                    int32_t* d_obs, int obs_rows, int obs_fill, void* stream) {
+  return step_device(b, d_actions, d_rewards, d_dones, d_rows, d_obs, obs_rows, obs_fill, stream, 0);
+}
+int bbx_step_device_autoreset(bbx_batch* b, const int32_t* d_actions, double* d_rewards, uint8_t* d_dones, int32_t* d_rows,
+                              int32_t* d_obs, int obs_rows, int obs_fill, void* stream) {
+  return step_device(b, d_actions, d_rewards, d_dones, d_rows, d_obs, obs_rows, obs_fill, stream, 1);
+}
+
+int bbx_pmlp_act(const int32_t* d_obs, const int32_t* d_rows, int batch, int obs_rows, int cols, const float* d_w1, const float* d_b1,
+                 const float* d_w2, float b2, int hidden, const float* d_u, int32_t* d_actions, float* d_logprobs, void* stream) {
+  if (!d_obs || !d_rows || !d_w1 || !d_b1 || !d_w2 || !d_u || !d_actions || !d_logprobs) return fail(BBX_E_ARG, "null argument");
+  if (batch < 1 || obs_rows < 1 || cols < 1 || hidden < 1) return fail(BBX_E_ARG, "bad policy shape");
+  {   // shapes the register-resident kernel is instantiated for (deepgroebner_amd/rollout.py falls back to torch otherwise)
+    const int cp4 = (cols + 3) / 4, upl = (hidden + 63) / 64;
+    const bool cols_ok = cp4 <= 8 || cp4 == 10 || cp4 == 12 || cp4 == 16;
+    if (!cols_ok || upl > 4 || (upl > 2 && cp4 > 8)) return fail(BBX_E_UNSUPPORTED, "policy shape %d x %d is not built into the fused kernel", cols, hidden);
+  }
+  int lrc = bbx_launch_pmlp_act(d_obs, d_rows, batch, obs_rows, cols, d_w1, d_b1, d_w2, b2, hidden, d_u, d_actions, d_logprobs, (hipStream_t)stream);
+  if (lrc) return fail(BBX_E_DEVICE, "policy launch failed: %s", hipGetErrorString((hipError_t)lrc));
+  return BBX_OK;
 }
 
 int bbx_rollout_device(bbx_batch* b, int agent, int nsteps, int auto_reset, double* d_rewards, uint8_t* d_dones,
@@ -957,7 +985,7 @@ int bbx_rollout_device(bbx_batch* b, int agent, int nsteps, int auto_reset, doub
   p.obs_every_step = obs_every_step ? 1 : 0;
   p.nsteps = nsteps; p.set_budget = 1; p.agent = agent; p.auto_reset = auto_reset ? 1 : 0;
   p.rewards = d_rewards; p.dones = d_dones; p.rows = d_rows; p.obs = d_obs; p.obs_rows = obs_rows; p.obs_fill = obs_fill;
-  return launch(b, p, (hipStream_t)stream, d_obs != nullptr);
+  return launch(b, p, (hipStream_t)stream, d_obs != nullptr, true);
 }
 
 int bbx_sync(bbx_batch* b) {

@@ -177,6 +177,10 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
   const int agent = HL ? BBX_AGENT_HASH : p.agent;
   const bool auto_reset = HL ? true : p.auto_reset != 0;
   const bool obs_fill = HL ? false : p.obs_fill != 0;
+  // rows [filled_to, obs_rows) of this environment's block already hold the -1 padding: everything after a full fill
+  // (obs_fill == 1: unknown contents, so the first write pads the whole block), or — obs_fill == 2, the caller vouches
+  // that block and rows[] still hold what the previous call left — everything beyond the row count written then
+  int filled_to = (!HL && p.obs_fill == 2 && p.rows) ? uni(p.rows[env]) : 0x7fffffff;
   const bool obs_step = HL ? true : (p.obs_every_step && p.obs);
   const int per_row = 2 * kk;
   const int obs_row_bytes = 4 * per_row * n;
@@ -206,7 +210,9 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
     }
     if (obs_fill) {
       int32_t* out = p.obs + (size_t)env * p.obs_rows * 12;
-      for (int idx = rows * 12 + lane; idx < p.obs_rows * 12; idx += WAVE) out[idx] = -1;
+      const int hi = filled_to < p.obs_rows ? filled_to : p.obs_rows;
+      for (int idx = rows * 12 + lane; idx < hi * 12; idx += WAVE) out[idx] = -1;
+      filled_to = rows;
     }
   };
   auto write_obs = [&](bool write, bool want_hash) -> uint64_t {
@@ -256,7 +262,11 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
         }
       }
     }
-    if (out && obs_fill) for (int idx = rows * cols + lane; idx < p.obs_rows * cols; idx += WAVE) out[idx] = -1;
+    if (out && obs_fill) {
+      const int hi = filled_to < p.obs_rows ? filled_to : p.obs_rows;
+      for (int idx = rows * cols + lane; idx < hi * cols; idx += WAVE) out[idx] = -1;
+      filled_to = rows;
+    }
     return (TRACE && want_hash) ? wave_sum64(h) : 0;
   };
 
@@ -483,7 +493,26 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
     }
 
     FSTAMP(2);                                             // 2: S-polynomial
+#ifdef BBX_EXP_SALU   // experiment: N independent scalar / vector / no-op instructions per step
+    { uint32_t sa_ = (uint32_t)nP, sb_ = (uint32_t)nG;
+#pragma unroll
+      for (int q_ = 0; q_ < BBX_EXP_SALU / 2; q_++) asm volatile("s_add_u32 %0, %0, 0x11\n\ts_mul_i32 %1, %1, 3" : "+s"(sa_), "+s"(sb_));
+      asm volatile("" :: "s"(sa_), "s"(sb_)); }
+#endif
+#ifdef BBX_EXP_VALU
+    { uint32_t va_ = (uint32_t)lane, vb_ = (uint32_t)lane + 1u;
+#pragma unroll
+      for (int q_ = 0; q_ < BBX_EXP_VALU / 2; q_++) asm volatile("v_add_u32 %0, 0x11, %0\n\tv_mul_lo_u32 %1, %1, 3" : "+v"(va_), "+v"(vb_));
+      asm volatile("" :: "v"(va_), "v"(vb_)); }
+#endif
+#ifdef BBX_EXP_NOP
+#pragma unroll
+    for (int q_ = 0; q_ < BBX_EXP_NOP; q_++) asm volatile("s_nop 0");
+#endif
     // ---- reduce (buchberger.cpp:24-49), entirely in registers -----------------------------------------------------------
+    // (Measured alternatives, DESIGN.md section 4: the same loop in select form on the vector unit — v_cndmask instead of
+    // branches — is 12-15 % slower, on the scalar unit 25 % slower: the branches skip work, and 32-bit multiplies of the
+    // modular arithmetic are quarter-rate on the vector unit.)
     // h and r are wave-uniform, so they are carried as scalars (SGPRs): the loop's control flow is then scalar
     // branches (no exec masking, no per-lane copies at the joins) and its arithmetic runs on the scalar unit; only
     // the divisor scan over the reducer registers and the v_readlane of the chosen reducer are vector instructions.

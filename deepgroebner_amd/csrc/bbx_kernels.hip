@@ -1290,6 +1290,124 @@ extern "C" int bbx_launch_gather_hdr(const char* recs, uint32_t rec_bytes, int B
   return (int)hipGetLastError();
 }
 
+// ------------------------------------------------------------------ the consumer of the observation block: PMLP policy
+// The reference's default policy (ParallelMultilayerPerceptron, networks.py:522-571 = ParallelEmbeddingLayer :49-95 with
+// one dense layer + ParallelDecidingLayer :414-460) evaluated on the padded observation block and sampled, without the
+// block leaving the device:   logit_r = w2 . relu(W1^T x_r + b1) + b2   over the |P| rows of an environment,
+// log-softmax over them, and one action drawn by inverse CDF from a caller-supplied uniform number u (so that the
+// torch module of deepgroebner_amd/rollout.py reproduces the draw).  fp32 throughout.
+// One wavefront per environment.  Environments have ~20 rows but the layer has 128+ units, so the lanes are dealt over
+// the HIDDEN UNITS (lane l owns units l, l + 64, ... with their weights in registers: no LDS, no weight traffic in the
+// loop); a row of the block is the same for every lane — wave-uniform loads through the scalar cache — and its logit is
+// a DPP sum over the lanes.  Padded rows (beyond rows[e]) are never touched: the -1 padding the reference masks out
+// (networks.py:94-95, 456-457) simply is not read.
+constexpr int PMLP_MAXROWS = 1024;
+__device__ __forceinline__ float wave_sum_f32(float x) {    // sum over the 64 lanes, valid in lane 63
+#define BBX_DPPADD(ctrl, rmask) x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), ctrl, rmask, 0xF, false));
+  BBX_DPPADD(0x111, 0xF) BBX_DPPADD(0x112, 0xF) BBX_DPPADD(0x114, 0xF) BBX_DPPADD(0x118, 0xF) BBX_DPPADD(0x142, 0xA) BBX_DPPADD(0x143, 0xC)
+#undef BBX_DPPADD
+  return x;
+}
+template <int CP4, int UPL>                                // padded columns / 4; hidden units per lane
+__global__ __launch_bounds__(256) void bbx_pmlp_act_kernel(const int32_t* __restrict__ obs, const int32_t* __restrict__ rows, int B, int obs_rows,
+                                                           int cols, const float* __restrict__ w1, const float* __restrict__ b1,
+                                                           const float* __restrict__ w2, float b2, int hidden, const float* __restrict__ u,
+                                                           int32_t* __restrict__ actions, float* __restrict__ logprobs) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int cp = 4 * CP4;
+  const int lane = lane_id(), wave = uni((int)(threadIdx.x / WAVE));
+  const int env = blockIdx.x * (blockDim.x / WAVE) + wave;
+  if (env >= B) return;
+  float* lg = (float*)smem + (size_t)wave * (PMLP_MAXROWS + WAVE * cp);   // logits of this wave's environment
+  float* xs = lg + PMLP_MAXROWS;                             // 64 rows of the block at a time, as floats, rows padded to cp
+  // my hidden units: weights in registers
+  float wj[UPL][cp], bj[UPL], vj[UPL];
+#pragma unroll
+  for (int q = 0; q < UPL; q++) {
+    const int h = lane + q * WAVE;
+    const bool on = h < hidden;
+    bj[q] = on ? b1[h] : 0.f; vj[q] = on ? w2[h] : 0.f;
+#pragma unroll
+    for (int f = 0; f < cp; f++) wj[q][f] = (on && f < cols) ? w1[(size_t)f * hidden + h] : 0.f;
+  }
+  int n = uni(rows[env]); n = n < obs_rows ? n : obs_rows; n = n < PMLP_MAXROWS ? n : PMLP_MAXROWS;
+  if (n <= 0) { if (lane == 0) { actions[env] = 0; logprobs[env] = 0.f; } return; }
+  const int32_t* ob = obs + (size_t)env * obs_rows * cols;
+  for (int r0 = 0; r0 < n; r0 += WAVE) {
+    const int nr = n - r0 < WAVE ? n - r0 : WAVE;
+    // the chunk's rows come in with coalesced loads (all in flight together) and are read back as wave-uniform
+    // 16-byte LDS reads: the row loop itself never waits on memory
+    for (int i = lane; i < nr * cols; i += WAVE) { const int rr = i / cols, f = i - rr * cols; xs[rr * cp + f] = (float)ob[(size_t)r0 * cols + i]; }
+    if (cp != cols) for (int i = lane; i < nr * (cp - cols); i += WAVE) { const int rr = i / (cp - cols), f = cols + i - rr * (cp - cols); xs[rr * cp + f] = 0.f; }
+    wave_sync();
+    for (int rb = 0; rb < nr; rb += 4) {                    // four rows at a time: four independent FMA chains and DPP sums in flight
+      float part[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int r = rb + j < nr ? rb + j : nr - 1;         // (the chunk's tail repeats its last row)
+        float x[cp];
+#pragma unroll
+        for (int f4 = 0; f4 < CP4; f4++) { const float4 v = *(const float4*)(xs + r * cp + 4 * f4); x[4 * f4] = v.x; x[4 * f4 + 1] = v.y; x[4 * f4 + 2] = v.z; x[4 * f4 + 3] = v.w; }
+        float pj = 0.f;
+#pragma unroll
+        for (int q = 0; q < UPL; q++) {
+          float acc = bj[q];
+#pragma unroll
+          for (int f = 0; f < cp; f++) acc = fmaf(x[f], wj[q][f], acc);
+          pj = fmaf(acc > 0.f ? acc : 0.f, vj[q], pj);
+        }
+        part[j] = pj;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) part[j] = wave_sum_f32(part[j]);
+      if (lane == 63) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) if (rb + j < nr) lg[r0 + rb + j] = part[j] + b2;
+      }
+    }
+    wave_sync();
+  }
+  wave_sync();
+  float mx = -3.0e38f;
+  for (int r = lane; r < n; r += WAVE) { const float t = lg[r]; mx = t > mx ? t : mx; }
+  for (int o = 32; o > 0; o >>= 1) { const float t = __shfl_xor(mx, o, WAVE); mx = t > mx ? t : mx; }
+  float se = 0.f;
+  for (int r = lane; r < n; r += WAVE) se += __expf(lg[r] - mx);
+  for (int o = 32; o > 0; o >>= 1) se += __shfl_xor(se, o, WAVE);
+  const float logz = mx + __logf(se);
+  // inverse CDF over the rows in order: the first row whose cumulative probability exceeds u (the last one on round-off)
+  const float target = u[env] * se;
+  float run = 0.f; int pick = -1;
+  for (int base = 0; base < n; base += WAVE) {
+    const int r = base + lane;
+    const float e = r < n ? __expf(lg[r] - mx) : 0.f;
+    float c = e;                                             // inclusive prefix within the wave
+    for (int o = 1; o < WAVE; o <<= 1) { const float t = __shfl_up(c, o, WAVE); if (lane >= o) c += t; }
+    const uint64_t hit = ballot64(r < n && run + c > target);
+    if (hit) { pick = base + (int)__builtin_ctzll(hit); break; }
+    run += __shfl(c, WAVE - 1, WAVE);
+  }
+  if (pick < 0) pick = n - 1;
+  if (lane == 0) { actions[env] = pick; logprobs[env] = lg[pick] - logz; }
+}
+extern "C" int bbx_launch_pmlp_act(const int32_t* obs, const int32_t* rows, int B, int obs_rows, int cols, const float* w1, const float* b1,
+                                   const float* w2, float b2, int hidden, const float* u, int32_t* actions, float* logprobs, hipStream_t stream) {
+  const int waves = 4, cp4 = (cols + 3) / 4, upl = (hidden + WAVE - 1) / WAVE;
+  const size_t lds = (size_t)waves * (PMLP_MAXROWS + WAVE * 4 * cp4) * sizeof(float);
+#define BBX_PMLP_GO(N, U) hipLaunchKernelGGL((bbx_pmlp_act_kernel<N, U>), dim3((B + waves - 1) / waves), dim3(waves * WAVE), lds, stream, obs, rows, B, \
+                                             obs_rows, cols, w1, b1, w2, b2, hidden, u, actions, logprobs)
+#define BBX_PMLP_CASE(N) case N: if (upl <= 1) BBX_PMLP_GO(N, 1); else if (upl <= 2) BBX_PMLP_GO(N, 2); else if (upl <= 4 && N <= 8) BBX_PMLP_GO(N, 4); \
+                                 else return (int)hipErrorInvalidValue; break;
+  switch (cp4) {
+    BBX_PMLP_CASE(1) BBX_PMLP_CASE(2) BBX_PMLP_CASE(3) BBX_PMLP_CASE(4) BBX_PMLP_CASE(5) BBX_PMLP_CASE(6) BBX_PMLP_CASE(7) BBX_PMLP_CASE(8)
+    BBX_PMLP_CASE(10) BBX_PMLP_CASE(12) BBX_PMLP_CASE(16)
+    default: return (int)hipErrorInvalidValue;
+  }
+#undef BBX_PMLP_CASE
+#undef BBX_PMLP_GO
+  return (int)hipGetLastError();
+}
+
 #ifdef BBX_PROF_BUILD
 extern "C" int bbx_wide_prof_read(unsigned long long* out, int reset) {   // diagnostic build only
   hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(bbx_wide_prof_acc), 32 * sizeof(unsigned long long));

@@ -1,0 +1,225 @@
+"""The consumer side of the batched environment: policy, trajectory buffer and rollout loop, all on the
+device, replacing the per-step host round trip of the reference's agents.
+
+    PMLPPolicy                 ParallelMultilayerPerceptron           networks.py:522-571 (:49-95, :414-460)
+    discount_rewards, compute_advantages                              pg.py:20-76
+    DeviceTrajectoryBuffer     TrajectoryBuffer (store/finish/get)    pg.py:79-240
+    run_rollout                PGAgent.run_episode(s)                 pg.py:451-503
+
+PyTorch is the plumbing here (device memory, autograd for training); the per-step policy evaluation + sampling of the
+default one-hidden-layer network runs in a hand-written HIP kernel of libbbx (bbx_pmlp_act) fed by the padded
+observation block the step kernel leaves in HBM; deeper networks take the torch path.  Actions never visit the host.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _ffi
+
+
+def discount_rewards(rewards, gam):
+    """Discounted rewards-to-go (pg.py:20-47), float64."""
+    out = np.zeros(len(rewards), dtype=np.float64)
+    c = 0.0
+    for i in reversed(range(len(rewards))):
+        c = rewards[i] + gam * c
+        out[i] = c
+    return out
+
+
+def compute_advantages(rewards, values, gam, lam):
+    """Generalized advantage estimates of one complete trajectory (pg.py:50-76), float64."""
+    rewards = np.array(rewards, dtype=np.float64)
+    values = np.array(values, dtype=np.float64)
+    delta = rewards - values
+    delta[:-1] += gam * values[1:]
+    return discount_rewards(delta, gam * lam)
+
+
+class PMLPPolicy(torch.nn.Module):
+    """ParallelMultilayerPerceptron(hidden_layers) of the reference: every row of the -1-padded [batch, rows, cols] int
+    block is embedded by the same MLP (relu), scored by one linear unit, padded rows get -1e9, log-softmax over rows."""
+
+    def __init__(self, cols, hidden_layers=(128,)):
+        super().__init__()
+        dims = [cols] + list(hidden_layers)
+        self.embedding = torch.nn.ModuleList([torch.nn.Linear(a, b) for a, b in zip(dims[:-1], dims[1:])])
+        self.deciding = torch.nn.Linear(dims[-1], 1)
+        self.cols = cols
+
+    def forward(self, batch):
+        """int [B, R, cols] with -1 padding -> log-probabilities float32 [B, R] (about -1e9 on padded rows)."""
+        mask = batch[:, :, -1] != -1                                  # ParallelEmbeddingLayer.compute_mask
+        x = batch.to(torch.float32)
+        for layer in self.embedding:
+            x = torch.relu(layer(x))
+        x = self.deciding(x).squeeze(-1)
+        x = x + (~mask).to(torch.float32) * -1e9
+        return torch.log_softmax(x, dim=-1)
+
+    @torch.no_grad()
+    def act(self, obs, rows, u, actions=None, logprobs=None, stream=None):
+        """Sample one action per environment by inverse CDF from the uniforms u [B] -> (actions int32 [B], logprobs
+        float32 [B]) on the device.  One hidden layer: the fused HIP kernel (bbx_pmlp_act); otherwise torch ops."""
+        B, R, cols = obs.shape
+        if actions is None:
+            actions = torch.empty(B, dtype=torch.int32, device=obs.device)
+        if logprobs is None:
+            logprobs = torch.empty(B, dtype=torch.float32, device=obs.device)
+        if len(self.embedding) == 1 and self.fused_ok(cols, self.embedding[0].out_features):
+            w = self._fused_weights()
+            s = (stream if stream is not None else torch.cuda.current_stream()).cuda_stream
+            _ffi.check(_ffi.lib().bbx_pmlp_act(C.c_void_p(obs.data_ptr()), C.c_void_p(rows.data_ptr()), B, R, cols, w["w1"], w["b1"], w["w2"],
+                                               w["b2"], w["hidden"], C.c_void_p(u.data_ptr()), C.c_void_p(actions.data_ptr()),
+                                               C.c_void_p(logprobs.data_ptr()), C.c_void_p(s)))
+            return actions, logprobs
+        return self.act_torch(obs, rows, u, actions, logprobs)
+
+    @staticmethod
+    def fused_ok(cols, hidden):
+        """Shapes bbx_pmlp_act is instantiated for (weights of a lane's hidden units live in registers)."""
+        cp4, upl = (cols + 3) // 4, (hidden + 63) // 64
+        return (cp4 <= 8 or cp4 in (10, 12, 16)) and upl <= 4 and not (upl > 2 and cp4 > 8)
+
+    def _fused_weights(self):
+        """The kernel's view of the weights ([cols][hidden] fp32 etc.), rebuilt only when a parameter changed (an
+        optimiser step bumps the tensors' version counters): no per-step transposes, no per-step host read of b2."""
+        lin = self.embedding[0]
+        key = tuple(p._version for p in self.parameters()) + tuple(p.data_ptr() for p in self.parameters())
+        c = self.__dict__.get("_fused_cache")
+        if c is None or c["key"] != key:
+            w1 = lin.weight.detach().t().contiguous().float()
+            b1 = lin.bias.detach().contiguous().float()
+            w2 = self.deciding.weight.detach().reshape(-1).contiguous().float()
+            c = {"key": key, "keep": (w1, b1, w2), "w1": C.c_void_p(w1.data_ptr()), "b1": C.c_void_p(b1.data_ptr()),
+                 "w2": C.c_void_p(w2.data_ptr()), "b2": C.c_float(float(self.deciding.bias.item())), "hidden": lin.out_features}
+            self.__dict__["_fused_cache"] = c
+        return c
+
+    @torch.no_grad()
+    def act_torch(self, obs, rows, u, actions=None, logprobs=None):
+        """The same draw with torch ops (the reference of the fused kernel; any depth)."""
+        lp = self.forward(obs)
+        n = torch.clamp(rows, max=obs.shape[1]).to(torch.int64)
+        valid = torch.arange(obs.shape[1], device=obs.device)[None, :] < n[:, None]
+        p = torch.where(valid, torch.exp(lp - lp.max(dim=1, keepdim=True).values), torch.zeros_like(lp))
+        cdf = torch.cumsum(p, dim=1)
+        target = u * cdf[:, -1]
+        a = torch.minimum((cdf <= target[:, None]).sum(dim=1), n - 1).clamp(min=0)
+        out_a = a.to(torch.int32)
+        out_l = lp.gather(1, a[:, None]).squeeze(1)
+        if actions is not None:
+            actions.copy_(out_a); out_a = actions
+        if logprobs is not None:
+            logprobs.copy_(out_l); out_l = logprobs
+        return out_a, out_l
+
+
+class DeviceTrajectoryBuffer:
+    """TrajectoryBuffer (pg.py:79-240) for a batch of environments stepping in lockstep, kept on the device: per step the
+    -1-padded state block [B, R, cols] (optional), action, reward, log-probability, value and done flag of every
+    environment.  finish() turns rewards into discounted rewards-to-go and values into GAE advantages per EPISODE
+    (episodes end where done is set; an episode still running at the end of the buffer is incomplete and left out, like
+    the reference's `[:self.start]`); get() returns the training tensors with the reference's filtering (states with a
+    single row are dropped) and advantage normalisation."""
+
+    def __init__(self, nsteps, batch, gam=0.99, lam=0.97, obs_shape=None, device="cuda"):
+        self.T, self.B, self.gam, self.lam = nsteps, batch, gam, lam
+        self.actions = torch.zeros((nsteps, batch), dtype=torch.int32, device=device)
+        self.rewards = torch.zeros((nsteps, batch), dtype=torch.float64, device=device)
+        self.logprobs = torch.zeros((nsteps, batch), dtype=torch.float32, device=device)
+        self.values = torch.zeros((nsteps, batch), dtype=torch.float64, device=device)
+        self.dones = torch.zeros((nsteps, batch), dtype=torch.bool, device=device)
+        self.rows = torch.zeros((nsteps, batch), dtype=torch.int32, device=device)
+        self.states = torch.empty((nsteps, batch) + tuple(obs_shape), dtype=torch.int32, device=device) if obs_shape else None
+        self.t = 0
+        self.returns = self.advantages = self.complete = None
+
+    def store(self, state, rows, action, reward, logprob, value, done):
+        t = self.t
+        if self.states is not None:
+            self.states[t].copy_(state)
+        self.rows[t].copy_(rows); self.actions[t].copy_(action); self.rewards[t].copy_(reward)
+        self.logprobs[t].copy_(logprob); self.dones[t].copy_(done.to(torch.bool))
+        if value is not None:
+            self.values[t].copy_(value)
+        self.t += 1
+
+    def finish(self):
+        """Reverse scan over time with episode boundaries: ret_t = r_t + gam ret_{t+1}; delta_t = r_t - v_t + gam v_{t+1};
+        adv_t = delta_t + gam lam adv_{t+1}; nothing crosses a done flag (pg.py:20-76 per trajectory)."""
+        T = self.t
+        r, v, d = self.rewards[:T], self.values[:T], self.dones[:T]
+        ret = torch.zeros_like(r); adv = torch.zeros_like(r); comp = torch.zeros_like(d)
+        nret = torch.zeros(self.B, dtype=torch.float64, device=r.device); nadv = torch.zeros_like(nret)
+        nval = torch.zeros_like(nret); ncomp = torch.zeros(self.B, dtype=torch.bool, device=r.device)
+        for t in range(T - 1, -1, -1):
+            last = d[t]                                              # step t ends its episode: nothing follows it
+            nret = torch.where(last, torch.zeros_like(nret), nret); nadv = torch.where(last, torch.zeros_like(nadv), nadv)
+            nval = torch.where(last, torch.zeros_like(nval), nval); ncomp = ncomp | last
+            ret[t] = r[t] + self.gam * nret
+            adv[t] = (r[t] - v[t] + self.gam * nval) + self.gam * self.lam * nadv
+            comp[t] = ncomp
+            nret, nadv, nval = ret[t], adv[t], v[t]
+        self.returns, self.advantages, self.complete = ret, adv, comp
+        return ret, adv, comp
+
+    def get(self, normalize_advantages=True):
+        """(states or None, actions, logprobs, advantages, values-to-fit) of all complete-episode steps whose state had more
+        than one row (pg.py:184-196), advantages normalised by their mean and population std over the complete steps
+        (pg.py:176-178: before the single-row filter, like the reference)."""
+        if self.returns is None:
+            self.finish()
+        T = self.t
+        comp = self.complete[:T]
+        adv = self.advantages[:T][comp].to(torch.float32)
+        if normalize_advantages and adv.numel():
+            adv = (adv - adv.mean()) / adv.std(unbiased=False)
+        keep = self.rows[:T][comp] != 1
+        st = self.states[:T][comp][keep] if self.states is not None else None
+        return (st, self.actions[:T][comp][keep], self.logprobs[:T][comp][keep], adv[keep],
+                self.returns[:T][comp].to(torch.float32)[keep])
+
+
+@torch.no_grad()
+def run_rollout(env, policy, nsteps, buffer=None, obs_rows=128, generator=None, sync_every=64):
+    """nsteps vector steps of `env` (a VecLeadMonomialsEnv already reset) under `policy`, everything on the device:
+    observation block -> policy.act (log-softmax + inverse-CDF draw) -> bbx_step_device_autoreset -> next block.  The
+    host only enqueues kernels; it waits (env.sync: errors, environments that outgrew a kernel class) every
+    `sync_every` steps and at the end.  Returns (total reward per environment float64 [B] — for `additions` rewards —,
+    finished episodes int64 [B])."""
+    B, cols = env.batch, env.cols
+    dev = torch.device("cuda", torch.cuda.current_device())
+    stream = torch.cuda.current_stream()
+    obs = torch.empty((B, obs_rows, cols), dtype=torch.int32, device=dev)
+    rew = torch.zeros(B, dtype=torch.float64, device=dev); done = torch.zeros(B, dtype=torch.uint8, device=dev)
+    rows = torch.zeros(B, dtype=torch.int32, device=dev); act = torch.zeros(B, dtype=torch.int32, device=dev)
+    logp = torch.zeros(B, dtype=torch.float32, device=dev)
+    st0 = env.stats()
+    # the current observation: a zero-step launch writes the padded block and the row counts
+    env.rollout_device("first", 0, False, stream.cuda_stream, rew, done, rows, obs, obs_rows, True, False)
+    env.sync()
+    keep_states = buffer is not None and buffer.states is not None
+    nsync = 0
+    for t0 in range(0, nsteps, sync_every):
+        n = min(sync_every, nsteps - t0)
+        u_all = torch.rand((n, B), device=dev, generator=generator)   # one generator launch per chunk of steps
+        for i in range(n):
+            policy.act(obs, rows, u_all[i], act, logp, stream)
+            if buffer is not None:
+                t = buffer.t
+                if keep_states:
+                    buffer.states[t].copy_(obs)
+                buffer.rows[t].copy_(rows); buffer.actions[t].copy_(act); buffer.logprobs[t].copy_(logp)
+            env.step_device(act, rew, done, rows, obs, obs_rows, 2, stream.cuda_stream, auto_reset=True)   # (2: incremental padding)
+            if buffer is not None:
+                buffer.rewards[buffer.t].copy_(rew); buffer.dones[buffer.t].copy_(done)
+                buffer.t += 1
+        env.sync()
+        nsync += 1
+    # totals from the environments' own counters (additions rewards: reward = -additions, buchberger.cpp:328)
+    d = env.stats() - st0
+    total = torch.tensor(-d[:, 1].astype(np.float64), device=dev)
+    episodes = torch.tensor(d[:, 2], device=dev)
+    return total, episodes

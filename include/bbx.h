@@ -148,9 +148,24 @@ int bbx_value(bbx_batch* b, int idx, const char* strategy, double gamma, double*
 int bbx_values(bbx_batch* b, const char* strategy, double gamma, double* out);
 
 /* ---- same calls on caller-owned DEVICE buffers (e.g. torch tensors), asynchronous on `stream` ----
- * (hipStream_t passed as void*; NULL = the default stream).  obs may be NULL. */
+ * (hipStream_t passed as void*; NULL = the default stream).  obs may be NULL.
+ * obs_fill: 0 = rows beyond |P| are left alone; 1 = they are padded with -1 (pg.py:217-226); 2 = incremental padding:
+ * the caller vouches that d_obs and d_rows still hold what the previous call on this handle wrote, so only the rows
+ * that stopped being valid are re-padded (classes without the incremental path pad everything, like 1). */
 int bbx_step_device(bbx_batch* b, const int32_t* d_actions, double* d_rewards, uint8_t* d_dones, int32_t* d_rows,
                     int32_t* d_obs, int obs_rows, int obs_fill, void* stream);
+/* the same with the vectorised-environment convention of bbx_step_autoreset (finished episodes restart inside the call) */
+int bbx_step_device_autoreset(bbx_batch* b, const int32_t* d_actions, double* d_rewards, uint8_t* d_dones, int32_t* d_rows,
+                              int32_t* d_obs, int obs_rows, int obs_fill, void* stream);
+/* ---- the consumer of the padded observation block: the reference's default policy network on the device ----------
+ * ParallelMultilayerPerceptron([hidden]) (networks.py:522-571: ParallelEmbeddingLayer :49-95 with one dense relu layer,
+ * ParallelDecidingLayer :414-460) evaluated on d_obs [batch, obs_rows, cols] over the d_rows[e] valid rows of each
+ * environment (the -1 padding is masked out there, never read here), log-softmax over the rows and ONE action drawn by
+ * inverse CDF from the uniform number d_u[e] in [0, 1) — the step of pg.py:451-503's run_episode that used to cross to
+ * the host every step.  d_w1 [cols][hidden], d_b1 [hidden], d_w2 [hidden], b2: fp32 weights (the layout of
+ * torch.nn.Linear(...).weight.t()).  d_actions[e] in [0, rows), d_logprobs[e] = its log-probability. */
+int bbx_pmlp_act(const int32_t* d_obs, const int32_t* d_rows, int batch, int obs_rows, int cols, const float* d_w1, const float* d_b1,
+                 const float* d_w2, float b2, int hidden, const float* d_u, int32_t* d_actions, float* d_logprobs, void* stream);
 /* obs_every_step != 0 materialises the observation in d_obs after every step (what a device-side policy
  * would consume), otherwise only the state at the end of the rollout is written */
 int bbx_rollout_device(bbx_batch* b, int agent, int nsteps, int auto_reset, double* d_rewards, uint8_t* d_dones,
