@@ -12,6 +12,13 @@
 // 299-329 (reset/step), 354-408 (observation); polynomials.cpp:148-202 (merge, negate, term product).
 #pragma once
 
+#ifdef BBX_PROF_BUILD
+__device__ unsigned long long bbx_bin_prof_acc[32];
+#define BSTAMP(slot) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); bprof[slot] += t_ - blast; blast = t_; } while (0)
+#else
+#define BSTAMP(slot) do {} while (0)
+#endif
+
 template <int W> struct BEnv {
   BbxHdr* hdr;
   Mono<W>*lm, *tm, *slm, *stm, *lcm;
@@ -60,7 +67,8 @@ __device__ void bstage_copy(const BEnv<W>& dst, const BEnv<W>& src, int nG, int 
 // append the binomial (t0, t1) as G[nG]: metadata, update(), sorted reducer insert (buchberger.cpp:321-326)
 template <int W>
 __device__ bool bin_add_poly(BEnv<W>& e, const BbxParams& p, const BbxLayout& L, int& nG, int& nP,
-                             const BTerm<W>& t0, const BTerm<W>& t1, int sugar, int* status) {
+                             const BTerm<W>& t0, const BTerm<W>& t1, int sugar, int* status, char* peel_lds = nullptr,
+                             unsigned long long* prof = nullptr, unsigned long long* plast = nullptr) {
   const int lane = lane_id();
   if (nG >= (int)L.maxG) { *status = BBX_ST_G_FULL; return false; }
   const int g = nG;
@@ -70,22 +78,33 @@ __device__ bool bin_add_poly(BEnv<W>& e, const BbxParams& p, const BbxLayout& L,
     e.ginfo[g] = make_uint2(t0.c | (t1.c << 16), inv | ((uint32_t)sugar << 16));
   }
   wave_sync();
-  if (!wave_update<W>(e, L, nG, nP, t0.m, p.elim, status)) return false;
+  if (!wave_update<W>(e, L, nG, nP, t0.m, p.elim, status, peel_lds, prof, plast)) return false;
   // reducer order: std::upper_bound by lead monomial
   int pos = g;
   if (p.sort_reducers) {
     pos = 0;
-    for (int base = 0; base < g; base += WAVE) {
-      int k = base + lane;
-      bool le = k < g && !m_gt(e.slm[k], t0.m);
-      pos += __popcll(ballot64(le));
+    constexpr int UI = 4;
+    for (int base = 0; base < g; base += WAVE * UI) {   // #reducers with LM <= LM f: four chunk loads in flight per trip
+      Mono<W> sv[UI];
+#pragma unroll
+      for (int u = 0; u < UI; u++) { const int k = base + u * WAVE + lane; sv[u] = k < g ? e.slm[k] : m_zero<W>(); }
+#pragma unroll
+      for (int u = 0; u < UI; u++) { const int k = base + u * WAVE + lane; pos += __popcll(ballot64(k < g && !m_gt(sv[u], t0.m))); }
     }
-    for (int hi = g; hi > pos; hi -= WAVE) {     // shift [pos, g) up by one, top chunk first
-      int k = hi - 1 - lane;
-      Mono<W> a, b; uint2 s = make_uint2(0, 0);
-      if (k >= pos) { a = e.slm[k]; b = e.stm[k]; s = e.sinfo[k]; }
+    for (int hi = g; hi > pos; hi -= WAVE * UI) {      // shift [pos, g) up by one, from the top, four chunks per trip:
+      Mono<W> a[UI], b[UI]; uint2 si[UI];               // all loads of a trip complete before its first store
+#pragma unroll
+      for (int u = 0; u < UI; u++) {
+        const int k = hi - 1 - u * WAVE - lane;
+        si[u] = make_uint2(0, 0);
+        if (k >= pos) { a[u] = e.slm[k]; b[u] = e.stm[k]; si[u] = e.sinfo[k]; }
+      }
       wave_sync();
-      if (k >= pos) { e.slm[k + 1] = a; e.stm[k + 1] = b; e.sinfo[k + 1] = s; }
+#pragma unroll
+      for (int u = 0; u < UI; u++) {
+        const int k = hi - 1 - u * WAVE - lane;
+        if (k >= pos) { e.slm[k + 1] = a[u]; e.stm[k + 1] = b[u]; e.sinfo[k + 1] = si[u]; }
+      }
       wave_sync();
     }
   }
@@ -100,7 +119,7 @@ __device__ bool bin_add_poly(BEnv<W>& e, const BbxParams& p, const BbxLayout& L,
 
 template <int W>
 __device__ bool bin_reset(BEnv<W>& e, const BbxParams& p, const BbxLayout& L, int env, int& nG, int& nP, int& q_head, int* status,
-                          uint32_t& gen_state) {
+                          uint32_t& gen_state, char* peel_lds = nullptr) {
   if (p.gen) {                                       // the ideal is drawn here (gen_binomial): no queue, no host
     const int npoly = (int)ldc(p.gen + 2), ncp = (int)ldc(p.gen + 4);
     const uint32_t gflags = ldc(p.gen + 3);
@@ -113,7 +132,7 @@ __device__ bool bin_reset(BEnv<W>& e, const BbxParams& p, const BbxLayout& L, in
         BTerm<W> t0, t1;
         t0.c = 1;
         if (!gen_binomial<W>(x, p.gen, GL, gflags, ncp, t0.m, t1.m, t1.c)) { *status = BBX_ST_GEN_FAIL; gen_state = x; return false; }
-        if (!bin_add_poly<W>(e, p, L, nG, nP, t0, t1, (int)m_deg(t0.m), status)) { gen_state = x_start; return false; }   // (a spill redoes this draw)
+        if (!bin_add_poly<W>(e, p, L, nG, nP, t0, t1, (int)m_deg(t0.m), status, peel_lds)) { gen_state = x_start; return false; }   // (a spill redoes this draw)
       }
       if (nP != 0) { gen_state = x; return true; }   // buchberger.cpp:313-314: redraw while the pair set is empty
     }
@@ -143,7 +162,7 @@ __device__ bool bin_reset(BEnv<W>& e, const BbxParams& p, const BbxLayout& L, in
 #pragma unroll
         for (int i = 0; i < W; i++) t1.m.w[i] = ldc(w + 2 + W + i);
       }
-      if (!bin_add_poly<W>(e, p, L, nG, nP, t0, t1, sugar, status)) return false;
+      if (!bin_add_poly<W>(e, p, L, nG, nP, t0, t1, sugar, status, peel_lds)) return false;
       w += (size_t)n * (1 + W);
     }
     if (!p.q.fixed) q_head++;
@@ -153,7 +172,7 @@ __device__ bool bin_reset(BEnv<W>& e, const BbxParams& p, const BbxLayout& L, in
 
 // observation rows (buchberger.cpp:354-370, 391-394): one lane per monomial slot of the matrix
 template <int W, bool HASH>
-__device__ uint64_t bin_obs(const BEnv<W>& e, const BbxParams& p, int env, int nP, bool write, bool want_hash) {
+__device__ uint64_t bin_obs(const BEnv<W>& e, const BbxParams& p, int env, int nP, bool write, bool want_hash, char* stage_lds = nullptr) {
   const int lane = lane_id();
   const int n = p.nvars, k = p.k;
   const int cols = 2 * n * k;
@@ -183,13 +202,28 @@ __device__ uint64_t bin_obs(const BEnv<W>& e, const BbxParams& p, int env, int n
       for (int u = 0; u < U; u++) {
         const int g = half ? (int)(pr[u] >> 16) : (int)(pr[u] & 0xffffu);
         mm[u] = m_zero<W>();
+#if defined(BBX_ABL_OBS) && BBX_ABL_OBS == 2   // ablation experiment: no gathers
+        if (on[u]) { mm[u].w[0] = (uint32_t)g; }
+#else
         if (on[u]) { if (t == 0) mm[u] = e.lm[g]; else if (t == 1) mm[u] = e.tm[g]; }
+#endif
       }
 #pragma unroll
       for (int u = 0; u < U; u++) {
         if (on[u]) {
           const int base = (rr[u] * per_row + slot) * n;
+#if defined(BBX_ABL_OBS) && BBX_ABL_OBS == 1   // ablation experiment: no stores (one per sweep keeps the gathers alive)
+          if (out && mm[u].w[0] == 0x12345678u) obs_store<W>(out + base, mm[u], n);
+#elif defined(BBX_ABL_OBS) && BBX_ABL_OBS == 3 // ablation experiment: the same bytes as ideal stores (16-byte aligned, lane-contiguous)
+          if (out) {                             // 64 lanes x 20 B = 1280 B per sweep = 80 aligned 16-byte units: lanes 0..63 + lanes 0..15
+            const int sweep = rr[u] / rows_per_sweep;
+            ObsI4* o4 = (ObsI4*)(out + (size_t)sweep * rows_per_sweep * per_row * n);
+            o4[lane] = ObsI4{(int)mm[u].w[0], (int)mm[u].w[1], (int)mm[u].w[2], (int)mm[u].w[3]};
+            if (lane < 16) o4[64 + lane] = ObsI4{(int)mm[u].w[0], 0, 0, 0};
+          }
+#else
           if (out) obs_store<W>(out + base, mm[u], n);
+#endif
           if (HASH && want_hash) for (int v = 0; v < n; v++) h += bbx_mix64((uint64_t)(base + v), m_exp(mm[u], v));
         }
       }
@@ -272,11 +306,17 @@ __device__ __forceinline__ void binom_body(const BbxParams& p, char* smem) {
   double last_reward = 0.0;
   const bool tracing = TRACE && p.trace != nullptr;
   const int obs_term_bytes = 4 * 2 * p.nvars * p.k;
+  // HBM-resident instantiation: the launcher provides one Gebauer-Moeller peel scratch per wave in LDS
+  char* const peel_lds = (!STAGED && smem != nullptr) ? smem + (size_t)wave_in_block * update_lds_bytes<W>() : nullptr;
+#ifdef BBX_PROF_BUILD
+  unsigned long long bprof[32] = {0};
+  unsigned long long blast = __builtin_amdgcn_s_memtime();
+#endif
 
   for (;;) {
     if (status != BBX_ST_OK) break;
     if (need_reset) {
-      if (!bin_reset<W>(e, p, L, env, nG, nP, q_head, &status, gen_state)) {
+      if (!bin_reset<W>(e, p, L, env, nG, nP, q_head, &status, gen_state, peel_lds)) {
         if (STAGED && (status == BBX_ST_G_FULL || status == BBX_ST_P_FULL)) { status = BBX_ST_SPILL; nG = 0; nP = 0; }
         break;
       }
@@ -289,6 +329,7 @@ __device__ __forceinline__ void binom_body(const BbxParams& p, char* smem) {
       break;
     }
 
+    BSTAMP(0);
     // ---- choose the pair ------------------------------------------------------------------------
     int action;
     if (p.agent == BBX_AGENT_EXTERNAL) action = p.actions[env];
@@ -301,16 +342,18 @@ __device__ __forceinline__ void binom_body(const BbxParams& p, char* smem) {
     if (action < 0 || action >= nP) { status = BBX_ST_BAD_ACTION; break; }
     const uint32_t pr = (uint32_t)uni((int)e.pairs[action]);
     const int gi = pr & 0xffffu, gj = pr >> 16;
-    for (int base = action; base < nP - 1; base += WAVE) {             // P.erase(remove(action)), stable
-      int k = base + lane;
-      uint32_t v = 0;
-      if (k < nP - 1) v = e.pairs[k + 1];
+    for (int base = action; base < nP - 1; base += WAVE * 4) {         // P.erase(remove(action)), stable: four chunks per trip
+      uint32_t v[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) { const int k = base + u * WAVE + lane; v[u] = k < nP - 1 ? e.pairs[k + 1] : 0u; }
       wave_sync();
-      if (k < nP - 1) e.pairs[k] = v;
+#pragma unroll
+      for (int u = 0; u < 4; u++) { const int k = base + u * WAVE + lane; if (k < nP - 1) e.pairs[k] = v[u]; }
       wave_sync();
     }
     nP -= 1;
 
+    BSTAMP(1);
     // ---- S-polynomial (buchberger.cpp:18-21): the lead terms cancel, the two tails remain -------------
     BTerm<W> h0, h1;
     int hsug;
@@ -331,16 +374,36 @@ __device__ __forceinline__ void binom_body(const BbxParams& p, char* smem) {
       bytes += 12 * ((tci ? 2 : 1) + (tcj ? 2 : 1) + (h0.c ? 1 : 0) + (h1.c ? 1 : 0));
     }
 
+    BSTAMP(2);
     // ---- reduce (buchberger.cpp:24-49) --------------------------------------------------------------
     BTerm<W> r0, r1;
     r0.c = 0; r1.c = 0; r0.m = m_zero<W>(); r1.m = m_zero<W>();
     int nsteps_red = 0, rsug = 0;
     bool overflow = false;
+    // The reducers' lead monomials do not change during a reduction: the first 64 * SR of them (reducer order) are
+    // loaded ONCE, all loads in flight together, and every round scans registers; larger bases continue in memory.
+    constexpr int SR = W == 4 ? 6 : 8;
+    Mono<W> S[SR];
+    const int nsr = (nG + WAVE - 1) / WAVE < SR ? (nG + WAVE - 1) / WAVE : SR;
+#pragma unroll
+    for (int u = 0; u < SR; u++) { const int k = u * WAVE + lane; S[u] = (u < nsr && k < nG) ? e.slm[k] : m_zero<W>(); }
     while (uni((int)h0.c) != 0) {
       const int hn = h1.c ? 2 : 1;
       int found = -1;
       Mono<W> lmg = m_zero<W>();
-      for (int base = 0; base < nG; base += WAVE) {                    // first reducer whose LM divides LM(h)
+#pragma unroll
+      for (int u = 0; u < SR; u++) {                                    // first reducer whose LM divides LM(h)
+        if (u < nsr && found < 0) {
+          const uint64_t mask = ballot64(u * WAVE + lane < nG && m_divides(S[u], h0.m));
+          if (mask) {
+            const int src = __builtin_ctzll(mask);
+            found = u * WAVE + src;
+#pragma unroll
+            for (int i = 0; i < W; i++) lmg.w[i] = (uint32_t)__builtin_amdgcn_readlane((int)S[u].w[i], src);
+          }
+        }
+      }
+      for (int base = SR * WAVE; base < nG && found < 0; base += WAVE) {
         int k = base + lane;
         Mono<W> s = m_zero<W>();
         bool d = false;
@@ -351,7 +414,6 @@ __device__ __forceinline__ void binom_body(const BbxParams& p, char* smem) {
           found = base + src;
 #pragma unroll
           for (int i = 0; i < W; i++) lmg.w[i] = (uint32_t)__builtin_amdgcn_readlane((int)s.w[i], src);
-          break;
         }
       }
       if (found >= 0) {                                                 // h <- h - (LT h / LT f) f
@@ -383,10 +445,16 @@ __device__ __forceinline__ void binom_body(const BbxParams& p, char* smem) {
     if (overflow) break;
     rsug = uni(rsug > hsug ? rsug : hsug);
 
+    BSTAMP(3);
     // ---- basis / pair-set update (buchberger.cpp:321-327) ---------------------------------------------
     const int nG_before = nG, nP_before = nP;
     if (uni((int)r0.c) != 0) {
-      if (!bin_add_poly<W>(e, p, L, nG, nP, r0, r1, rsug, &status)) break;
+#ifdef BBX_PROF_BUILD
+      if (!bin_add_poly<W>(e, p, L, nG, nP, r0, r1, rsug, &status, peel_lds, bprof, &blast)) break;
+      BSTAMP(4);
+#else
+      if (!bin_add_poly<W>(e, p, L, nG, nP, r0, r1, rsug, &status, peel_lds)) break;
+#endif
       bytes += 12 * (r1.c ? 2 : 1) + 8 * nG_before + 8 * (nP_before + nP);
     } else zero_red++;
     bytes += nP * obs_term_bytes;
@@ -397,7 +465,9 @@ __device__ __forceinline__ void binom_body(const BbxParams& p, char* smem) {
     total_steps++; total_adds += 1 + nsteps_red; t_agent++; episode_steps++; steps_done++;
     const bool done = nP == 0;
 
-    if (p.obs_every_step && p.obs) { bin_obs<W, false>(e, p, env, nP, true, false); obs_trunc |= nP > p.obs_rows ? 1 : 0; }
+    BSTAMP(5);
+    if (p.obs_every_step && p.obs) { bin_obs<W, false>(e, p, env, nP, true, false, peel_lds); obs_trunc |= nP > p.obs_rows ? 1 : 0; }
+    BSTAMP(6);
     if (TRACE && tracing) {
       uint64_t oh = bin_obs<W, true>(e, p, env, nP, false, true);
       uint64_t ph = wave_pairs_hash<W, BEnv<W>>(e, nP);
@@ -416,8 +486,11 @@ __device__ __forceinline__ void binom_body(const BbxParams& p, char* smem) {
     }
   }
 
+#ifdef BBX_PROF_BUILD
+  if (lane == 0) for (int i = 0; i < 32; i++) if (bprof[i]) atomicAdd(&bbx_bin_prof_acc[i], bprof[i]);
+#endif
   const bool handoff = status == BBX_ST_SPILL;
-  if (p.obs && status == BBX_ST_OK) { bin_obs<W, false>(e, p, env, nP, true, false); obs_trunc |= nP > p.obs_rows ? 1 : 0; }
+  if (p.obs && status == BBX_ST_OK) { bin_obs<W, false>(e, p, env, nP, true, false, peel_lds); obs_trunc |= nP > p.obs_rows ? 1 : 0; }
   if (STAGED && staged_in) {
     wave_sync();
     bstage_copy<W>(ge, e, nG, nP);
@@ -441,7 +514,7 @@ __device__ __forceinline__ void binom_body(const BbxParams& p, char* smem) {
 }
 
 template <int W, bool STAGED, bool TRACE>
-__global__ __launch_bounds__(256) void bbx_binom_kernel(BbxParams p) {
+__global__ __launch_bounds__(256, 4) void bbx_binom_kernel(BbxParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   binom_body<W, STAGED, TRACE>(p, smem);
 }

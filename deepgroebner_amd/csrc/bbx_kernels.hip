@@ -504,31 +504,112 @@ __device__ __forceinline__ int gen_poisson(uint32_t& x, double lm_thr) {
 // ------------------------------------------------------------------ update()   buchberger.cpp:52-99
 // Adds the polynomial whose lead monomial is lmf as G[m] (the caller has already stored its terms and
 // metadata) and updates the pair set.  Returns false on capacity overflow.
+#ifdef BBX_PROF_BUILD
+#define USTAMP(slot) do { if (prof) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); prof[slot] += t_ - *plast; *plast = t_; } } while (0)
+#else
+#define USTAMP(slot) do {} while (0)
+#endif
+// peel_lds: per-wave LDS scratch of WAVE * UPD_CHUNKS monomials for the Gebauer-Moeller peel (or null: the record's
+// scratch arrays in HBM are used)
+constexpr int UPD_CHUNKS = 8;
+template <int W> __host__ __device__ constexpr int update_lds_bytes() { return WAVE * UPD_CHUNKS * 4 * W; }
 template <int W, class EnvT>
-__device__ bool wave_update(EnvT& e, const BbxLayout& L, int& nG, int& nP, const Mono<W> lmf, int elim, int* status) {
+__device__ bool wave_update(EnvT& e, const BbxLayout& L, int& nG, int& nP, const Mono<W> lmf, int elim, int* status,
+                            char* peel_lds = nullptr, unsigned long long* prof = nullptr, unsigned long long* plast = nullptr) {
   const int lane = lane_id();
   const int m = nG;
   if (elim == BBX_ELIM_GM) {
     // (70-76) drop old pairs (i,j) with LM f | lcm_ij, lcm_ij != lcm_if, lcm_ij != lcm_jf  — stable
+    // Four chunks of 64 pairs per trip: all pair words are loaded together, then all lead-monomial gathers are in flight
+    // together (two dependent trips to memory per 256 pairs instead of two per 64); the survivors are then written, in
+    // order, behind the write cursor — which never passes a pair that has not been read yet.
     int w = 0;
-    for (int base = 0; base < nP; base += WAVE) {
-      int k = base + lane;
-      bool keep = false; uint32_t pr = 0;
-      if (k < nP) {
-        pr = e.pairs[k];
-        Mono<W> li = e.lm[pr & 0xffffu], lj = e.lm[pr >> 16];
-        Mono<W> l = m_lcm(li, lj);
-        bool drop = m_divides(lmf, l) && !m_eq(l, m_lcm(li, lmf)) && !m_eq(l, m_lcm(lj, lmf));
-        keep = !drop;
-      }
-      uint64_t mask = ballot64(keep);
+    constexpr int UF = 4;
+    for (int base = 0; base < nP; base += WAVE * UF) {
+      uint32_t pr[UF]; Mono<W> li[UF], lj[UF]; bool in[UF];
+#pragma unroll
+      for (int u = 0; u < UF; u++) { const int k = base + u * WAVE + lane; in[u] = k < nP; pr[u] = in[u] ? e.pairs[k] : 0u; }
+#pragma unroll
+      for (int u = 0; u < UF; u++) { li[u] = e.lm[pr[u] & 0xffffu]; lj[u] = e.lm[pr[u] >> 16]; }   // (index 0 for absent lanes)
       wave_sync();
-      if (keep) e.pairs[w + prefix_of(mask, lane)] = pr;
-      w = uni(w + __popcll(mask));       // pinned: the optimiser otherwise threads the count through the per-lane
-                                         // branch above and the uniformity analysis gives up on |P| (-> exec-masked code)
+#pragma unroll
+      for (int u = 0; u < UF; u++) {
+        if (base + u * WAVE < nP) {
+          const Mono<W> l = m_lcm(li[u], lj[u]);
+          const bool drop = m_divides(lmf, l) && !m_eq(l, m_lcm(li[u], lmf)) && !m_eq(l, m_lcm(lj[u], lmf));
+          const bool keep = in[u] && !drop;
+          const uint64_t mask = ballot64(keep);
+          if (keep) e.pairs[w + prefix_of(mask, lane)] = pr[u];
+          w = uni(w + __popcll(mask));   // pinned: the optimiser otherwise threads the count through the per-lane branch
+                                         // above and the uniformity analysis gives up on |P| (-> exec-masked code)
+        }
+      }
       wave_sync();
     }
     nP = w;
+    USTAMP(8);
+    if (peel_lds != nullptr && m <= WAVE * UPD_CHUNKS) {
+      // (78-91) new pairs (i, m), everything on chip: L_i = lcm(LM G[i], LM f) in the wave's LDS scratch (element i at slot
+      // i: conflict-free 16-byte reads), the candidate / coprime / emit flags one bit per element in three registers
+      // (lane l owns elements l, l + 64, ...), a bucket's lcm travels by v_readlane.  The std::map walk keeps exactly the
+      // lcms minimal under divisibility among the distinct values; they are peeled by increasing degree (see below).
+      typedef uint32_t bbx_u32xW __attribute__((ext_vector_type(W)));
+      __attribute__((address_space(3))) bbx_u32xW* Ll = (__attribute__((address_space(3))) bbx_u32xW*)peel_lds;
+      const int nch = (m + WAVE - 1) / WAVE;
+      uint32_t candb = 0, cpb = 0, emitb = 0;
+      for (int u = 0; u < nch; u++) {
+        const int i = u * WAVE + lane;
+        const bool v = i < m;
+        const Mono<W> li = v ? e.lm[i] : m_zero<W>();
+        const Mono<W> Li = m_lcm(li, lmf);
+        bbx_u32xW pk;
+#pragma unroll
+        for (int q = 0; q < W; q++) pk[q] = Li.w[q];
+        Ll[i] = pk;
+        candb |= v ? (1u << u) : 0u;
+        cpb |= (v && m_coprime(li, lmf)) ? (1u << u) : 0u;
+      }
+      wave_sync();
+      USTAMP(9);
+      auto ldsL = [&](int i) { const bbx_u32xW pk = Ll[i]; Mono<W> r; for (int q = 0; q < W; q++) r.w[q] = pk[q]; return r; };
+      for (;;) {
+        uint32_t dm = 0xFFFFFFFFu;
+        for (int u = 0; u < nch; u++) { const uint32_t d = m_deg(ldsL(u * WAVE + lane)); dm = ((candb >> u) & 1u) && d < dm ? d : dm; }
+        const uint32_t dmin = wave_min32(dm);
+        if (dmin == 0xFFFFFFFFu) break;
+        for (int u = 0; u < nch; u++) {
+          const Mono<W> Lu = ldsL(u * WAVE + lane);
+          uint64_t surv = ballot64(((candb >> u) & 1u) && m_deg(Lu) == dmin);
+          while (surv) {
+            const int sl = __builtin_ctzll(surv);
+            Mono<W> Ls;
+#pragma unroll
+            for (int q = 0; q < W; q++) Ls.w[q] = (uint32_t)__builtin_amdgcn_readlane((int)Lu.w[q], sl);
+            uint64_t any_cp = 0;
+            for (int v = 0; v < nch; v++) {
+              const Mono<W> Lv = ldsL(v * WAVE + lane);
+              const bool eq = m_eq(Lv, Ls);
+              if (m_divides(Ls, Lv)) candb &= ~(1u << v);
+              any_cp |= ballot64(eq && ((cpb >> v) & 1u));
+              if (v == u) surv &= ~ballot64(eq);
+            }
+            if (any_cp == 0 && lane == sl) emitb |= 1u << u;
+          }
+        }
+      }
+      USTAMP(10);
+      for (int u = 0; u < nch; u++) {
+        const bool emit = (emitb >> u) & 1u;
+        const uint64_t mask = ballot64(emit);
+        const int cnt = __popcll(mask);
+        if (nP + cnt > (int)L.maxP) { *status = BBX_ST_P_FULL; return false; }
+        if (emit) e.pairs[nP + prefix_of(mask, lane)] = (uint32_t)(u * WAVE + lane) | ((uint32_t)m << 16);  // (92) ascending i
+        nP = uni(nP + cnt);
+      }
+      wave_sync();
+      USTAMP(11);
+      return true;
+    }
     // (78-81) lcm_i = lcm(LM G[i], LM f); flags: 1 = G[i] coprime to f, 2 = still a candidate, 4 = emits a pair
     for (int i = lane; i < m; i += WAVE) {
       Mono<W> li = e.lm[i];
@@ -536,6 +617,7 @@ __device__ bool wave_update(EnvT& e, const BbxLayout& L, int& nG, int& nP, const
       e.cp[i] = (uint8_t)((m_coprime(li, lmf) ? 1 : 0) | 2);
     }
     wave_sync();
+    USTAMP(9);
     // (82-91) The std::map walk keeps exactly the lcms that are minimal under divisibility among the distinct
     // values (a proper divisor has smaller degree, hence comes earlier in grevlex).  They are peeled by increasing
     // degree: every candidate of minimal degree is minimal; its bucket of equal lcms emits (smallest index, m)
@@ -574,6 +656,7 @@ __device__ bool wave_update(EnvT& e, const BbxLayout& L, int& nG, int& nP, const
         }
       }
     }
+    USTAMP(10);
     for (int base = 0; base < m; base += WAVE) {
       const int i = base + lane;
       const bool emit = i < m && (e.cp[i] & 4);
@@ -596,6 +679,7 @@ __device__ bool wave_update(EnvT& e, const BbxLayout& L, int& nG, int& nP, const
     }
   }
   wave_sync();
+  USTAMP(11);
   return true;
 }
 
@@ -1409,6 +1493,11 @@ extern "C" int bbx_launch_pmlp_act(const int32_t* obs, const int32_t* rows, int 
 }
 
 #ifdef BBX_PROF_BUILD
+extern "C" int bbx_bin_prof_read(unsigned long long* out, int reset) {   // diagnostic build only
+  hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(bbx_bin_prof_acc), 32 * sizeof(unsigned long long));
+  if (e == hipSuccess && reset) { unsigned long long z[32] = {0}; e = hipMemcpyToSymbol(HIP_SYMBOL(bbx_bin_prof_acc), z, sizeof z); }
+  return (int)e;
+}
 extern "C" int bbx_wide_prof_read(unsigned long long* out, int reset) {   // diagnostic build only
   hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(bbx_wide_prof_acc), 32 * sizeof(unsigned long long));
   if (e == hipSuccess && reset) { unsigned long long z[32] = {0}; e = hipMemcpyToSymbol(HIP_SYMBOL(bbx_wide_prof_acc), z, sizeof z); }
@@ -1455,8 +1544,10 @@ static int launch_w(const BbxParams* p, int kind, int blocks, int threads, size_
     return 0;
   }
 #endif
-  if (binom) { if (trace) BBX_LAUNCH((bbx_binom_kernel<W, false, true>)); else BBX_LAUNCH((bbx_binom_kernel<W, false, false>)); }
-  else {
+  if (binom) {
+    lds = (size_t)(threads / WAVE) * update_lds_bytes<W>();           // Gebauer-Moeller peel scratch, one per wave
+    if (trace) BBX_LAUNCH((bbx_binom_kernel<W, false, true>)); else BBX_LAUNCH((bbx_binom_kernel<W, false, false>));
+  } else {
     lds = (size_t)(threads / WAVE) * merge_lds_bytes<W>();          // merge-path tile scratch, one per wave
     const void* fn = trace ? (const void*)bbx_step_kernel<W, false, true> : (const void*)bbx_step_kernel<W, false, false>;
     hipError_t err = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -17,7 +17,7 @@ def pytest_sessionstart(session):
     """GPU runs: bring torch's HIP runtime up before any test starts child processes (tests/test_multirank_gpu.py) —
     torch failed to find the GPU when it was first initialised after this process had forked children."""
     expr = session.config.getoption("markexpr", "") or ""
-    if "gpu" in expr and "not gpu" not in expr:
+    if "not gpu" not in expr:                      # (-m gpu, or a -k selection that may include GPU tests)
         try:
             import torch
             if torch.cuda.is_available():
