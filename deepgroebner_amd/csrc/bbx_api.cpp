@@ -163,7 +163,7 @@ namespace {
 
 int pack_mono(const bbx_batch* b, const bbx::HTerm& t, uint32_t* w) {
   const int W = b->W, slots = 2 * W;
-  uint32_t s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint32_t s[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   for (int v = 0; v < bbx::kN; v++) {
     if (t.e[v] == 0) continue;
     if (v >= slots - 1) return fail(BBX_E_UNSUPPORTED, "variable index %d does not fit the %d-slot monomial", v, slots);
@@ -300,6 +300,7 @@ void fill_params(bbx_batch* b, BbxParams* p) {
   p->q.words = b->d_q; p->q.env_stride = b->fixed ? 0 : b->nslots * b->slot_words; p->q.slot_words = b->slot_words;
   p->q.nslots = b->nslots; p->q.fixed = b->fixed ? 1 : 0; p->q.tail = b->d_tail;
   p->elim = b->elim; p->rewards_mode = b->rewards; p->sort_reducers = b->sort_reducers; p->k = b->k; p->nvars = b->nvars;
+  p->sort_input = (b->device_gen && b->sort_input) ? 1 : 0;
   p->trace = b->d_trace; p->trace_stride = b->trace_cap;
   p->inv_table = b->d_inv;
   p->accounting = b->accounting ? 1 : 0;
@@ -491,9 +492,9 @@ int create_common(std::unique_ptr<bbx::IdealGen> proto, int nvars_obs, int elimi
     if (list) for (auto& I : *list) for (auto& f : I) for (auto& t : f.t) for (int v = 0; v < bbx::kN; v++) if (t.e[v]) maxvar = std::max(maxvar, v + 1);
     if (!b->fixed && !list) maxvar = std::max(maxvar, proto->nvars());
   }
-  if (maxvar > 7) return fail(BBX_E_UNSUPPORTED, "8-variable rings are not supported by the device monomial format (7 exponents + degree)");
-  if (b->nvars > 7) return fail(BBX_E_UNSUPPORTED, "observation width of %d variables is not supported", b->nvars);
-  b->W = maxvar <= 3 ? 2 : 4;
+  if (maxvar > bbx::kN || b->nvars > bbx::kN) return fail(BBX_E_UNSUPPORTED, "more than %d variables", bbx::kN);
+  // words per packed monomial: 8 bytes (<= 3 variables), 16 bytes (<= 7), 32 bytes (the reference's N = 8, polynomials.h:29)
+  b->W = maxvar <= 3 ? 2 : (maxvar <= 7 ? 4 : 8);
   const bool binomial = !b->fixed && !list && proto->max_terms_hint() == 2;
   bbx_caps c{};
   if (caps) c = *caps;
@@ -518,7 +519,7 @@ int create_common(std::unique_ptr<bbx::IdealGen> proto, int nvars_obs, int elimi
   if (c.max_basis & 1) c.max_basis += c.max_basis < 65535 ? 1 : -1;
   b->binom = binomial && !c.general_class && !getenv("BBX_NO_BINOM");
   // long-polynomial environments (fixed ideals such as cyclic-n) in small batches: one workgroup per environment
-  if ((b->fixed || list) && !getenv("BBX_NO_WIDE")) b->wide = c.wide_waves > 0 ? std::min(8, c.wide_waves) : (c.wide_waves < 0 ? 0 : (batch <= 4096 ? 8 : 0));
+  if ((b->fixed || list) && b->W <= 4 && !getenv("BBX_NO_WIDE")) b->wide = c.wide_waves > 0 ? std::min(8, c.wide_waves) : (c.wide_waves < 0 ? 0 : (batch <= 4096 ? 8 : 0));
   if (c.wide_lds_terms < 0 || c.wide_lds_terms > 4096) return fail(BBX_E_ARG, "wide_lds_terms out of range");
   b->wide_terms = c.wide_lds_terms;
   // LDS-resident class: small binomial environments work out of LDS for the whole launch; anything that
@@ -538,10 +539,11 @@ int create_common(std::unique_ptr<bbx::IdealGen> proto, int nvars_obs, int elimi
   b->L = b->binom ? make_layout_binom(b->W, c.max_basis, c.max_pairs)
                   : make_layout(b->W, c.max_basis, c.max_pairs, c.arena_terms, c.max_poly_terms);
   // random distributions: the ideals are drawn on the device (same seeded streams; see gen_binomial / gen_polynomial in
-  // bbx_kernels.hip) and the ideal queue shrinks to one unused slot.  Not with sort_input (the generators would have to
-  // be sorted first) or ideal lists.
+  // bbx_kernels.hip) and the ideal queue shrinks to one unused slot.  sort_input: the device sorts up to 16 generators
+  // (gen_sorted_rank; std::sort is a stable insertion sort up to there, beyond it the host's std::sort decides ties).  Not
+  // for ideal lists.
   std::vector<uint32_t> gen_table;
-  if (!b->fixed && !list && !sort_input && !getenv("BBX_HOST_GEN")) proto->device_table(b->W, &gen_table);
+  if (!b->fixed && !list && !(sort_input && proto->npolys() > 16) && !getenv("BBX_HOST_GEN")) proto->device_table(b->W, &gen_table);
   b->nslots = (b->fixed || !gen_table.empty()) ? 1 : (uint32_t)c.queue_slots;
   b->slot_words = 1 + (uint32_t)proto->npolys() * (2 + (uint32_t)std::min(proto->max_terms_hint(), c.max_poly_terms) * (1 + b->W));
   b->slot_words = (b->slot_words + 3u) & ~3u;
@@ -1050,12 +1052,10 @@ int bbx_batch_size(const bbx_batch* b) { return b ? b->B : 0; }
 namespace {
 
 bool packed_less(int W, const uint32_t* a, const uint32_t* b) {   // grevlex a < b on packed monomials (device m_gt)
-  const uint64_t ha = (((uint64_t)a[W - 1] << 32) | a[W - 2]) ^ 0x0000FFFFFFFFFFFFull;
-  const uint64_t hb = (((uint64_t)b[W - 1] << 32) | b[W - 2]) ^ 0x0000FFFFFFFFFFFFull;
-  if (ha != hb) return ha < hb;
-  if (W == 4) {
-    const uint64_t la = ~(((uint64_t)a[1] << 32) | a[0]), lb = ~(((uint64_t)b[1] << 32) | b[0]);
-    return la < lb;
+  for (int i = W - 1; i >= 0; i--) {              // most significant word first; exponent slots complemented, degree not
+    const uint32_t mk = i == W - 1 ? 0x0000FFFFu : 0xFFFFFFFFu;
+    const uint32_t ka = a[i] ^ mk, kb = b[i] ^ mk;
+    if (ka != kb) return ka < kb;
   }
   return false;
 }

@@ -125,13 +125,29 @@ __device__ bool bin_reset(BEnv<W>& e, const BbxParams& p, const BbxLayout& L, in
     const uint32_t gflags = ldc(p.gen + 3);
     const GenLanes GL = gen_lanes(p.gen);
     uint32_t x = (uint32_t)uni((int)gen_state);
+    const int lane = lane_id();
     for (;;) {
       const uint32_t x_start = x;
       nG = 0; nP = 0;
+      // sort_input: all generators are drawn first (lane f keeps generator f), then enter in sorted order
+      Mono<W> tabL = m_zero<W>(), tabT = m_zero<W>(); uint32_t tabC = 0; int rank = 0;
+      if (p.sort_input) {
+        for (int f = 0; f < npoly; f++) {
+          Mono<W> lead, tail; uint32_t c;
+          if (!gen_binomial<W>(x, p.gen, GL, gflags, ncp, lead, tail, c)) { *status = BBX_ST_GEN_FAIL; gen_state = x; return false; }
+          if (lane == f) { tabL = lead; tabT = tail; tabC = c; }
+        }
+        rank = gen_sorted_rank<W>(tabL, npoly);
+      }
       for (int f = 0; f < npoly; f++) {
         BTerm<W> t0, t1;
         t0.c = 1;
-        if (!gen_binomial<W>(x, p.gen, GL, gflags, ncp, t0.m, t1.m, t1.c)) { *status = BBX_ST_GEN_FAIL; gen_state = x; return false; }
+        if (p.sort_input) {
+          const int src = __builtin_ctzll(ballot64(lane < npoly && rank == f));
+#pragma unroll
+          for (int q = 0; q < W; q++) { t0.m.w[q] = (uint32_t)__builtin_amdgcn_readlane((int)tabL.w[q], src); t1.m.w[q] = (uint32_t)__builtin_amdgcn_readlane((int)tabT.w[q], src); }
+          t1.c = (uint32_t)__builtin_amdgcn_readlane((int)tabC, src);
+        } else if (!gen_binomial<W>(x, p.gen, GL, gflags, ncp, t0.m, t1.m, t1.c)) { *status = BBX_ST_GEN_FAIL; gen_state = x; return false; }
         if (!bin_add_poly<W>(e, p, L, nG, nP, t0, t1, (int)m_deg(t0.m), status, peel_lds)) { gen_state = x_start; return false; }   // (a spill redoes this draw)
       }
       if (nP != 0) { gen_state = x; return true; }   // buchberger.cpp:313-314: redraw while the pair set is empty
@@ -382,7 +398,7 @@ __device__ __forceinline__ void binom_body(const BbxParams& p, char* smem) {
     bool overflow = false;
     // The reducers' lead monomials do not change during a reduction: the first 64 * SR of them (reducer order) are
     // loaded ONCE, all loads in flight together, and every round scans registers; larger bases continue in memory.
-    constexpr int SR = W == 4 ? 6 : 8;
+    constexpr int SR = W == 2 ? 8 : (W == 4 ? 6 : 3);
     Mono<W> S[SR];
     const int nsr = (nG + WAVE - 1) / WAVE < SR ? (nG + WAVE - 1) / WAVE : SR;
 #pragma unroll

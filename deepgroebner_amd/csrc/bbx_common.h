@@ -120,6 +120,8 @@ struct BbxParams {
   int32_t agent;
   int32_t auto_reset;
   int32_t elim, rewards_mode, sort_reducers, k, nvars;
+  int32_t sort_input;       // device-drawn ideals: the generators of a new ideal enter in ascending lead-monomial order
+                            // (BuchbergerEnv::reset, buchberger.cpp:299-303; at most 16 generators: see gen_sorted_rank)
   const int32_t* actions;   // [B], agent == EXTERNAL
   double* rewards;          // [B] reward of the last executed step
   uint8_t* dones;           // [B]

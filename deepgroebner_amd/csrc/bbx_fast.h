@@ -39,6 +39,7 @@ struct BbxFastParams {
   int32_t agent, auto_reset, set_budget, pass, obs_every_step, obs_fill, rewards_mode;
   int32_t* lite;                                      // [B][4] {status, q_head, budget, |P|} for the host, or null
   const uint32_t* gen;                                // device-side ideal generator table or null (ideals come from the queue)
+  int32_t sort_input;                                 // device-drawn ideals enter in ascending lead-monomial order
   unsigned long long* prof;                           // diagnostic build only: [B][8] cycle sums per phase
 };
 
@@ -396,11 +397,25 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
           const uint32_t x_start = x;
           nG = 0; nP = 0;
           S.slmA.w[0] = S.slmA.w[1] = S.slmB.w[0] = S.slmB.w[1] = FSENT;
-          for (int fidx = 0; fidx < npoly; fidx++) {
+          // sort_input: all generators are drawn first (lane f keeps generator f), then enter in sorted order
+          const bool sorted = cq->sort_input != 0;
+          M2 tabL = m_zero<2>(), tabT = m_zero<2>(); uint32_t tabC = 0; int rank = 0;
+          if (sorted) {
+            for (int fidx = 0; fidx < npoly && ok; fidx++) {
+              M2 lead, tail; uint32_t c;
+              if (!gen_binomial<2>(x, gtab, GL, gflags, ncp, lead, tail, c)) { status = BBX_ST_GEN_FAIL; ok = false; break; }
+              if (lane == fidx) { tabL = lead; tabT = tail; tabC = c; }
+            }
+            rank = gen_sorted_rank<2>(tabL, npoly);
+          }
+          for (int fidx = 0; fidx < npoly && ok; fidx++) {
             if (nG + 1 > limG || nP + nG > limP) { status = BBX_ST_SPILL; ok = false; x = x_start; break; }   // redone from the same draw
             BTerm<2> t0, t1;
             t0.c = 1;
-            if (!gen_binomial<2>(x, gtab, GL, gflags, ncp, t0.m, t1.m, t1.c)) { status = BBX_ST_GEN_FAIL; ok = false; break; }
+            if (sorted) {
+              const int src = __builtin_ctzll(ballot64(lane < npoly && rank == fidx));
+              t0.m = f_readlane(tabL, src); t1.m = f_readlane(tabT, src); t1.c = f_readlane(tabC, src);
+            } else if (!gen_binomial<2>(x, gtab, GL, gflags, ncp, t0.m, t1.m, t1.c)) { status = BBX_ST_GEN_FAIL; ok = false; break; }
             if (npoly <= 64) add_poly(t0, t1, (int)m_deg(t0.m), -1, std::true_type{});
             else add_poly(t0, t1, (int)m_deg(t0.m), -1, std::false_type{});
           }

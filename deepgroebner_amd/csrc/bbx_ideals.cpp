@@ -176,13 +176,87 @@ struct Discrete {               // discrete_distribution<int>::param_type::_M_in
     return (int)(std::lower_bound(cp.begin(), cp.end(), p) - cp.begin());
   }
 };
-// poisson_distribution<int>{mean}(rng), mean < 12 (random.tcc)
-static int poisson_small(MinStd0& r, double lm_thr) {
-  int x = 0;
-  double prod = 1.0;
-  do { prod *= canonical(r); x += 1; } while (prod > lm_thr);
-  return x - 1;
-}
+// std::poisson_distribution<int>{mean} of libstdc++ 11 (bits/random.tcc:1261-1404) over minstd_rand0: products of
+// canonical draws below mean 12; from 12 on Devroye's rejection algorithm (Non-Uniform Random Variate Generation, X.3.3-4
+// + errata) with the distribution's own std::normal_distribution<double> (Marsaglia polar method, which keeps the second
+// variate of a pair for the next call: that state belongs to the generator and travels with its copies, as the
+// reference's member `length_dist` does, ideals.h:227).  Same libm calls as the library, so the same doubles.
+struct Poisson {
+  double mean = 0, lm_thr = 0, lfm = 0, sm = 0, d = 0, scx = 0, cx1 = 0, c2b = 0, cb = 0;
+  bool saved_available = false; double saved = 0;
+  void init(double m_) {
+    mean = m_;
+    if (mean >= 12) {
+      const double m = std::floor(mean);
+      lm_thr = std::log(mean); lfm = std::lgamma(m + 1); sm = std::sqrt(m);
+      const double pi_4 = 0.7853981633974483096156608458198757L;
+      const double dx = std::sqrt(2 * m * std::log(32 * m / pi_4));
+      d = std::round(std::max<double>(6.0, std::min(m, dx)));
+      const double cx = 2 * m + d;
+      scx = std::sqrt(cx / 2); cx1 = 1 / cx;
+      c2b = std::sqrt(pi_4 * cx) * std::exp(cx1);
+      cb = 2 * cx * std::exp(-d * cx1 * (1 + d / 2)) / d;
+    } else lm_thr = std::exp(-mean);
+  }
+  double normal(MinStd0& r) {                  // normal_distribution<double>(0, 1), random.tcc:1802-1835
+    double ret;
+    if (saved_available) { saved_available = false; ret = saved; }
+    else {
+      double x, y, r2;
+      do { x = 2.0 * canonical(r) - 1.0; y = 2.0 * canonical(r) - 1.0; r2 = x * x + y * y; } while (r2 > 1.0 || r2 == 0.0);
+      const double mult = std::sqrt(-2 * std::log(r2) / r2);
+      saved = x * mult; saved_available = true;
+      ret = y * mult;
+    }
+    return ret * 1.0 + 0.0;
+  }
+  int draw(MinStd0& r) {
+    if (mean < 12) {
+      int x = 0;
+      double prod = 1.0;
+      do { prod *= canonical(r); x += 1; } while (prod > lm_thr);
+      return x - 1;
+    }
+    double x;
+    const double naf = (1 - std::numeric_limits<double>::epsilon()) / 2;
+    const double thr = std::numeric_limits<int>::max() + naf;
+    const double m = std::floor(mean);
+    const double spi_2 = 1.2533141373155002512078826424055226L;
+    const double c1 = sm * spi_2, c2 = c2b + c1, c3 = c2 + 1, c4 = c3 + 1;
+    const double k178 = 0.0128205128205128205128205128205128L, e178 = 1.0129030479320018583185514777512983L;
+    const double c5 = c4 + e178, c = cb + c5, cx2 = 2 * (2 * m + d);
+    bool reject = true;
+    do {
+      const double u = c * canonical(r);
+      const double e = -std::log(1.0 - canonical(r));
+      double w = 0.0;
+      if (u <= c1) {
+        const double n = normal(r);
+        const double y = -std::abs(n) * sm - 1;
+        x = std::floor(y);
+        w = -n * n / 2;
+        if (x < -m) continue;
+      } else if (u <= c2) {
+        const double n = normal(r);
+        const double y = 1 + std::abs(n) * scx;
+        x = std::ceil(y);
+        w = y * (2 - y) * cx1;
+        if (x > d) continue;
+      } else if (u <= c3) x = -1;
+      else if (u <= c4) x = 0;
+      else if (u <= c5) { x = 1; w = k178; }
+      else {
+        const double v = -std::log(1.0 - canonical(r));
+        const double y = d + v * cx2 / d;
+        x = std::ceil(y);
+        w = -d * cx1 * (1 + y / 2);
+      }
+      reject = (w - e - x * lm_thr > lfm - std::lgamma(x + m + 1));
+      reject |= x + m >= thr;
+    } while (reject);
+    return (int)(x + m + naf);
+  }
+};
 
 // ---------------------------------------------------------------- ideals.cpp
 std::vector<HPoly> cyclic(int n) {
@@ -316,7 +390,7 @@ class RandomBase : public IdealGen {
       t[BBX_GEN_DEG + 8 * i + 2] = (uint32_t)scaling; t[BBX_GEN_DEG + 8 * i + 3] = (uint32_t)past;
       t[BBX_GEN_DEG + 8 * i + 4] = (uint32_t)((1ull << 32) / scaling);
       for (auto& e : B) {
-        uint32_t s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        uint32_t s[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         for (int v = 0; v < n_; v++) s[v] = (uint32_t)e[v];
         s[slots - 1] = (uint32_t)i;
         for (int w = 0; w < W; w++) t[BBX_GEN_MONO + at * W + w] = s[2 * w] | (s[2 * w + 1] << 16);
@@ -373,13 +447,12 @@ class BinomialGen : public RandomBase {   // ideals.cpp:156-201
 class RandomGen : public RandomBase {     // ideals.cpp:203-231
  public:
   RandomGen(int n, int d, int s, double lam, DistType dist, bool constants, bool homogeneous)
-      : RandomBase(n, d, s, dist, constants, homogeneous), lam_(lam), lm_thr_(std::exp(-lam)) {}
+      : RandomBase(n, d, s, dist, constants, homogeneous), lam_(lam), lm_thr_(std::exp(-lam)) { length_.init(lam); }
   bool next(HIdeal& F, std::string* err) override {
     F.clear();
-    if (lam_ >= 12.0) { if (err) *err = "poisson means >= 12 are not supported"; return false; }
     for (int i = 0; i < s_; i++) {
       HPoly f;
-      int terms = 2 + poisson_small(rng_, lm_thr_);
+      int terms = 2 + length_.draw(rng_);
       int d = degree_.draw(rng_);
       for (int j = 0; j < terms; j++) {
         int c = uniform_int(rng_, 1, kP - 1);
@@ -396,10 +469,15 @@ class RandomGen : public RandomBase {     // ideals.cpp:203-231
     return true;
   }
   std::unique_ptr<IdealGen> clone() const override { return std::make_unique<RandomGen>(*this); }
-  int max_terms_hint() const override { return 64; }
+  // 2 + Poisson(lam) terms: the queue slots are sized for the mean + 10 standard deviations (a longer draw is reported
+  // as a capacity error, not truncated)
+  int max_terms_hint() const override { return lam_ < 12.0 ? 64 : (int)(18 + lam_ + 10 * std::sqrt(lam_)); }
+  // means >= 12 are drawn on the host only: the rejection sampler's log / lgamma / exp would have to give the host
+  // library's doubles bit for bit on the device
   bool device_table(int W, std::vector<uint32_t>* out) const override { return lam_ < 12.0 && base_table(W, out, 4u, lm_thr_); }
  private:
   double lam_, lm_thr_;
+  Poisson length_;
 };
 
 }  // namespace

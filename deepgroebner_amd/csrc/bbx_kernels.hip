@@ -158,6 +158,17 @@ __device__ __forceinline__ bool m_gt(const Mono<4>& a, const Mono<4>& b) {
   uint64_t lb = ~(((uint64_t)b.w[1] << 32) | b.w[0]);
   return ha > hb || (ha == hb && la > lb);
 }
+// 8-variable rings (the reference's N = 8, polynomials.h:29): 32-byte monomials, 15 exponent slots + degree.  Most
+// significant word first; the degree is the high half of the last word, every exponent slot is complemented.
+__device__ __forceinline__ bool m_gt(const Mono<8>& a, const Mono<8>& b) {
+#pragma unroll
+  for (int i = 7; i >= 0; i--) {
+    const uint32_t mk = i == 7 ? 0x0000FFFFu : 0xFFFFFFFFu;
+    const uint32_t ka = a.w[i] ^ mk, kb = b.w[i] ^ mk;
+    if (ka != kb) return ka > kb;
+  }
+  return false;
+}
 template <int W> __device__ __forceinline__ uint32_t m_exp(const Mono<W>& a, int v) {
   uint32_t w = a.w[0];                          // select chain, not a runtime index (keeps Mono in VGPRs)
 #pragma unroll
@@ -170,7 +181,7 @@ template <int W> __device__ __forceinline__ uint32_t m_exp(const Mono<W>& a, int
 struct __attribute__((aligned(4))) ObsI4 { int32_t a, b, c, d; };
 struct __attribute__((aligned(4))) ObsI2 { int32_t a, b; };
 template <int W> __device__ __forceinline__ void obs_store(int32_t* dst, const Mono<W>& mm, int n) {
-  int32_t x[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int32_t x[2 * W > 8 ? 2 * W : 8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
   for (int i = 0; i < W; i++) { x[2 * i] = (int32_t)(mm.w[i] & 0xffffu); x[2 * i + 1] = (int32_t)(mm.w[i] >> 16); }
   switch (n) {                                             // wave-uniform
@@ -180,7 +191,8 @@ template <int W> __device__ __forceinline__ void obs_store(int32_t* dst, const M
     case 4: *(ObsI4*)dst = ObsI4{x[0], x[1], x[2], x[3]}; break;
     case 5: *(ObsI4*)dst = ObsI4{x[0], x[1], x[2], x[3]}; dst[4] = x[4]; break;
     case 6: *(ObsI4*)dst = ObsI4{x[0], x[1], x[2], x[3]}; *(ObsI2*)(dst + 4) = ObsI2{x[4], x[5]}; break;
-    default: *(ObsI4*)dst = ObsI4{x[0], x[1], x[2], x[3]}; *(ObsI2*)(dst + 4) = ObsI2{x[4], x[5]}; dst[6] = x[6]; break;
+    case 7: *(ObsI4*)dst = ObsI4{x[0], x[1], x[2], x[3]}; *(ObsI2*)(dst + 4) = ObsI2{x[4], x[5]}; dst[6] = x[6]; break;
+    default: *(ObsI4*)dst = ObsI4{x[0], x[1], x[2], x[3]}; *(ObsI4*)(dst + 4) = ObsI4{x[4], x[5], x[6], x[7]}; break;   // 8 variables
   }
 }
 
@@ -490,6 +502,22 @@ __device__ __forceinline__ bool gen_binomial(uint32_t& x, const uint32_t* g, con
     if (m_gt(m1, m2)) { lead = m1; tail = m2; return true; }
   }
   return false;
+}
+
+// sort_input (buchberger.cpp:299-303: std::sort of the drawn generators by lead monomial, ascending).  For at most 16
+// elements libstdc++'s std::sort IS its insertion sort (introsort's threshold, bits/stl_algo.h:1880-1886), which never
+// moves an element past an equal one: the order is the stable one.  Lane f holds LM(generator f); returns the position of
+// the lane's generator in that order.  (More than 16 generators: the host generators sort, bbx_api.cpp.)
+template <int W> __device__ __forceinline__ int gen_sorted_rank(const Mono<W>& mine, int npoly) {
+  const int lane = lane_id();
+  int rank = 0;
+  for (int g = 0; g < npoly; g++) {
+    Mono<W> o;
+#pragma unroll
+    for (int q = 0; q < W; q++) o.w[q] = (uint32_t)__builtin_amdgcn_readlane((int)mine.w[q], g);
+    rank += (m_gt(mine, o) || (m_eq(mine, o) && g < lane)) ? 1 : 0;
+  }
+  return rank;
 }
 
 // poisson_distribution<int>(lambda)(rng) for lambda < 12 (random.tcc): multiply canonical draws until below exp(-lambda)
@@ -814,6 +842,25 @@ __device__ bool wave_reset(Env<W>& e, const BbxParams& p, const BbxLayout& L, in
     for (;;) {
       const uint32_t x_start = x;
       nG = 0; nP = 0; arena_used = 0;
+      if (p.sort_input) {
+        // all generators are drawn first, back to back in the scratch polynomials, then enter in sorted order
+        Mono<W> lmine = m_zero<W>(); int nmine = 0, smine = 0, omine = 0, at = 0;
+        for (int f = 0; f < npoly; f++) {
+          int sugar = 0;
+          if (at + ((gflags & 4u) ? WAVE : 2) > 5 * (int)L.maxT) { *status = BBX_ST_POLY_TOO_LONG; gen_state = x_start; return false; }
+          const int n = gen_polynomial<W>(x, p.gen, GL, gflags, ncp, lm_thr, e.hm + at, e.hc + at, (int)L.maxT, &sugar, status);
+          if (n == 0) { gen_state = x; return false; }
+          const Mono<W> lead = e.hm[at];
+          if (lane == f) { lmine = lead; nmine = n; smine = sugar; omine = at; }
+          at += n;
+        }
+        const int rank = gen_sorted_rank<W>(lmine, npoly);
+        for (int r = 0; r < npoly; r++) {
+          const int src = __builtin_ctzll(ballot64(lane < npoly && rank == r));
+          const int n = __builtin_amdgcn_readlane(nmine, src), sugar = __builtin_amdgcn_readlane(smine, src), off = __builtin_amdgcn_readlane(omine, src);
+          if (!wave_add_poly<W>(e, L, nG, nP, arena_used, e.hm + off, e.hc + off, n, sugar, p.elim, p.sort_reducers, status)) { gen_state = x_start; return false; }
+        }
+      } else
       for (int f = 0; f < npoly; f++) {
         int sugar = 0;
         const int n = gen_polynomial<W>(x, p.gen, GL, gflags, ncp, lm_thr, e.hm, e.hc, (int)L.maxT, &sugar, status);
@@ -1348,7 +1395,8 @@ extern "C" int bbx_launch_clone(const char* src_recs, char* dst_recs, const BbxL
                                 const uint32_t* seeds, int keep_counters, hipStream_t stream) {
   const int blocks = (n + 3) / 4;
   if (L->W == 2) hipLaunchKernelGGL((bbx_clone_kernel<2>), dim3(blocks), dim3(256), 0, stream, src_recs, dst_recs, *L, src, dst, n, seeds, keep_counters);
-  else hipLaunchKernelGGL((bbx_clone_kernel<4>), dim3(blocks), dim3(256), 0, stream, src_recs, dst_recs, *L, src, dst, n, seeds, keep_counters);
+  else if (L->W == 4) hipLaunchKernelGGL((bbx_clone_kernel<4>), dim3(blocks), dim3(256), 0, stream, src_recs, dst_recs, *L, src, dst, n, seeds, keep_counters);
+  else hipLaunchKernelGGL((bbx_clone_kernel<8>), dim3(blocks), dim3(256), 0, stream, src_recs, dst_recs, *L, src, dst, n, seeds, keep_counters);
   return (int)hipGetLastError();
 }
 
@@ -1569,6 +1617,7 @@ static int launch_fast(const BbxParams* p, int blocks, int threads, int envs_per
   f.obs_every_step = p->obs_every_step; f.obs_fill = p->obs_fill; f.rewards_mode = p->rewards_mode;
   f.lite = p->lite;
   f.gen = p->gen;
+  f.sort_input = p->sort_input;
   const size_t lds = (size_t)envs_per_block * FLDS_BYTES;
 #ifdef BBX_PROF_BUILD
   static unsigned long long* d_prof = nullptr;
@@ -1599,6 +1648,7 @@ extern "C" int bbx_launch_step(const BbxParams* p, int kind, int envs_per_block,
   const int blocks = (p->B + envs_per_block - 1) / envs_per_block;
   if (kind == 3) { launch_fast(p, blocks, threads, envs_per_block, stream); return (int)hipGetLastError(); }
   if (kind == 4) {                                         // wide: envs_per_block is the number of waves per environment
+    if (p->L.W != 2 && p->L.W != 4) return (int)hipErrorInvalidValue;   // (8-variable rings take the general class)
     const int nw = envs_per_block;
     BbxParams q = *p;                                      // LDS capacities of the workgroup (terms): forced by the caller or
     const int W_ = (int)q.L.W;                             // as large as the residency aimed at allows
@@ -1630,7 +1680,8 @@ extern "C" int bbx_launch_step(const BbxParams* p, int kind, int envs_per_block,
     return (int)hipGetLastError();
   }
   const size_t lds = kind == 1 ? (size_t)envs_per_block * p->LL.rec_bytes : 0;
-  int rc = p->L.W == 2 ? launch_w<2>(p, kind, blocks, threads, lds, stream) : launch_w<4>(p, kind, blocks, threads, lds, stream);
+  int rc = p->L.W == 2 ? launch_w<2>(p, kind, blocks, threads, lds, stream)
+         : p->L.W == 4 ? launch_w<4>(p, kind, blocks, threads, lds, stream) : launch_w<8>(p, kind, blocks, threads, lds, stream);
   if (rc) return rc;
   return (int)hipGetLastError();
 }

@@ -593,13 +593,86 @@ static int dd_draw(const discrete_dist* d, minstd0* r) {
   while (lo < hi) { int mid = lo + (hi - lo) / 2; if (d->cp[mid] < p) lo = mid + 1; else hi = mid; }
   return lo;
 }
-/* poisson_distribution<int>(mean)(urng), mean < 12 branch (random.tcc) */
-static int rng_poisson(minstd0* r, double mean, double lm_thr) {
-  (void)mean;
-  int x = 0;
-  double prod = 1.0;
-  do { prod *= rng_canonical(r); x += 1; } while (prod > lm_thr);
-  return x - 1;
+/* std::poisson_distribution<int>(mean) of libstdc++ 11 (bits/random.tcc:1261-1404) over minstd_rand0, both branches:
+ * products of canonical draws below mean 12, Devroye's rejection algorithm from 12 on, with the distribution's own
+ * normal_distribution<double> (polar method; the second variate of a pair is kept for the next call). */
+typedef struct {
+  double mean, lm_thr, lfm, sm, d, scx, cx1, c2b, cb;
+  int saved_available; double saved;
+} poisson_dist;
+static void pd_init(poisson_dist* p, double mean) {
+  memset(p, 0, sizeof *p);
+  p->mean = mean;
+  if (mean >= 12) {
+    const double m = floor(mean);
+    p->lm_thr = log(mean); p->lfm = lgamma(m + 1); p->sm = sqrt(m);
+    const double pi_4 = 0.7853981633974483096156608458198757L;
+    const double dx = sqrt(2 * m * log(32 * m / pi_4));
+    double dd = m < dx ? m : dx; if (dd < 6.0) dd = 6.0;
+    p->d = round(dd);
+    const double cx = 2 * m + p->d;
+    p->scx = sqrt(cx / 2); p->cx1 = 1 / cx;
+    p->c2b = sqrt(pi_4 * cx) * exp(p->cx1);
+    p->cb = 2 * cx * exp(-p->d * p->cx1 * (1 + p->d / 2)) / p->d;
+  } else p->lm_thr = exp(-mean);
+}
+static double pd_normal(poisson_dist* p, minstd0* r) {
+  double ret;
+  if (p->saved_available) { p->saved_available = 0; ret = p->saved; }
+  else {
+    double x, y, r2;
+    do { x = 2.0 * rng_canonical(r) - 1.0; y = 2.0 * rng_canonical(r) - 1.0; r2 = x * x + y * y; } while (r2 > 1.0 || r2 == 0.0);
+    const double mult = sqrt(-2 * log(r2) / r2);
+    p->saved = x * mult; p->saved_available = 1;
+    ret = y * mult;
+  }
+  return ret * 1.0 + 0.0;
+}
+static int rng_poisson(minstd0* r, poisson_dist* p) {
+  if (p->mean < 12) {
+    int x = 0;
+    double prod = 1.0;
+    do { prod *= rng_canonical(r); x += 1; } while (prod > p->lm_thr);
+    return x - 1;
+  }
+  double x;
+  const double naf = (1 - 2.220446049250313e-16) / 2;
+  const double thr = 2147483647.0 + naf;
+  const double m = floor(p->mean);
+  const double spi_2 = 1.2533141373155002512078826424055226L;
+  const double c1 = p->sm * spi_2, c2 = p->c2b + c1, c3 = c2 + 1, c4 = c3 + 1;
+  const double k178 = 0.0128205128205128205128205128205128L, e178 = 1.0129030479320018583185514777512983L;
+  const double c5 = c4 + e178, c = p->cb + c5, cx2 = 2 * (2 * m + p->d);
+  int reject = 1;
+  do {
+    const double u = c * rng_canonical(r);
+    const double e = -log(1.0 - rng_canonical(r));
+    double w = 0.0;
+    if (u <= c1) {
+      const double n = pd_normal(p, r);
+      const double y = -fabs(n) * p->sm - 1;
+      x = floor(y);
+      w = -n * n / 2;
+      if (x < -m) continue;
+    } else if (u <= c2) {
+      const double n = pd_normal(p, r);
+      const double y = 1 + fabs(n) * p->scx;
+      x = ceil(y);
+      w = y * (2 - y) * p->cx1;
+      if (x > p->d) continue;
+    } else if (u <= c3) x = -1;
+    else if (u <= c4) x = 0;
+    else if (u <= c5) { x = 1; w = k178; }
+    else {
+      const double v = -log(1.0 - rng_canonical(r));
+      const double y = p->d + v * cx2 / p->d;
+      x = ceil(y);
+      w = -p->d * p->cx1 * (1 + y / 2);
+    }
+    reject = (w - e - x * p->lm_thr > p->lfm - lgamma(x + m + 1));
+    reject |= x + m >= thr;
+  } while (reject);
+  return (int)(x + m + naf);
 }
 
 /* ---- selection strategies, buchberger.h:111 ------------------------------ */
@@ -797,6 +870,7 @@ typedef struct {
   int kind, n, s, d;
   int homogeneous, pure;
   double lam, lm_thr;
+  poisson_dist length_dist;
   monovec* bases; /* bases[0..d] */
   discrete_dist degree_dist;
   minstd0 rng;
@@ -894,6 +968,7 @@ static gen* parse_ideal_dist(const char* dist) {
   gen* g = gen_random_common(GEN_RANDOM, atoi(a[0]), atoi(a[1]), atoi(a[2]), dt, consts, homog);
   g->lam = atof(a[3]);
   g->lm_thr = exp(-g->lam);
+  pd_init(&g->length_dist, g->lam);
   return g;
 }
 static mono gen_choice(gen* g, int d) { /* choice(): fresh uniform_int_distribution(0, len-1), ideals.h:68-73 */
@@ -930,7 +1005,7 @@ static int gen_next(gen* g, polyvec* F) {
   }
   for (int i = 0; i < g->s; i++) { /* GEN_RANDOM */
     poly f; poly_init(&f);
-    int terms = 2 + rng_poisson(&g->rng, g->lam, g->lm_thr);
+    int terms = 2 + rng_poisson(&g->rng, &g->length_dist);
     int d = dd_draw(&g->degree_dist, &g->rng);
     for (int j = 0; j < terms; j++) {
       term t; t.c = rng_uniform_int(&g->rng, 1, BO_P - 1);

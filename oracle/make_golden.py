@@ -30,6 +30,14 @@ TRACES = {
     "w3_none_reductions": ("3-20-10-weighted", {"elimination": "none", "rewards": "reductions"}, 2, 3, 310, 2, "hash", 60, False),
     "w3_sortinput_nosortred": ("3-20-10-weighted", {"sort_input": True, "sort_reducers": False}, 2, 3, 320, 3, "hash", 120, False),
     "m3_pure_homog": ("3-8-6-maximum-pure-homog", {}, 2, 3, 5, 5, "hash", 100, False),
+    # Poisson mean >= 12 (libstdc++'s rejection branch): polynomials of ~18 terms
+    "p3_poisson16": ("3-5-3-16.0-uniform", {}, 2, 2, 77, 5, "hash", 40, False),
+    # 8-variable rings (the reference's N, polynomials.h:29)
+    "b8_hash_b3": ("8-4-5-uniform", {}, 1, 3, 900, 2, "hash", 150, False),
+    "r8_hash_b2": ("8-3-4-1.5-weighted", {}, 2, 2, 31, 4, "hash", 60, False),
+    # sort_input with sorted reducers (BuchbergerEnv::reset sorts the drawn generators, buchberger.cpp:299-303)
+    "w3_sortinput": ("3-20-10-weighted", {"sort_input": True}, 2, 4, 640, 6, "hash", 160, False),
+    "u5_sortinput": ("5-10-5-uniform", {"sort_input": True}, 2, 2, 650, 7, "hash", 200, False),
 }
 
 GENERATORS = [
@@ -45,6 +53,11 @@ GENERATORS = [
     ("6-4-7-2.0-maximum", [17]),
     ("cyclic-4", [0]),
     ("cyclic-7", [0]),
+    ("3-6-4-15.5-uniform", [123, 9]),
+    ("4-5-3-30.0-weighted-homog", [4]),
+    ("2-9-3-12.0-maximum-consts", [8]),
+    ("8-4-5-uniform", [123]),
+    ("8-3-4-1.5-weighted", [6]),
 ]
 
 

@@ -310,7 +310,7 @@ def test_lead_monomial_padding_and_k_sweep():
             assert r == o.step(a)
 
 
-@pytest.mark.parametrize("dist", ["2-8-4-weighted", "4-5-4-weighted", "6-4-4-uniform", "7-3-4-weighted",
+@pytest.mark.parametrize("dist", ["2-8-4-weighted", "4-5-4-weighted", "6-4-4-uniform", "7-3-4-weighted", "8-3-4-weighted",
                                   "2-5-4-0.8-uniform", "6-3-4-0.5-weighted"])
 def test_observation_width_sweep(dist):
     """Every row width the observation writer knows how to store (n = 2..7 variables: dword / dwordx2 / dwordx4
@@ -331,20 +331,22 @@ def test_observation_width_sweep(dist):
             assert r == o.step(a)
 
 
+@pytest.mark.parametrize("sort_input", [False, True])
 @pytest.mark.parametrize("dist", ["3-20-10-weighted", "3-20-10-uniform-consts", "3-8-6-maximum-pure-homog", "5-10-5-uniform",
-                                  "7-4-4-weighted-homog", "3-6-5-0.5-uniform", "4-4-4-1.5-weighted-consts", "3-5-4-2.0-maximum-homog"])
-def test_device_drawn_ideals_equal_host_drawn(dist, monkeypatch):
+                                  "7-4-4-weighted-homog", "3-6-5-0.5-uniform", "4-4-4-1.5-weighted-consts", "3-5-4-2.0-maximum-homog",
+                                  "8-4-5-uniform", "8-2-3-0.5-weighted"])
+def test_device_drawn_ideals_equal_host_drawn(dist, sort_input, monkeypatch):
     """Random distributions — binomial and polynomial (Poisson term counts, sums of single terms, 1/LC scaling) — are
     drawn inside the kernels (minstd_rand0 + libstdc++'s distributions restated on the device); BBX_HOST_GEN=1 selects the
     host generators + ideal queue instead.  Same seeds, same rollout: identical
     counters and final states, episode after episode (each reset consumes the next ideal of the stream)."""
     from deepgroebner_amd import VecLeadMonomialsEnv
-    B, T = 6, (6000 if dist.startswith("5-") else 400)
+    B, T = 6, {"5-10-5-uniform": 6000, "8-4-5-uniform": 6000}.get(dist, 400)
     envs = []
     for host in (False, True):
         if host:
             monkeypatch.setenv("BBX_HOST_GEN", "1")
-        env = VecLeadMonomialsEnv(dist, batch=B, k=1)
+        env = VecLeadMonomialsEnv(dist, batch=B, k=1, sort_input=sort_input)   # (sort_input: sorted on the device / by the host's std::sort)
         env.seed(np.arange(B) * 7 + 3); env.seed_agent(np.arange(B) + 50); env.reset()
         env.rollout("random", T, auto_reset=True)
         envs.append(env)
