@@ -27,17 +27,30 @@
 #include <string>
 #include <vector>
 
-// The reducer list G_ and the wrapped env are private in the reference
-// classes; the driver needs to read them to dump complete traces.  All
-// standard headers are already included above, so this only affects the
-// reference headers.
-#define private public
-#define protected public
 #include "buchberger.h"
 #include "ideals.h"
 #include "polynomials.h"
-#undef private
-#undef protected
+
+// BuchbergerEnv keeps its reducer list G_ and its ideal generator private.  The driver must read the former (to dump the
+// reducer order into the golden traces) and set the latter (environments over a fixed ideal).  It reaches them through
+// pointers to members obtained in explicit template instantiations — the one place where the language does not apply
+// access checks to names ([temp.spec]) — so the reference headers are compiled exactly as they are: no macro games, no
+// second definition of its classes.
+namespace access {
+template <typename Tag> struct Member { static typename Tag::type ptr; };
+template <typename Tag> typename Tag::type Member<Tag>::ptr;
+template <typename Tag, typename Tag::type P> struct Bind {
+  struct Init { Init() { Member<Tag>::ptr = P; } };
+  static Init init;
+};
+template <typename Tag, typename Tag::type P> typename Bind<Tag, P>::Init Bind<Tag, P>::init;
+struct Reducers { typedef std::vector<Polynomial> BuchbergerEnv::*type; };
+struct Generator { typedef std::unique_ptr<IdealGenerator> BuchbergerEnv::*type; };
+template struct Bind<Reducers, &BuchbergerEnv::G_>;
+template struct Bind<Generator, &BuchbergerEnv::ideal_gen>;
+}  // namespace access
+static std::vector<Polynomial>& reducers_of(BuchbergerEnv& env) { return env.*access::Member<access::Reducers>::ptr; }
+static std::unique_ptr<IdealGenerator>& generator_of(BuchbergerEnv& env) { return env.*access::Member<access::Generator>::ptr; }
 
 namespace {
 
@@ -199,7 +212,7 @@ void* ref_env_new(const char* dist, int elim, int rewards, int sort_input, int s
 void* ref_env_new_fixed(void* pl, int elim, int rewards, int sort_input, int sort_reducers) {
   Env* e = new Env("cyclic-3", elim_of(elim), rewards == 0 ? RewardType::Additions : RewardType::Reductions,
                    sort_input, sort_reducers);
-  e->env.ideal_gen = std::make_unique<FixedIdealGenerator>(static_cast<PolyList*>(pl)->v);
+  generator_of(e->env) = std::make_unique<FixedIdealGenerator>(static_cast<PolyList*>(pl)->v);
   return e;
 }
 void ref_env_free(void* e) { delete static_cast<Env*>(e); }
@@ -236,10 +249,11 @@ void ref_env_poly_get(void* e, int i, int* coef, int* exps) {
 void ref_env_reducer_order(void* e, int* out) {
   BuchbergerEnv& env = static_cast<Env*>(e)->env;
   std::vector<char> used(env.G.size(), 0);
-  for (size_t r = 0; r < env.G_.size(); r++) {
+  const std::vector<Polynomial>& G_ = reducers_of(env);
+  for (size_t r = 0; r < G_.size(); r++) {
     out[r] = -1;
     for (size_t i = 0; i < env.G.size(); i++) {
-      if (!used[i] && env.G[i] == env.G_[r]) { used[i] = 1; out[r] = (int)i; break; }
+      if (!used[i] && env.G[i] == G_[r]) { used[i] = 1; out[r] = (int)i; break; }
     }
   }
 }
