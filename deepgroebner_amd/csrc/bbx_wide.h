@@ -336,6 +336,55 @@ __device__ unsigned long long bbx_wide_prof_acc[32];
 #define WCOUNT(slot, v) do {} while (0)
 #endif
 
+// Leader-wave sections that run once per episode / once per step on the HBM record.  They are compiled as functions of
+// their own (results travel through the control block) so that the register allocation of the reduction loop does not
+// depend on code it never runs: an addition to the reset path once cost the loop 25 % through relocated spills.
+template <int W>
+__device__ __noinline__ void wide_leader_reset(const BbxParams* pp, BBX_AS3 WideCtl* ctl, int env) {
+  const BbxParams& p = *pp;   // (the kernarg pointer intrinsic is null outside the kernel function itself)
+  Env<W> e = env_view<W>(p.recs + (size_t)env * p.L.rec_bytes, p.L);
+  BBX_AS3 WideCold* const st = &ctl->st;
+  int nG = 0, nP = 0, arena_used = 0, status = BBX_ST_OK;
+  int q_head = st->q_head; uint32_t gen_state = st->gen_state;
+  const bool ok = wave_reset<W>(e, p, p.L, env, nG, nP, arena_used, q_head, &status, gen_state);
+  if (lane_id() == 0) {
+    ctl->bc[0] = ok ? 1 : 0; ctl->bc[1] = nG; ctl->bc[2] = nP; ctl->bc[3] = arena_used; ctl->bc[5] = status;
+    st->q_head = q_head; st->gen_state = gen_state; st->episode_steps = 0;
+  }
+}
+template <int W>
+__device__ __noinline__ void wide_leader_add(const BbxParams* pp, BBX_AS3 WideCtl* ctl, int env, int nG, int nP, int arena_used, int rn, int rsug) {
+  const BbxParams& p = *pp;   // (the kernarg pointer intrinsic is null outside the kernel function itself)
+  Env<W> e = env_view<W>(p.recs + (size_t)env * p.L.rec_bytes, p.L);
+  int status = BBX_ST_OK;
+  wave_sync();
+  const bool ok = wave_add_poly<W>(e, p.L, nG, nP, arena_used, e.am + arena_used, e.ac + arena_used, rn, rsug, p.elim, p.sort_reducers, &status, true);
+  if (lane_id() == 0) { ctl->bc[0] = ok ? 1 : 0; ctl->bc[1] = nG; ctl->bc[2] = nP; ctl->bc[3] = arena_used; ctl->bc[5] = status; }
+}
+template <int W>
+__device__ __noinline__ void wide_leader_select(const BbxParams* pp, BBX_AS3 WideCtl* ctl, int env, int nP, int agent) {
+  const BbxParams& p = *pp;   // (the kernarg pointer intrinsic is null outside the kernel function itself)
+  const Env<W> e = env_view<W>(p.recs + (size_t)env * p.L.rec_bytes, p.L);
+  BBX_AS3 WideCold* const st = &ctl->st;
+  int a;
+  if (agent == BBX_AGENT_STDRANDOM) { uint32_t r = st->std_rng; a = std_choice(r, nP); if (lane_id() == 0) st->std_rng = r; }
+  else a = select_pair<W>(e, nP, agent, [&](int g) { return (int)e.psug[g]; });
+  if (lane_id() == 0) ctl->bc[0] = a;
+}
+template <int W>
+__device__ __noinline__ void wide_leader_trace(const BbxParams* pp, BBX_AS3 WideCtl* ctl, int env, int nP, int nG, int nG_before, int action, int done, double reward) {
+  const BbxParams& p = *pp;   // (the kernarg pointer intrinsic is null outside the kernel function itself)
+  const Env<W> e = env_view<W>(p.recs + (size_t)env * p.L.rec_bytes, p.L);
+  const uint64_t oh = wave_obs<W, true>(e, p, env, nP, false, true);
+  const uint64_t ph = wave_pairs_hash<W, Env<W>>(e, nP);
+  const uint64_t nh = nG > nG_before ? wave_poly_hash<W>(e, nG - 1) : 0;
+  if (lane_id() == 0) {
+    BbxTraceRec& tr = p.trace[(size_t)env * p.trace_stride + ctl->st.rollout_pos];
+    tr.action = action; tr.nP = nP; tr.nG = nG; tr.done = done; tr.reward = reward;
+    tr.obs_hash = oh; tr.pairs_hash = ph; tr.newpoly_hash = nh;
+  }
+}
+
 template <int W, bool TRACE, bool LAZY>
 __device__ __forceinline__ void wide_body(char* smem) {
 #ifdef BBX_PROF_BUILD
@@ -506,16 +555,7 @@ __device__ __forceinline__ void wide_body(char* smem) {
     WSTAMP(8);
     if (status != BBX_ST_OK) break;
     if (need_reset) {                                                         // leader alone (once per episode), wave-level code
-      if (leader) {
-        const BbxParams& p = wide_params();
-        Env<W> e = env_view<W>(WIDE_REC(p), p.L);
-        int q_head = st->q_head; uint32_t gen_state = st->gen_state;
-        const bool ok = wave_reset<W>(e, p, p.L, env, nG, nP, arena_used, q_head, &status, gen_state);
-        if (x.lane == 0) {
-          x.ctl->bc[0] = ok ? 1 : 0; x.ctl->bc[1] = nG; x.ctl->bc[2] = nP; x.ctl->bc[3] = arena_used; x.ctl->bc[5] = status;
-          st->q_head = q_head; st->gen_state = gen_state; st->episode_steps = 0;
-        }
-      }
+      if (leader) wide_leader_reset<W>(&wide_params(), x.ctl, env);
       __syncthreads();
       const int ok = uni(x.ctl->bc[0]);
       nG = uni(x.ctl->bc[1]); nP = uni(x.ctl->bc[2]); arena_used = uni(x.ctl->bc[3]); status = uni(x.ctl->bc[5]);
@@ -560,12 +600,7 @@ __device__ __forceinline__ void wide_body(char* smem) {
       else if (agent == BBX_AGENT_FIRST) action = 0;
       else if (agent == BBX_AGENT_LAST) action = nP - 1;
       else {                                                                  // seeded std random / the ordering strategies: leader
-        if (leader) {
-          int a;
-          if (agent == BBX_AGENT_STDRANDOM) { uint32_t r = st->std_rng; a = std_choice(r, nP); if (x.lane == 0) st->std_rng = r; }
-          else a = select_pair<W>(e, nP, agent, [&](int g) { return (int)e.psug[g]; });
-          if (x.lane == 0) x.ctl->bc[0] = a;
-        }
+        if (leader) wide_leader_select<W>(&wide_params(), x.ctl, env, nP, agent);
         __syncthreads();
         action = x.ctl->bc[0];
         __syncthreads();
@@ -747,13 +782,7 @@ __device__ __forceinline__ void wide_body(char* smem) {
     // ---- basis / pair-set update  buchberger.cpp:321-327: leader, wave-level code on the HBM record ----------------
     const int nG_before = nG, nP_before = nP;
     if (rn != 0) {
-      if (leader) {
-        const BbxParams& p = wide_params();
-        Env<W> e = env_view<W>(WIDE_REC(p), p.L);
-        wave_sync();
-        const bool ok = wave_add_poly<W>(e, p.L, nG, nP, arena_used, e.am + arena_used, e.ac + arena_used, rn, rsug, p.elim, p.sort_reducers, &status, true);
-        if (x.lane == 0) { x.ctl->bc[0] = ok ? 1 : 0; x.ctl->bc[1] = nG; x.ctl->bc[2] = nP; x.ctl->bc[3] = arena_used; x.ctl->bc[5] = status; }
-      }
+      if (leader) wide_leader_add<W>(&wide_params(), x.ctl, env, nG, nP, arena_used, rn, rsug);
       __syncthreads();
       const int ok = uni(x.ctl->bc[0]);
       nG = uni(x.ctl->bc[1]); nP = uni(x.ctl->bc[2]); arena_used = uni(x.ctl->bc[3]); status = uni(x.ctl->bc[5]);
@@ -772,17 +801,7 @@ __device__ __forceinline__ void wide_body(char* smem) {
         const Env<W> e = env_view<W>(WIDE_REC(p), p.L);
         wide_obs<W>(e, p, env, nP, x);
       }
-      if (TRACE && p.trace != nullptr && leader) {
-        const Env<W> e = env_view<W>(WIDE_REC(p), p.L);
-        const uint64_t oh = wave_obs<W, true>(e, p, env, nP, false, true);
-        const uint64_t ph = wave_pairs_hash<W, Env<W>>(e, nP);
-        const uint64_t nh = nG > nG_before ? wave_poly_hash<W>(e, nG - 1) : 0;
-        if (x.lane == 0) {
-          BbxTraceRec& tr = p.trace[(size_t)env * p.trace_stride + st->rollout_pos];
-          tr.action = action; tr.nP = nP; tr.nG = nG; tr.done = done ? 1 : 0; tr.reward = reward;
-          tr.obs_hash = oh; tr.pairs_hash = ph; tr.newpoly_hash = nh;
-        }
-      }
+      if (TRACE && p.trace != nullptr && leader) wide_leader_trace<W>(&wide_params(), x.ctl, env, nP, nG, nG_before, action, done ? 1 : 0, reward);
       if (x.tid == 0) {                                                       // bookkeeping (single writer)
         if (!LAZY) st->alg_bytes += step_bytes;                                // (the accumulator hides the canonical length of h)
         st->last_reward = reward;

@@ -31,6 +31,7 @@ ap.add_argument("--agent", default="random")
 ap.add_argument("--to-completion", action="store_true", help="one rollout until every pair set is empty (no auto-reset)")
 ap.add_argument("--no-obs", action="store_true", help="diagnostic: observation only at the end of the rollout")
 ap.add_argument("--accounting", action="store_true", help="time the accounting variant itself")
+ap.add_argument("--no-twin", action="store_true", help="profiling runs: no accounting replay (no algorithmic bytes, no roofline object)")
 ap.add_argument("--kernel", default=None, help="name of the step kernel (for the roofline object)")
 ap.add_argument("--profile", default=None, help="profiles/*.json with hbm_traffic_bytes_per_launch for this exact workload")
 a = ap.parse_args()
@@ -48,10 +49,14 @@ env.prefetch()
 binomial3 = a.dist.startswith("3-") and "." not in a.dist
 fixed = a.dist.startswith("cyclic")
 twin = None
+lean = False
 if (binomial3 or fixed) and not a.accounting:
+    lean = True
+if lean and not a.no_twin:
     # classes with a lean variant (no algorithmic-byte counting): time the lean one, take the bytes — a property of
     # the workload — from a replay of the same steps on a copy with accounting on (like bench.py)
     twin = env.copy()
+if lean:
     env.accounting(False)
 d_obs = torch.empty((B, a.obs_rows, env.cols), dtype=torch.int32, device="cuda")
 d_rew = torch.empty(B, dtype=torch.float64, device="cuda"); d_done = torch.empty(B, dtype=torch.uint8, device="cuda")

@@ -1,0 +1,15 @@
+# rocprofv3 evidence for the step kernels of the other single-GPU BASELINE configs (scripts/bench_configs.py workloads):
+# one kernel-trace --stats run and the PMC passes of scripts/pmc_kernel.sh each, on the lean (timed) variant only
+# (--no-twin: no accounting replay, whose kernel is another instantiation of the same template).
+#   bash scripts/profile_configs.sh r02    -> gpurun_out/cfg_<tag>_*; then python3 scripts/profile_configs_summary.py r02
+cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?run on the GPU box (gpurun)}"
+tag=${1:-r02}
+run() {  # name kernel args...
+  name=$1; kern=$2; shift 2
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/cfg_${tag}_${name}_stats -o s -- python3 scripts/bench_configs.py "$@" --cpu-envs 0 --no-twin > gpurun_out/cfg_${tag}_${name}_stats.log 2>&1 || echo "stats run $name failed"
+  bash scripts/pmc_kernel.sh ${tag}_${name} $kern -- python3 scripts/bench_configs.py "$@" --cpu-envs 0 --no-twin > gpurun_out/cfg_${tag}_${name}_pmc.log 2>&1 || echo "pmc $name failed"
+  # the judged line itself: lean timing + algorithmic bytes from the accounting replay + compiled reference beside it
+  timeout -k 10 600 python3 scripts/bench_configs.py "$@" --kernel $kern > gpurun_out/cfg_${tag}_${name}.json 2> gpurun_out/cfg_${tag}_${name}.err || echo "bench line $name failed"
+}
+run cyclic7 bbx_wide_kernel cyclic-7 --batch 512 --steps 512
+run u5 bbx_binom_kernel 5-10-5-uniform --batch 4096 --steps 2048 --obs-rows 2048
