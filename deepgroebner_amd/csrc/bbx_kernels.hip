@@ -1653,12 +1653,14 @@ extern "C" int bbx_launch_step(const BbxParams* p, int kind, int envs_per_block,
     BbxParams q = *p;                                      // LDS capacities of the workgroup (terms): forced by the caller or
     const int W_ = (int)q.L.W;                             // as large as the residency aimed at allows
     const bool lazy = !q.accounting;                       // lean variant: reducer tails collect in an LDS accumulator
+    bool one_per_cu = false;
     if (q.wide_hc > 0) { q.wide_hc = (q.wide_hc + 7) & ~7; q.wide_fc = q.wide_hc; q.wide_rc = q.wide_hc; q.wide_sc = lazy ? q.wide_hc : 0; }
     else {
       static int ncu = 0;
       if (!ncu) { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount; if (ncu <= 0) ncu = 256; }
       // one workgroup per CU while the batch fits that way (160 KB each), otherwise two per CU (80 KB each)
       const bool one = q.B <= ncu;
+      one_per_cu = one;
       const size_t budget = one ? 160u * 1024u : 80u * 1024u;
       q.wide_fc = one ? 1024 : 512; q.wide_rc = one ? 1024 : 704; q.wide_sc = lazy ? (one ? 1536 : 1024) : 0;
       const size_t fixed = wide_lds_bytes(W_, 0, q.wide_fc, q.wide_rc, q.wide_sc);
@@ -1672,11 +1674,20 @@ extern "C" int bbx_launch_step(const BbxParams* p, int kind, int envs_per_block,
       hipError_t err_ = hipFuncSetAttribute((const void*)bbx_wide_kernel<WW, TT, LL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl); \
       if (err_ != hipSuccess) return (int)err_; \
       hipLaunchKernelGGL((bbx_wide_kernel<WW, TT, LL>), dim3(p->B), dim3(nw * WAVE), wl, stream, *p); } while (0)
+#define BBX_WIDE_LAUNCH1(WW, LL) do { \
+      hipError_t err_ = hipFuncSetAttribute((const void*)bbx_wide_kernel_1cu<WW, LL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl); \
+      if (err_ != hipSuccess) return (int)err_; \
+      hipLaunchKernelGGL((bbx_wide_kernel_1cu<WW, LL>), dim3(p->B), dim3(nw * WAVE), wl, stream, *p); } while (0)
+    if (!tr && one_per_cu && !getenv("BBX_WIDE_NO1CU")) {
+      if (W_ == 2) { if (lazy) BBX_WIDE_LAUNCH1(2, true); else BBX_WIDE_LAUNCH1(2, false); }
+      else { if (lazy) BBX_WIDE_LAUNCH1(4, true); else BBX_WIDE_LAUNCH1(4, false); }
+    } else
     if (W_ == 2) { if (tr) { if (lazy) BBX_WIDE_LAUNCH(2, true, true); else BBX_WIDE_LAUNCH(2, true, false); }
                    else { if (lazy) BBX_WIDE_LAUNCH(2, false, true); else BBX_WIDE_LAUNCH(2, false, false); } }
     else { if (tr) { if (lazy) BBX_WIDE_LAUNCH(4, true, true); else BBX_WIDE_LAUNCH(4, true, false); }
            else { if (lazy) BBX_WIDE_LAUNCH(4, false, true); else BBX_WIDE_LAUNCH(4, false, false); } }
 #undef BBX_WIDE_LAUNCH
+#undef BBX_WIDE_LAUNCH1
     return (int)hipGetLastError();
   }
   const size_t lds = kind == 1 ? (size_t)envs_per_block * p->LL.rec_bytes : 0;

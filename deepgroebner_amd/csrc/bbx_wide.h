@@ -122,6 +122,9 @@ struct WideCtx {
   BBX_AS3 WideCtl* ctl;
   int tid, lane, wave, NT, NW;
   int par_found, par_count, par_end;                      // parities of the exchange slots (advance once per use)
+#ifdef BBX_PROF_BUILD
+  int prof_trips;
+#endif
 };
 
 __device__ __forceinline__ int wide_shr1(int v) {         // lane i <- lane i-1 (lane 0: undefined, fixed by the caller)
@@ -141,18 +144,18 @@ __device__ __forceinline__ int wide_count_ge(const LdsKeys& A, int n, uint64_t x
 // O[nout ...) <- A[0..na) + B[0..nb)  (both descending grevlex; equal monomials summed, zero sums dropped):
 // Polynomial operator+ (polynomials.cpp:148-177) as a workgroup merge-path merge.  Returns the new output count; nothing
 // is stored at or beyond ocap (the caller compares the count with ocap).  Called by ALL threads with uniform arguments.
-template <class AV, class BV, class OV>
-__device__ int wide_merge(const AV& A, int na_, const BV& B, int nb_, const OV& O, int nout_, int ocap_, WideCtx& x) {
+template <int SEG, class AV, class BV, class OV>
+__device__ __forceinline__ int wide_merge_seg(const AV& A, int na_, const BV& B, int nb_, const OV& O, int nout_, int ocap_, WideCtx& x) {
   typedef typename AV::K K;
   // uniform by construction; pinned so that the loops and branches on them are scalar
   const int na = uni(na_), nb = uni(nb_), ocap = uni(ocap_);
   int nout = uni(nout_);
   const int total = na + nb;
   int ci = 0, cj = 0;                                     // merge-path boundary at the start of the current tile
-  for (int base = 0; base < total; base += x.NT * WSEG) {
+  for (int base = 0; base < total; base += x.NT * SEG) {
     // ---- my END boundary: (i1, j1), i1 + j1 = d, such that A[0..i1) and B[0..j1) are exactly the first d terms of the
     // merge (ties: the A term first); an equal pair is never split across a boundary
-    int d = base + (x.tid + 1) * WSEG; d = d < total ? d : total;
+    int d = base + (x.tid + 1) * SEG; d = d < total ? d : total;
     int lo = d - nb > 0 ? d - nb : 0, hi = d < na ? d : na;
     while (lo < hi) {
       const int mid = (lo + hi) >> 1;
@@ -170,15 +173,15 @@ __device__ int wide_merge(const AV& A, int na_, const BV& B, int nb_, const OV& 
       else { i0 = x.ctl->wend[pe][x.wave - 1][0]; j0 = x.ctl->wend[pe][x.wave - 1][1]; }
     }
     ci = uni(x.ctl->wend[pe][x.NW - 1][0]); cj = uni(x.ctl->wend[pe][x.NW - 1][1]);
-    // ---- sequential merge of A[i0..i1) with B[j0..j1): at most WSEG + 1 elements, at most WSEG + 1 outputs
-    K om[WSEG + 1]; uint32_t oc[WSEG + 1];
+    // ---- sequential merge of A[i0..i1) with B[j0..j1): at most SEG + 1 elements, at most SEG + 1 outputs
+    K om[SEG + 1]; uint32_t oc[SEG + 1];
     int i = i0, j = j0;
     K a, b; wk_zero(a); wk_zero(b);
     uint32_t ac = 0, bc = 0;
     if (i < i1) { a = A.key(i); ac = A.coef(i); }
     if (j < j1) { b = B.key(j); bc = B.coef(j); }
 #pragma unroll
-    for (int s = 0; s <= WSEG; s++) {
+    for (int s = 0; s <= SEG; s++) {
       const bool ha = i < i1, hb = j < j1;
       const bool bgt = wk_gt(b, a);
       const bool eq = ha && hb && wk_eq(a, b);
@@ -194,7 +197,7 @@ __device__ int wide_merge(const AV& A, int na_, const BV& B, int nb_, const OV& 
     // ---- positions: thread-major, within a thread in merge order
     int prefix = 0, wtot = 0;
 #pragma unroll
-    for (int s = 0; s <= WSEG; s++) {
+    for (int s = 0; s <= SEG; s++) {
       const uint64_t mk = ballot64(oc[s] != 0);
       prefix += (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
       wtot += __popcll(mk);
@@ -211,12 +214,21 @@ __device__ int wide_merge(const AV& A, int na_, const BV& B, int nb_, const OV& 
     }
     int pos = nout + woff + prefix;
 #pragma unroll
-    for (int s = 0; s <= WSEG; s++) {
+    for (int s = 0; s <= SEG; s++) {
       if (oc[s] != 0) { if (pos < ocap) O.put(pos, om[s], oc[s]); pos++; }
     }
     nout = uni(nout + ttot);
   }
   return nout;
+}
+
+// SEG merged positions per thread per tile: short merges (the common case when one environment owns the whole device:
+// a few hundred terms) are spread over more threads, which shortens each thread's sequential part
+constexpr int WSEG_SHORT = 2;
+template <class AV, class BV, class OV>
+__device__ __forceinline__ int wide_merge(const AV& A, int na, const BV& B, int nb, const OV& O, int nout, int ocap, WideCtx& x) {
+  if (uni(na + nb) <= x.NT * WSEG_SHORT) return wide_merge_seg<WSEG_SHORT>(A, na, B, nb, O, nout, ocap, x);
+  return wide_merge_seg<WSEG>(A, na, B, nb, O, nout, ocap, x);
 }
 
 // tier 3 (cold): the same merge on HBM-resident views.  Not inlined: its register needs (16-byte monomials in flight)
@@ -229,7 +241,7 @@ __device__ __noinline__ int wide_merge_hbm(const Mono<W>* am, const uint16_t* ac
   A.m = am; A.c = ac; A.shift = m_zero<W>(); A.scale = 1u;
   Bv.m = fm; Bv.c = fc; Bv.shift = shift; Bv.scale = scale;
   const GlbOut<W> O{om, oc};
-  return wide_merge(A, an, Bv, fn, O, 0, ocap, x);
+  return wide_merge_seg<WSEG>(A, an, Bv, fn, O, 0, ocap, x);
 }
 
 // D[0..n) <- keys of (scale * x^shift) * src[0..n)   (Term * Polynomial, polynomials.cpp:196-202), all threads
@@ -281,6 +293,9 @@ __device__ int wide_find_divisor(const WideTable<W>& R, int rcl_, const Mono<W>*
       if (k < rcl) s = R.mono(k); else s = slm[k];
       d = m_divides(s, lmh);
     }
+#ifdef BBX_PROF_BUILD
+    x.prof_trips++;
+#endif
     const uint64_t mask = ballot64(d);
     const int mine = mask ? base + x.wave * WAVE + (int)__builtin_ctzll(mask) : 0x7fffffff;
     const int pf = x.par_found; x.par_found ^= 1;
@@ -329,8 +344,12 @@ __device__ void wide_obs(const Env<W>& e, const BbxParams& p, int env, int nP, c
 
 #ifdef BBX_PROF_BUILD   // diagnostic build only: cycles per phase and event counts, summed over all workgroups
 __device__ unsigned long long bbx_wide_prof_acc[32];
-#define WSTAMP(slot) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); wprof[slot] += t_ - wlast; wlast = t_; } while (0)
-#define WCOUNT(slot, v) (wprof[slot] += (unsigned long long)(v))
+// six coarse time slots and a few counters, all at compile-time indices (a 32-slot array lives in scratch and more than
+// doubles the run time, which distorts the very shares it is meant to show)
+#define WSLOT(slot) ((slot) == 2 ? 0 : (slot) == 4 ? 1 : (slot) == 20 ? 2 : (slot) == 22 ? 3 : ((slot) == 5 || (slot) == 6) ? 4 : 5)
+#define WSTAMP(slot) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); wprof[WSLOT(slot)] += t_ - wlast; wlast = t_; } while (0)
+#define WCSLOT(slot) ((slot) == 10 ? 0 : (slot) == 13 ? 1 : (slot) == 23 ? 2 : (slot) == 24 ? 3 : (slot) == 25 ? 4 : (slot) == 15 ? 5 : 6)
+#define WCOUNT(slot, v) (wcnt[WCSLOT(slot)] += (unsigned long long)(v))
 #else
 #define WSTAMP(slot) do {} while (0)
 #define WCOUNT(slot, v) do {} while (0)
@@ -388,7 +407,7 @@ __device__ __noinline__ void wide_leader_trace(const BbxParams* pp, BBX_AS3 Wide
 template <int W, bool TRACE, bool LAZY>
 __device__ __forceinline__ void wide_body(char* smem) {
 #ifdef BBX_PROF_BUILD
-  unsigned long long wprof[32] = {0};
+  unsigned long long wprof[6] = {0, 0, 0, 0, 0, 0}, wcnt[7] = {0, 0, 0, 0, 0, 0, 0};
   unsigned long long wlast = __builtin_amdgcn_s_memtime();
 #endif
   WideCtx x;
@@ -396,6 +415,9 @@ __device__ __forceinline__ void wide_body(char* smem) {
   x.tid = (int)threadIdx.x; x.lane = x.tid & (WAVE - 1); x.wave = uni(x.tid / WAVE);
   x.NT = uni((int)blockDim.x); x.NW = x.NT / WAVE;
   x.par_found = x.par_count = x.par_end = 0;
+#ifdef BBX_PROF_BUILD
+  x.prof_trips = 0;
+#endif
   const int env = (int)blockIdx.x;
   const bool leader = x.wave == 0;
   BBX_AS3 WideCold* const st = &x.ctl->st;
@@ -710,6 +732,9 @@ __device__ __forceinline__ void wide_body(char* smem) {
         { const BbxParams& p = wide_params(); slm_g = (const Mono<W>*)(WIDE_REC(p) + p.L.off_slm); }
         found = wide_find_divisor<W>(R, rcl, slm_g, nG, lmh, x);
         WSTAMP(2);
+#ifdef BBX_PROF_BUILD
+        WCOUNT(23, x.prof_trips); x.prof_trips = 0; WCOUNT(24, found >= 0 ? found : 0); WCOUNT(25, nG);
+#endif
         an = (hn - hoff) + (sn - soff);                                       // (exact in the eager variant: S is empty)
         if (found < 0) {                                                      // r <- r + LT h ; h <- h - LT h   (41-44)
           if (rn >= maxT) { status = BBX_ST_POLY_TOO_LONG; overflow = true; break; }
@@ -819,7 +844,11 @@ __device__ __forceinline__ void wide_body(char* smem) {
 
   __syncthreads();
 #ifdef BBX_PROF_BUILD
-  if (x.tid == 0) for (int i = 0; i < 32; i++) atomicAdd(&bbx_wide_prof_acc[i], wprof[i]);
+  if (x.tid == 0) {
+    const int tslot[6] = {2, 4, 20, 22, 5, 8}, cslot[7] = {10, 13, 23, 24, 25, 15, 31};
+    for (int i = 0; i < 6; i++) atomicAdd(&bbx_wide_prof_acc[tslot[i]], wprof[i]);
+    for (int i = 0; i < 7; i++) atomicAdd(&bbx_wide_prof_acc[cslot[i]], wcnt[i]);
+  }
 #endif
   {
     const BbxParams& p = wide_params();
@@ -853,4 +882,10 @@ template <int W, bool TRACE, bool LAZY>
 __global__ __launch_bounds__(512, 4) void bbx_wide_kernel(BbxParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   wide_body<W, TRACE, LAZY>(smem);
+}
+// the same code for batches of at most one workgroup per CU (two waves per SIMD): no 128-register cap, no spills
+template <int W, bool LAZY>
+__global__ __launch_bounds__(512, 2) void bbx_wide_kernel_1cu(BbxParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  wide_body<W, false, LAZY>(smem);
 }

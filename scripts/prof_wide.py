@@ -1,5 +1,5 @@
 """Diagnostic (BBX_PROF_BUILD library only): per-phase cycle shares of the wide kernel.
-usage: prof_wide.py DIST BATCH STEPS [AGENT_SEED0]"""
+usage: prof_wide.py DIST BATCH STEPS [AGENT_SEED0] [lean|acct] [AGENT]     (STEPS <= 0: to completion, no auto-reset)"""
 import ctypes as C, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -14,19 +14,22 @@ lib = _ffi.lib()
 acc = (C.c_ulonglong * 32)()
 lib.bbx_wide_prof_read(acc, 1)
 t0 = time.perf_counter()
-env.rollout("random", T, auto_reset=True)
+agent = sys.argv[6] if len(sys.argv) > 6 else "random"
+if T > 0:
+    env.rollout(agent, T, auto_reset=True)
+else:
+    env.rollout(agent, 1 << 30, auto_reset=False)
 dt = time.perf_counter() - t0
 lib.bbx_wide_prof_read(acc, 1)
 a = np.array(list(acc), dtype=np.float64)
-names = {0: "loop top/reset/table", 1: "select+removal+spoly setup", 2: "lead term + divisor scan", 3: "tail moves / loop exit", 4: "reducer metadata",
-         5: "add_scaled -> LDS", 6: "add_scaled -> HBM", 7: "leader basis update", 8: "obs + bookkeeping"}
-names.update({20: "  tier 1: reducer tail -> F (load + barrier)", 21: "  tier 1: chunk range search", 22: "  tier 1: merge", 5: "add_scaled -> LDS (rest)"})
+names = {2: "lead term + divisor scan", 4: "reducer metadata", 20: "reducer tail -> F (load + barrier)", 22: "tier-1 merge",
+         5: "rest of add_scaled", 8: "everything else"}
 tot = sum(a[i] for i in names)
 st = env.stats()
 print("seconds %.3f  steps %d additions %d  max additions/env %d (env %d)" % (dt, st[:, 0].sum(), st[:, 1].sum(), st[:, 1].max(), int(st[:, 1].argmax())))
 for i, n in names.items():
-    print("  %-28s %6.2f %%" % (n, 100 * a[i] / tot))
-print("seconds per million: scans %.2f  tier-1 merges %.2f  tail loads %.2f" % (dt * a[2] / tot / max(1, a[10] + a[11] + a[12] + a[13]) * 1e6 / B, dt * a[22] / tot / max(1, a[14]) * 1e6 / B, dt * a[20] / tot / max(1, a[14]) * 1e6 / B))
-print("H rewrites: tier1 %d tier2 %d tier3 %d  accumulator merges %d  tail-moves %d | chunks %d mean an %.0f mean bn %.0f | bring-backs %d spills %d" %
-      (a[10], a[11], a[12], a[15], a[13], a[14], a[16] / max(1, a[10]), a[17] / max(1, a[10]), a[18], a[19]))
-print("cycles per reduction round (all phases): %.0f" % (tot / max(1, a[10] + a[11] + a[12])))
+    print("  %-36s %6.2f %%" % (n, 100 * a[i] / tot))
+scans = max(1.0, a[10] + a[13])
+print("tier-1 rewrites %d  accumulator merges %d  tail-moves %d | scans: trips/scan %.2f  mean found index %.0f  mean |G| %.0f" %
+      (a[10], a[15], a[13], a[23] / scans, a[24] / max(1.0, scans - a[13]), a[25] / scans))
+print("cycles (100 MHz s_memtime ticks x 21) per reduction round: %.0f ticks" % (tot / scans))
