@@ -970,7 +970,8 @@ int bbx_pmlp_act(const int32_t* d_obs, const int32_t* d_rows, int batch, int obs
   {   // shapes the register-resident kernel is instantiated for (deepgroebner_amd/rollout.py falls back to torch otherwise)
     const int cp4 = (cols + 3) / 4, upl = (hidden + 63) / 64;
     const bool cols_ok = cp4 <= 8 || cp4 == 10 || cp4 == 12 || cp4 == 16;
-    if (!cols_ok || upl > 4 || (upl > 2 && cp4 > 8)) return fail(BBX_E_UNSUPPORTED, "policy shape %d x %d is not built into the fused kernel", cols, hidden);
+    const bool mfma_ok = hidden <= 256 && cols <= 64;        // matrix-core kernel (W1 in LDS)
+    if (!mfma_ok && (!cols_ok || upl > 4 || (upl > 2 && cp4 > 8))) return fail(BBX_E_UNSUPPORTED, "policy shape %d x %d is not built into the fused kernel", cols, hidden);
   }
   int lrc = bbx_launch_pmlp_act(d_obs, d_rows, batch, obs_rows, cols, d_w1, d_b1, d_w2, b2, hidden, d_u, d_actions, d_logprobs, (hipStream_t)stream);
   if (lrc) return fail(BBX_E_DEVICE, "policy launch failed: %s", hipGetErrorString((hipError_t)lrc));

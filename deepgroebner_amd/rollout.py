@@ -78,9 +78,10 @@ class PMLPPolicy(torch.nn.Module):
 
     @staticmethod
     def fused_ok(cols, hidden):
-        """Shapes bbx_pmlp_act is instantiated for (weights of a lane's hidden units live in registers)."""
+        """Shapes bbx_pmlp_act is built for: the matrix-core kernel (hidden <= 256, cols <= 64) or the register-resident
+        vector kernel."""
         cp4, upl = (cols + 3) // 4, (hidden + 63) // 64
-        return (cp4 <= 8 or cp4 in (10, 12, 16)) and upl <= 4 and not (upl > 2 and cp4 > 8)
+        return (hidden <= 256 and cols <= 64) or ((cp4 <= 8 or cp4 in (10, 12, 16)) and upl <= 4 and not (upl > 2 and cp4 > 8))
 
     def _fused_weights(self):
         """The kernel's view of the weights ([cols][hidden] fp32 etc.), rebuilt only when a parameter changed (an
