@@ -327,6 +327,7 @@ int enqueue(bbx_batch* b, const BbxParams& p0, bool resume, hipStream_t stream) 
   for (int i = 0; i < nk; i++) {
     if (resume) { p.set_budget = 0; p.pass = 1; }
     else if (i > 0) { p.set_budget = 0; p.pass = 1; }
+    if (resume || i > 0 || kinds[i] != 3) p.policy = nullptr;       // only the first pass of the fast class evaluates the policy
     hipEvent_t e0 = nullptr, e1 = nullptr;
     const bool timed = b->timing && i == 0 && kinds[i] != 2;   // the primary (dominant) kernel of the sequence
     if (timed) {
@@ -442,6 +443,7 @@ int launch(bbx_batch* b, BbxParams& p, hipStream_t stream, bool obs_external = f
   int rc = fill_queues(b, 1, stream);
   if (rc) return rc;
   b->last = p;
+  b->last.policy = nullptr;                 // (a host pointer of the caller's frame: never kept)
   b->last_stream = stream;
   b->in_flight = true;
   b->obs_external = obs_external;
@@ -976,6 +978,31 @@ int bbx_pmlp_act(const int32_t* d_obs, const int32_t* d_rows, int batch, int obs
   int lrc = bbx_launch_pmlp_act(d_obs, d_rows, batch, obs_rows, cols, d_w1, d_b1, d_w2, b2, hidden, d_u, d_actions, d_logprobs, (hipStream_t)stream);
   if (lrc) return fail(BBX_E_DEVICE, "policy launch failed: %s", hipGetErrorString((hipError_t)lrc));
   return BBX_OK;
+}
+
+int bbx_policy_step_device(bbx_batch* b, const float* d_w1, const float* d_b1, const float* d_w2, float b2, int hidden, const float* d_u,
+                           int32_t* d_actions, float* d_logprobs, double* d_rewards, uint8_t* d_dones, int32_t* d_rows, int32_t* d_obs,
+                           int obs_rows, int obs_fill, void* stream) {
+  if (!b || !d_w1 || !d_b1 || !d_w2 || !d_u || !d_actions || !d_logprobs || !d_rows || !d_obs) return fail(BBX_E_ARG, "null argument");
+  if (obs_rows < 1 || hidden < 1) return fail(BBX_E_ARG, "bad policy shape");
+  const int cols = 2 * b->nvars * b->k;
+  // one launch for policy + step where the step kernel has the policy built in (the register/LDS-resident class, lean
+  // variant, hidden layer of at most 128 units); everywhere else the two launches it replaces
+  const bool fused = b->fast && b->staged && !b->accounting && !(b->d_trace && b->trace_cap >= 1) && hidden <= 128 && cols <= 64 &&
+                     !getenv("BBX_NO_FUSED_POLICY");
+  if (!fused) {
+    int rc = bbx_pmlp_act(d_obs, d_rows, b->B, obs_rows, cols, d_w1, d_b1, d_w2, b2, hidden, d_u, d_actions, d_logprobs, stream);
+    if (rc) return rc;
+    return step_device(b, d_actions, d_rewards, d_dones, d_rows, d_obs, obs_rows, obs_fill, stream, 1);
+  }
+  HIPCHK(hipSetDevice(b->device));
+  BbxPolicy pol{d_w1, d_b1, d_w2, b2, hidden, d_u, d_actions, d_logprobs};
+  BbxParams p; fill_params(b, &p);
+  p.nsteps = 1; p.set_budget = 1; p.agent = BBX_AGENT_EXTERNAL; p.auto_reset = 1; p.actions = d_actions;   // (the follow-up pass reads them)
+  p.rewards = d_rewards; p.dones = d_dones; p.rows = d_rows; p.obs = d_obs; p.obs_rows = obs_rows; p.obs_fill = obs_fill;
+  p.trace = nullptr;
+  p.policy = &pol;
+  return launch(b, p, (hipStream_t)stream, true, true);
 }
 
 int bbx_rollout_device(bbx_batch* b, int agent, int nsteps, int auto_reset, double* d_rewards, uint8_t* d_dones,

@@ -109,6 +109,12 @@ enum { BBX_AGENT_EXTERNAL = 0, BBX_AGENT_HASH = 1, BBX_AGENT_DEGREE = 2, BBX_AGE
 enum { BBX_ELIM_GM = 0, BBX_ELIM_LCM = 1, BBX_ELIM_NONE = 2 };
 enum { BBX_REW_ADDITIONS = 0, BBX_REW_REDUCTIONS = 1 };
 
+// one-hidden-layer PMLP policy (networks.py:49-95, 414-460) for the fused policy + step launch: device pointers
+struct BbxPolicy {
+  const float* w1; const float* b1; const float* w2; float b2; int32_t hidden;   // w1 [cols][hidden], b1 / w2 [hidden]
+  const float* u;                 // [B] uniforms in [0, 1) for the inverse-CDF draw
+  int32_t* actions; float* logprobs;   // [B] outputs: the sampled row and its log-probability
+};
 struct BbxParams {
   char* recs;
   BbxLayout L;              // layout of the records in HBM
@@ -120,6 +126,7 @@ struct BbxParams {
   int32_t agent;
   int32_t auto_reset;
   int32_t elim, rewards_mode, sort_reducers, k, nvars;
+  const struct BbxPolicy* policy;   // HOST pointer or null: a PMLP policy evaluated inside the step kernel (fast class only)
   int32_t sort_input;       // device-drawn ideals: the generators of a new ideal enter in ascending lead-monomial order
                             // (BuchbergerEnv::reset, buchberger.cpp:299-303; at most 16 generators: see gen_sorted_rank)
   const int32_t* actions;   // [B], agent == EXTERNAL

@@ -109,7 +109,7 @@ struct FastState {                 // reducer-order arrays, lane l <-> reducers 
 // written after every step without fill, auto-reset): no dispatch on launch parameters inside the step loop and fewer
 // scalar registers live across it.  The launcher picks it when the parameters say exactly that.
 template <bool TRACE, bool ACCT, bool PROF = false, bool HL = false>
-__device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
+__device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem, int ext_action = -1) {
   unsigned long long prof_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long prof_last = PROF ? __builtin_amdgcn_s_memtime() : 0;
   const int lane = lane_id();
@@ -473,7 +473,7 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem) {
     // ---- choose the pair -----------------------------------------------------------------------------------------
     int action;
     if (agent == BBX_AGENT_HASH) action = (int)(((uint64_t)f_readlane(hv, t_agent & 63) * (uint32_t)nP) >> 32);   // bbx_agent_action32
-    else if (agent == BBX_AGENT_EXTERNAL) action = uni(f_cold_params()->actions[env]);
+    else if (agent == BBX_AGENT_EXTERNAL) action = ext_action >= 0 ? ext_action : uni(f_cold_params()->actions[env]);
     else if (agent == BBX_AGENT_FIRST) action = 0;
     else {                                                 // degree: first row of minimal deg lcm (buchberger.cpp:171-176)
       uint32_t best = 0xFFFFFFFFu;
@@ -705,6 +705,21 @@ __global__ __launch_bounds__(256) void bbx_fast_kernel(BbxFastParams p) {
 __global__ __launch_bounds__(256) void bbx_fast_headline_kernel(BbxFastParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   fast_body<false, false, false, true>(p, smem);
+}
+// Policy + step in one launch: every wave first evaluates the PMLP policy on its environment's rows of the
+// observation block the previous launch left (pmlp_act_wave: matrix-core hidden layer, log-softmax, inverse-CDF draw),
+// then takes the step with the sampled row as its action.  The two phases use the same registers and the same LDS one
+// after the other; a vector step costs one kernel's launch, ramp and drain instead of two.  The struct starts with the
+// step parameters: f_cold_params() reads them at offset 0 of the kernel arguments.
+struct BbxFastPolicyParams { BbxFastParams f; BbxPolicy pol; };
+template <int NB>
+__global__ __launch_bounds__(256, 4) void bbx_fast_policy_kernel(BbxFastPolicyParams q) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int env = blockIdx.x * (blockDim.x / WAVE) + (int)(threadIdx.x / WAVE);
+  const int action = pmlp_act_wave<NB>(smem, env, env < q.f.B, q.f.obs, q.f.rows, q.f.obs_rows, 2 * q.f.k * q.f.nvars, q.pol.w1, q.pol.b1, q.pol.w2,
+                                       q.pol.b2, q.pol.hidden, q.pol.u, q.pol.actions, q.pol.logprobs);
+  __syncthreads();                                     // the policy's LDS scratch becomes the step's state
+  fast_body<false, false>(q.f, smem, action);
 }
 #ifdef BBX_PROF_BUILD
 // diagnostic build with s_memtime stamps between the phases of a step (never timed, never shipped as a result)

@@ -202,20 +202,27 @@ def run_rollout(env, policy, nsteps, buffer=None, obs_rows=128, generator=None, 
     env.rollout_device("first", 0, False, stream.cuda_stream, rew, done, rows, obs, obs_rows, True, False)
     env.sync()
     keep_states = buffer is not None and buffer.states is not None
+    one_call = len(policy.embedding) == 1 and policy.fused_ok(cols, policy.embedding[0].out_features) and hasattr(env, "policy_step_device")
+    w = policy._fused_weights() if one_call else None
     nsync = 0
     for t0 in range(0, nsteps, sync_every):
         n = min(sync_every, nsteps - t0)
         u_all = torch.rand((n, B), device=dev, generator=generator)   # one generator launch per chunk of steps
         for i in range(n):
-            policy.act(obs, rows, u_all[i], act, logp, stream)
-            if buffer is not None:
+            if buffer is not None:                      # what the policy is about to see
                 t = buffer.t
                 if keep_states:
                     buffer.states[t].copy_(obs)
-                buffer.rows[t].copy_(rows); buffer.actions[t].copy_(act); buffer.logprobs[t].copy_(logp)
-            env.step_device(act, rew, done, rows, obs, obs_rows, 2, stream.cuda_stream, auto_reset=True)   # (2: incremental padding)
+                buffer.rows[t].copy_(rows)
+            if one_call:                                # policy + step: one library call (one kernel where the class has it)
+                env.policy_step_device(w["w1"], w["b1"], w["w2"], w["b2"].value, w["hidden"], u_all[i], act, logp, rew, done, rows, obs,
+                                       obs_rows, 2, stream.cuda_stream)          # (2: incremental padding)
+            else:
+                policy.act(obs, rows, u_all[i], act, logp, stream)
+                env.step_device(act, rew, done, rows, obs, obs_rows, 2, stream.cuda_stream, auto_reset=True)
             if buffer is not None:
-                buffer.rewards[buffer.t].copy_(rew); buffer.dones[buffer.t].copy_(done)
+                buffer.actions[t].copy_(act); buffer.logprobs[t].copy_(logp)
+                buffer.rewards[t].copy_(rew); buffer.dones[t].copy_(done)
                 buffer.t += 1
         env.sync()
         nsync += 1

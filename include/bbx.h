@@ -166,6 +166,14 @@ int bbx_step_device_autoreset(bbx_batch* b, const int32_t* d_actions, double* d_
  * torch.nn.Linear(...).weight.t()).  d_actions[e] in [0, rows), d_logprobs[e] = its log-probability. */
 int bbx_pmlp_act(const int32_t* d_obs, const int32_t* d_rows, int batch, int obs_rows, int cols, const float* d_w1, const float* d_b1,
                  const float* d_w2, float b2, int hidden, const float* d_u, int32_t* d_actions, float* d_logprobs, void* stream);
+/* One vector step with the policy in the loop: bbx_pmlp_act on the block the previous call left in d_obs / d_rows, then
+ * bbx_step_device_autoreset with the sampled rows as actions, which rewrites d_obs / d_rows (the inner loop of
+ * pg.py:451-503 run_episode, batched).  Where the step kernel has the policy built in (the register/LDS-resident class
+ * with accounting off, hidden <= 128) this is ONE kernel launch; otherwise the two calls it stands for.  d_actions and
+ * d_logprobs receive what was sampled; arguments as in those two calls. */
+int bbx_policy_step_device(bbx_batch* b, const float* d_w1, const float* d_b1, const float* d_w2, float b2, int hidden, const float* d_u,
+                           int32_t* d_actions, float* d_logprobs, double* d_rewards, uint8_t* d_dones, int32_t* d_rows, int32_t* d_obs,
+                           int obs_rows, int obs_fill, void* stream);
 /* obs_every_step != 0 materialises the observation in d_obs after every step (what a device-side policy
  * would consume), otherwise only the state at the end of the rollout is written */
 int bbx_rollout_device(bbx_batch* b, int agent, int nsteps, int auto_reset, double* d_rewards, uint8_t* d_dones,
