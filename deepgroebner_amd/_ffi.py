@@ -66,8 +66,10 @@ SIGNATURES = {
     "bbx_values": (C.c_int, [_vp, C.c_char_p, C.c_double, _vp]),
     "bbx_step_device": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp]),
     "bbx_step_device_autoreset": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp]),
-    "bbx_pmlp_act": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_float, C.c_int, _vp, _vp, _vp, _vp]),
-    "bbx_policy_step_device": (C.c_int, [_vp, _vp, _vp, _vp, C.c_float, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp]),
+    "bbx_pmlp_prepared_floats": (C.c_int, [C.c_int, C.c_int]),
+    "bbx_pmlp_prepare": (C.c_int, [_vp, _vp, _vp, C.c_float, C.c_int, C.c_int, _vp, _vp]),
+    "bbx_pmlp_act": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp]),
+    "bbx_policy_step_device": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp]),
     "bbx_rollout_device": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "bbx_prefetch": (C.c_int, [_vp]),
     "bbx_accounting": (C.c_int, [_vp, C.c_int]),

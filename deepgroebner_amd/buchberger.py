@@ -236,16 +236,16 @@ class VecLeadMonomialsEnv:
         fn = _ffi.lib().bbx_step_device_autoreset if auto_reset else _ffi.lib().bbx_step_device
         _ffi.check(fn(self._h, dp(actions), dp(rewards), dp(dones), dp(rows), dp(obs), int(obs_rows), int(obs_fill), C.c_void_p(int(stream))))   # obs_fill: 0 / 1 / 2 (include/bbx.h)
 
-    def policy_step_device(self, w1, b1, w2, b2, hidden, u, actions, logprobs, rewards, dones, rows, obs, obs_rows, obs_fill=2, stream=0):
+    def policy_step_device(self, prepared, hidden, u, actions, logprobs, rewards, dones, rows, obs, obs_rows, obs_fill=2, stream=0):
         """One asynchronous vector step with the PMLP policy in the loop (bbx_policy_step_device): the policy reads the
-        block of the previous call in obs / rows, its draw is the action; obs / rows are rewritten.  w1 / b1 / w2 / u and
-        the outputs are device buffers (data_ptr() or addresses)."""
+        block of the previous call in obs / rows, its draw is the action; obs / rows are rewritten.  `prepared`: the
+        weights as bbx_pmlp_prepare left them; every buffer on the device (tensors or addresses)."""
         def dp(x):
             if x is None or isinstance(x, C.c_void_p):
                 return x
             return C.c_void_p(x.data_ptr() if hasattr(x, "data_ptr") else int(x))
-        _ffi.check(_ffi.lib().bbx_policy_step_device(self._h, dp(w1), dp(b1), dp(w2), float(b2), int(hidden), dp(u), dp(actions), dp(logprobs),
-                                                    dp(rewards), dp(dones), dp(rows), dp(obs), int(obs_rows), int(obs_fill), C.c_void_p(int(stream))))
+        _ffi.check(_ffi.lib().bbx_policy_step_device(self._h, dp(prepared), int(hidden), dp(u), dp(actions), dp(logprobs), dp(rewards), dp(dones),
+                                                    dp(rows), dp(obs), int(obs_rows), int(obs_fill), C.c_void_p(int(stream))))
 
     def sync(self):
         _ffi.check(_ffi.lib().bbx_sync(self._h))

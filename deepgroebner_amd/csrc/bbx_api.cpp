@@ -26,8 +26,9 @@ extern "C" int bbx_launch_scatter_queue(const uint32_t* stage, int n, uint32_t r
 extern "C" int bbx_launch_obs_pack(const int32_t* padded, int cap, int cols, const int32_t* rows, int B, int32_t* off, int32_t* packed, hipStream_t stream);
 extern "C" int bbx_launch_init(char* recs, uint32_t rec_bytes, int B, const uint32_t* agent_seeds, hipStream_t stream);
 extern "C" int bbx_launch_mark_reset(char* recs, uint32_t rec_bytes, int B, const uint8_t* mask, hipStream_t stream);
-extern "C" int bbx_launch_pmlp_act(const int32_t* obs, const int32_t* rows, int B, int obs_rows, int cols, const float* w1, const float* b1,
-                                   const float* w2, float b2, int hidden, const float* u, int32_t* actions, float* logprobs, hipStream_t stream);
+extern "C" int bbx_launch_pmlp_prepare(const float* w1, const float* b1, const float* w2, float b2, int cols, int hidden, float* out, hipStream_t stream);
+extern "C" int bbx_launch_pmlp_act(const int32_t* obs, const int32_t* rows, int B, int obs_rows, int cols, const float* wp, int hidden, const float* u,
+                                   int32_t* actions, float* logprobs, hipStream_t stream);
 
 namespace {
 
@@ -965,38 +966,50 @@ int bbx_step_device_autoreset(bbx_batch* b, const int32_t* d_actions, double* d_
   return step_device(b, d_actions, d_rewards, d_dones, d_rows, d_obs, obs_rows, obs_fill, stream, 1);
 }
 
-int bbx_pmlp_act(const int32_t* d_obs, const int32_t* d_rows, int batch, int obs_rows, int cols, const float* d_w1, const float* d_b1,
-                 const float* d_w2, float b2, int hidden, const float* d_u, int32_t* d_actions, float* d_logprobs, void* stream) {
-  if (!d_obs || !d_rows || !d_w1 || !d_b1 || !d_w2 || !d_u || !d_actions || !d_logprobs) return fail(BBX_E_ARG, "null argument");
-  if (batch < 1 || obs_rows < 1 || cols < 1 || hidden < 1) return fail(BBX_E_ARG, "bad policy shape");
-  {   // shapes the register-resident kernel is instantiated for (deepgroebner_amd/rollout.py falls back to torch otherwise)
-    const int cp4 = (cols + 3) / 4, upl = (hidden + 63) / 64;
-    const bool cols_ok = cp4 <= 8 || cp4 == 10 || cp4 == 12 || cp4 == 16;
-    const bool mfma_ok = hidden <= 256 && cols <= 64;        // matrix-core kernel (W1 in LDS)
-    if (!mfma_ok && (!cols_ok || upl > 4 || (upl > 2 && cp4 > 8))) return fail(BBX_E_UNSUPPORTED, "policy shape %d x %d is not built into the fused kernel", cols, hidden);
-  }
-  int lrc = bbx_launch_pmlp_act(d_obs, d_rows, batch, obs_rows, cols, d_w1, d_b1, d_w2, b2, hidden, d_u, d_actions, d_logprobs, (hipStream_t)stream);
+// prepared-weights geometry: the same constexpr rules as bbx_pmlp.h (k-steps 3 / 6 / 10 / 16 / 32, unit blocks 1 / 2 / 4 / 8)
+static int pmlp_ks(int cols) { const int ks = (cols + 1) / 2; return ks <= 3 ? 3 : ks <= 6 ? 6 : ks <= 10 ? 10 : ks <= 16 ? 16 : 32; }
+static int pmlp_nb(int hidden) { const int nb = (hidden + 31) / 32; return nb <= 1 ? 1 : nb <= 2 ? 2 : nb <= 4 ? 4 : 8; }
+
+int bbx_pmlp_prepared_floats(int cols, int hidden) {
+  if (cols < 1 || cols > 64 || hidden < 1 || hidden > 256) return fail(BBX_E_UNSUPPORTED, "policy shape %d x %d is not built into the policy kernel", cols, hidden);
+  return (2 * pmlp_ks(cols) + 2) * 32 * pmlp_nb(hidden) + 4;
+}
+
+int bbx_pmlp_prepare(const float* d_w1, const float* d_b1, const float* d_w2, float b2, int cols, int hidden, float* d_prepared, void* stream) {
+  if (!d_w1 || !d_b1 || !d_w2 || !d_prepared) return fail(BBX_E_ARG, "null argument");
+  if (bbx_pmlp_prepared_floats(cols, hidden) < 0) return BBX_E_UNSUPPORTED;
+  int lrc = bbx_launch_pmlp_prepare(d_w1, d_b1, d_w2, b2, cols, hidden, d_prepared, (hipStream_t)stream);
   if (lrc) return fail(BBX_E_DEVICE, "policy launch failed: %s", hipGetErrorString((hipError_t)lrc));
   return BBX_OK;
 }
 
-int bbx_policy_step_device(bbx_batch* b, const float* d_w1, const float* d_b1, const float* d_w2, float b2, int hidden, const float* d_u,
-                           int32_t* d_actions, float* d_logprobs, double* d_rewards, uint8_t* d_dones, int32_t* d_rows, int32_t* d_obs,
-                           int obs_rows, int obs_fill, void* stream) {
-  if (!b || !d_w1 || !d_b1 || !d_w2 || !d_u || !d_actions || !d_logprobs || !d_rows || !d_obs) return fail(BBX_E_ARG, "null argument");
-  if (obs_rows < 1 || hidden < 1) return fail(BBX_E_ARG, "bad policy shape");
+int bbx_pmlp_act(const int32_t* d_obs, const int32_t* d_rows, int batch, int obs_rows, int cols, const float* d_prepared, int hidden,
+                 const float* d_u, int32_t* d_actions, float* d_logprobs, void* stream) {
+  if (!d_obs || !d_rows || !d_prepared || !d_u || !d_actions || !d_logprobs) return fail(BBX_E_ARG, "null argument");
+  if (batch < 1 || obs_rows < 1) return fail(BBX_E_ARG, "bad policy shape");
+  if (bbx_pmlp_prepared_floats(cols, hidden) < 0) return BBX_E_UNSUPPORTED;
+  int lrc = bbx_launch_pmlp_act(d_obs, d_rows, batch, obs_rows, cols, d_prepared, hidden, d_u, d_actions, d_logprobs, (hipStream_t)stream);
+  if (lrc) return fail(BBX_E_DEVICE, "policy launch failed: %s", hipGetErrorString((hipError_t)lrc));
+  return BBX_OK;
+}
+
+int bbx_policy_step_device(bbx_batch* b, const float* d_prepared, int hidden, const float* d_u, int32_t* d_actions, float* d_logprobs,
+                           double* d_rewards, uint8_t* d_dones, int32_t* d_rows, int32_t* d_obs, int obs_rows, int obs_fill, void* stream) {
+  if (!b || !d_prepared || !d_u || !d_actions || !d_logprobs || !d_rows || !d_obs) return fail(BBX_E_ARG, "null argument");
+  if (obs_rows < 1) return fail(BBX_E_ARG, "obs_rows must be positive");
   const int cols = 2 * b->nvars * b->k;
+  if (bbx_pmlp_prepared_floats(cols, hidden) < 0) return BBX_E_UNSUPPORTED;
   // one launch for policy + step where the step kernel has the policy built in (the register/LDS-resident class, lean
-  // variant, hidden layer of at most 128 units); everywhere else the two launches it replaces
-  const bool fused = b->fast && b->staged && !b->accounting && !(b->d_trace && b->trace_cap >= 1) && hidden <= 128 && cols <= 64 &&
-                     !getenv("BBX_NO_FUSED_POLICY");
+  // variant, 33..128 hidden units, at most 12 columns); everywhere else the two launches it replaces
+  const bool fused = b->fast && b->staged && !b->accounting && !(b->d_trace && b->trace_cap >= 1) && (pmlp_nb(hidden) == 2 || pmlp_nb(hidden) == 4) &&
+                     cols <= 12 && !getenv("BBX_NO_FUSED_POLICY");
   if (!fused) {
-    int rc = bbx_pmlp_act(d_obs, d_rows, b->B, obs_rows, cols, d_w1, d_b1, d_w2, b2, hidden, d_u, d_actions, d_logprobs, stream);
+    int rc = bbx_pmlp_act(d_obs, d_rows, b->B, obs_rows, cols, d_prepared, hidden, d_u, d_actions, d_logprobs, stream);
     if (rc) return rc;
     return step_device(b, d_actions, d_rewards, d_dones, d_rows, d_obs, obs_rows, obs_fill, stream, 1);
   }
   HIPCHK(hipSetDevice(b->device));
-  BbxPolicy pol{d_w1, d_b1, d_w2, b2, hidden, d_u, d_actions, d_logprobs};
+  BbxPolicy pol{d_prepared, hidden, d_u, d_actions, d_logprobs};
   BbxParams p; fill_params(b, &p);
   p.nsteps = 1; p.set_budget = 1; p.agent = BBX_AGENT_EXTERNAL; p.auto_reset = 1; p.actions = d_actions;   // (the follow-up pass reads them)
   p.rewards = d_rewards; p.dones = d_dones; p.rows = d_rows; p.obs = d_obs; p.obs_rows = obs_rows; p.obs_fill = obs_fill;

@@ -109,10 +109,10 @@ enum { BBX_AGENT_EXTERNAL = 0, BBX_AGENT_HASH = 1, BBX_AGENT_DEGREE = 2, BBX_AGE
 enum { BBX_ELIM_GM = 0, BBX_ELIM_LCM = 1, BBX_ELIM_NONE = 2 };
 enum { BBX_REW_ADDITIONS = 0, BBX_REW_REDUCTIONS = 1 };
 
-// one-hidden-layer PMLP policy (networks.py:49-95, 414-460) for the fused policy + step launch: device pointers
+// one-hidden-layer PMLP policy (networks.py:49-95, 414-460) for the policy + step launch: device pointers
 struct BbxPolicy {
-  const float* w1; const float* b1; const float* w2; float b2; int32_t hidden;   // w1 [cols][hidden], b1 / w2 [hidden]
-  const float* u;                 // [B] uniforms in [0, 1) for the inverse-CDF draw
+  const float* wp; int32_t hidden;     // prepared weights (bbx_pmlp_prepare) of a [cols] -> [hidden] -> 1 network
+  const float* u;                      // [B] uniforms in [0, 1) for the inverse-CDF draw
   int32_t* actions; float* logprobs;   // [B] outputs: the sampled row and its log-probability
 };
 struct BbxParams {

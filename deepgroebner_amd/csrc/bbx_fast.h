@@ -712,12 +712,12 @@ __global__ __launch_bounds__(256) void bbx_fast_headline_kernel(BbxFastParams p)
 // after the other; a vector step costs one kernel's launch, ramp and drain instead of two.  The struct starts with the
 // step parameters: f_cold_params() reads them at offset 0 of the kernel arguments.
 struct BbxFastPolicyParams { BbxFastParams f; BbxPolicy pol; };
-template <int NB>
+template <int NB, int KS>
 __global__ __launch_bounds__(256, 4) void bbx_fast_policy_kernel(BbxFastPolicyParams q) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int env = blockIdx.x * (blockDim.x / WAVE) + (int)(threadIdx.x / WAVE);
-  const int action = pmlp_act_wave<NB>(smem, env, env < q.f.B, q.f.obs, q.f.rows, q.f.obs_rows, 2 * q.f.k * q.f.nvars, q.pol.w1, q.pol.b1, q.pol.w2,
-                                       q.pol.b2, q.pol.hidden, q.pol.u, q.pol.actions, q.pol.logprobs);
+  const int action = pmlp_act_wave<NB, KS>(smem, env, env < q.f.B, q.f.obs, q.f.rows, q.f.obs_rows, 2 * q.f.k * q.f.nvars, q.pol.wp, q.pol.u,
+                                           q.pol.actions, q.pol.logprobs);
   __syncthreads();                                     // the policy's LDS scratch becomes the step's state
   fast_body<false, false>(q.f, smem, action);
 }

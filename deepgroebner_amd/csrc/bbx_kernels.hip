@@ -1423,30 +1423,21 @@ extern "C" int bbx_launch_gather_hdr(const char* recs, uint32_t rec_bytes, int B
   return (int)hipGetLastError();
 }
 
-extern "C" int bbx_launch_pmlp_act(const int32_t* obs, const int32_t* rows, int B, int obs_rows, int cols, const float* w1, const float* b1,
-                                   const float* w2, float b2, int hidden, const float* u, int32_t* actions, float* logprobs, hipStream_t stream) {
-  const int waves = 4, cp4 = (cols + 3) / 4, upl = (hidden + WAVE - 1) / WAVE;
-  if (hidden <= 256 && cols <= 64 && !getenv("BBX_PMLP_VALU")) {     // matrix-core kernel: W1 in LDS, up to 8 unit blocks
-    const int nb = (hidden + 31) / 32;
-    const size_t ml = pmlp_lds_bytes(nb <= 1 ? 1 : nb <= 2 ? 2 : nb <= 4 ? 4 : 8, cols, waves);
-#define BBX_PMLP_MFMA(N) hipLaunchKernelGGL((bbx_pmlp_act_mfma_kernel<N>), dim3((B + waves - 1) / waves), dim3(waves * WAVE), ml, stream, obs, rows, B, \
-                                             obs_rows, cols, w1, b1, w2, b2, hidden, u, actions, logprobs)
-    if (nb <= 1) BBX_PMLP_MFMA(1); else if (nb <= 2) BBX_PMLP_MFMA(2); else if (nb <= 4) BBX_PMLP_MFMA(4); else BBX_PMLP_MFMA(8);
+extern "C" int bbx_launch_pmlp_prepare(const float* w1, const float* b1, const float* w2, float b2, int cols, int hidden, float* out, hipStream_t stream) {
+  hipLaunchKernelGGL(bbx_pmlp_prepare_kernel, dim3(16), dim3(256), 0, stream, w1, b1, w2, b2, cols, hidden, out);
+  return (int)hipGetLastError();
+}
+extern "C" int bbx_launch_pmlp_act(const int32_t* obs, const int32_t* rows, int B, int obs_rows, int cols, const float* wp, int hidden, const float* u,
+                                   int32_t* actions, float* logprobs, hipStream_t stream) {
+  const int waves = 4, nb = pmlp_nb_for(hidden), ks = pmlp_ks_for(cols);
+  const size_t ml = pmlp_lds_bytes(waves);
+#define BBX_PMLP_MFMA(N, K) hipLaunchKernelGGL((bbx_pmlp_act_mfma_kernel<N, K>), dim3((B + waves - 1) / waves), dim3(waves * WAVE), ml, stream, obs, rows, B, \
+                                                obs_rows, cols, wp, u, actions, logprobs)
+#define BBX_PMLP_MFMA_K(N) do { if (ks == 3) BBX_PMLP_MFMA(N, 3); else if (ks == 6) BBX_PMLP_MFMA(N, 6); else if (ks == 10) BBX_PMLP_MFMA(N, 10); \
+                                else if (ks == 16) BBX_PMLP_MFMA(N, 16); else BBX_PMLP_MFMA(N, 32); } while (0)
+  if (nb == 1) BBX_PMLP_MFMA_K(1); else if (nb == 2) BBX_PMLP_MFMA_K(2); else if (nb == 4) BBX_PMLP_MFMA_K(4); else BBX_PMLP_MFMA_K(8);
+#undef BBX_PMLP_MFMA_K
 #undef BBX_PMLP_MFMA
-    return (int)hipGetLastError();
-  }
-  const size_t lds = (size_t)waves * (PMLP_MAXROWS + WAVE * 4 * cp4) * sizeof(float);
-#define BBX_PMLP_GO(N, U) hipLaunchKernelGGL((bbx_pmlp_act_kernel<N, U>), dim3((B + waves - 1) / waves), dim3(waves * WAVE), lds, stream, obs, rows, B, \
-                                             obs_rows, cols, w1, b1, w2, b2, hidden, u, actions, logprobs)
-#define BBX_PMLP_CASE(N) case N: if (upl <= 1) BBX_PMLP_GO(N, 1); else if (upl <= 2) BBX_PMLP_GO(N, 2); else if (upl <= 4 && N <= 8) BBX_PMLP_GO(N, 4); \
-                                 else return (int)hipErrorInvalidValue; break;
-  switch (cp4) {
-    BBX_PMLP_CASE(1) BBX_PMLP_CASE(2) BBX_PMLP_CASE(3) BBX_PMLP_CASE(4) BBX_PMLP_CASE(5) BBX_PMLP_CASE(6) BBX_PMLP_CASE(7) BBX_PMLP_CASE(8)
-    BBX_PMLP_CASE(10) BBX_PMLP_CASE(12) BBX_PMLP_CASE(16)
-    default: return (int)hipErrorInvalidValue;
-  }
-#undef BBX_PMLP_CASE
-#undef BBX_PMLP_GO
   return (int)hipGetLastError();
 }
 
@@ -1549,10 +1540,12 @@ static int launch_fast(const BbxParams* p, int blocks, int threads, int envs_per
   if (p->policy) {                                         // policy + step in one launch (bbx_api.cpp checked the shapes)
     BbxFastPolicyParams q; q.f = f; q.pol = *p->policy;
     q.f.agent = BBX_AGENT_EXTERNAL; q.f.actions = q.pol.actions;
-    const int nb = (q.pol.hidden + 31) / 32, cols = 2 * f.k * f.nvars;
-    const size_t pl = pmlp_lds_bytes(nb <= 2 ? 2 : 4, cols, envs_per_block), ll = pl > lds ? pl : lds;
-    if (nb <= 2) hipLaunchKernelGGL((bbx_fast_policy_kernel<2>), dim3(blocks), dim3(threads), ll, stream, q);
-    else hipLaunchKernelGGL((bbx_fast_policy_kernel<4>), dim3(blocks), dim3(threads), ll, stream, q);
+    const int nb = pmlp_nb_for(q.pol.hidden), ks = pmlp_ks_for(2 * f.k * f.nvars);
+    const size_t pl = pmlp_lds_bytes(envs_per_block), ll = pl > lds ? pl : lds;
+    if (ks == 3) { if (nb == 2) hipLaunchKernelGGL((bbx_fast_policy_kernel<2, 3>), dim3(blocks), dim3(threads), ll, stream, q);
+                   else hipLaunchKernelGGL((bbx_fast_policy_kernel<4, 3>), dim3(blocks), dim3(threads), ll, stream, q); }
+    else { if (nb == 2) hipLaunchKernelGGL((bbx_fast_policy_kernel<2, 6>), dim3(blocks), dim3(threads), ll, stream, q);
+           else hipLaunchKernelGGL((bbx_fast_policy_kernel<4, 6>), dim3(blocks), dim3(threads), ll, stream, q); }
     return 0;
   }
   if (p->trace) hipLaunchKernelGGL((bbx_fast_kernel<true, true>), dim3(blocks), dim3(threads), lds, stream, f);

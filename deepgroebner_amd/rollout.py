@@ -70,35 +70,38 @@ class PMLPPolicy(torch.nn.Module):
         if len(self.embedding) == 1 and self.fused_ok(cols, self.embedding[0].out_features):
             w = self._fused_weights()
             s = (stream if stream is not None else torch.cuda.current_stream()).cuda_stream
-            _ffi.check(_ffi.lib().bbx_pmlp_act(C.c_void_p(obs.data_ptr()), C.c_void_p(rows.data_ptr()), B, R, cols, w["w1"], w["b1"], w["w2"],
-                                               w["b2"], w["hidden"], C.c_void_p(u.data_ptr()), C.c_void_p(actions.data_ptr()),
-                                               C.c_void_p(logprobs.data_ptr()), C.c_void_p(s)))
+            _ffi.check(_ffi.lib().bbx_pmlp_act(C.c_void_p(obs.data_ptr()), C.c_void_p(rows.data_ptr()), B, R, cols, w["prepared"], w["hidden"],
+                                               C.c_void_p(u.data_ptr()), C.c_void_p(actions.data_ptr()), C.c_void_p(logprobs.data_ptr()), C.c_void_p(s)))
             return actions, logprobs
         return self.act_torch(obs, rows, u, actions, logprobs)
 
     @staticmethod
     def fused_ok(cols, hidden):
-        """Shapes bbx_pmlp_act is built for: the matrix-core kernel (hidden <= 256, cols <= 64) or the register-resident
-        vector kernel."""
-        cp4, upl = (cols + 3) // 4, (hidden + 63) // 64
-        return (hidden <= 256 and cols <= 64) or ((cp4 <= 8 or cp4 in (10, 12, 16)) and upl <= 4 and not (upl > 2 and cp4 > 8))
+        """Shapes the policy kernel is built for (bbx_pmlp_prepared_floats >= 0)."""
+        return 1 <= hidden <= 256 and 1 <= cols <= 64
 
     def _fused_weights(self):
-        """The kernel's view of the weights ([cols][hidden] fp32 etc.), rebuilt only when a parameter changed (an
-        optimiser step bumps the tensors' version counters): no per-step transposes, no per-step host read of b2."""
+        """The kernels' view of the weights (bbx_pmlp_prepare: transposed, zero-padded to the tile sizes), rebuilt only when
+        a parameter changed (an optimiser step bumps the tensors' version counters): no per-step transposes, no per-step
+        host read of b2."""
         lin = self.embedding[0]
         key = tuple(p._version for p in self.parameters()) + tuple(p.data_ptr() for p in self.parameters())
         c = self.__dict__.get("_fused_cache")
         if c is None or c["key"] != key:
+            cols, hidden = lin.in_features, lin.out_features
             w1 = lin.weight.detach().t().contiguous().float()
             b1 = lin.bias.detach().contiguous().float()
             w2 = self.deciding.weight.detach().reshape(-1).contiguous().float()
-            c = {"key": key, "keep": (w1, b1, w2), "w1": C.c_void_p(w1.data_ptr()), "b1": C.c_void_p(b1.data_ptr()),
-                 "w2": C.c_void_p(w2.data_ptr()), "b2": C.c_float(float(self.deciding.bias.item())), "hidden": lin.out_features}
+            nfl = _ffi.lib().bbx_pmlp_prepared_floats(cols, hidden)
+            _ffi.check(min(nfl, 0))
+            prep = torch.empty(nfl, dtype=torch.float32, device=w1.device)
+            _ffi.check(_ffi.lib().bbx_pmlp_prepare(C.c_void_p(w1.data_ptr()), C.c_void_p(b1.data_ptr()), C.c_void_p(w2.data_ptr()),
+                                                   C.c_float(float(self.deciding.bias.item())), cols, hidden, C.c_void_p(prep.data_ptr()),
+                                                   C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+            c = {"key": key, "keep": prep, "prepared": C.c_void_p(prep.data_ptr()), "hidden": hidden}
             self.__dict__["_fused_cache"] = c
         return c
 
-    @torch.no_grad()
     def act_torch(self, obs, rows, u, actions=None, logprobs=None):
         """The same draw with torch ops (the reference of the fused kernel; any depth)."""
         lp = self.forward(obs)
@@ -215,8 +218,7 @@ def run_rollout(env, policy, nsteps, buffer=None, obs_rows=128, generator=None, 
                     buffer.states[t].copy_(obs)
                 buffer.rows[t].copy_(rows)
             if one_call:                                # policy + step: one library call (one kernel where the class has it)
-                env.policy_step_device(w["w1"], w["b1"], w["w2"], w["b2"].value, w["hidden"], u_all[i], act, logp, rew, done, rows, obs,
-                                       obs_rows, 2, stream.cuda_stream)          # (2: incremental padding)
+                env.policy_step_device(w["prepared"], w["hidden"], u_all[i], act, logp, rew, done, rows, obs, obs_rows, 2, stream.cuda_stream)   # (2: incremental padding)
             else:
                 policy.act(obs, rows, u_all[i], act, logp, stream)
                 env.step_device(act, rew, done, rows, obs, obs_rows, 2, stream.cuda_stream, auto_reset=True)

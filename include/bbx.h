@@ -160,20 +160,24 @@ int bbx_step_device_autoreset(bbx_batch* b, const int32_t* d_actions, double* d_
 /* ---- the consumer of the padded observation block: the reference's default policy network on the device ----------
  * ParallelMultilayerPerceptron([hidden]) (networks.py:522-571: ParallelEmbeddingLayer :49-95 with one dense relu layer,
  * ParallelDecidingLayer :414-460) evaluated on d_obs [batch, obs_rows, cols] over the d_rows[e] valid rows of each
- * environment (the -1 padding is masked out there, never read here), log-softmax over the rows and ONE action drawn by
- * inverse CDF from the uniform number d_u[e] in [0, 1) — the step of pg.py:451-503's run_episode that used to cross to
- * the host every step.  d_w1 [cols][hidden], d_b1 [hidden], d_w2 [hidden], b2: fp32 weights (the layout of
- * torch.nn.Linear(...).weight.t()).  d_actions[e] in [0, rows), d_logprobs[e] = its log-probability. */
-int bbx_pmlp_act(const int32_t* d_obs, const int32_t* d_rows, int batch, int obs_rows, int cols, const float* d_w1, const float* d_b1,
-                 const float* d_w2, float b2, int hidden, const float* d_u, int32_t* d_actions, float* d_logprobs, void* stream);
+ * environment (the -1 padding is masked out there, plays no part here), log-softmax over the rows and ONE action drawn
+ * by inverse CDF from the uniform number d_u[e] in [0, 1) — the step of pg.py:451-503's run_episode that used to cross to
+ * the host every step.  fp32, the hidden layer on the matrix cores (exact f32 MFMA); cols <= 64, hidden <= 256.
+ * The weights are handed over PREPARED: bbx_pmlp_prepare copies d_w1 [cols][hidden] (the layout of
+ * torch.nn.Linear(...).weight.t()), d_b1 [hidden], d_w2 [hidden], b2 into d_prepared (bbx_pmlp_prepared_floats(cols,
+ * hidden) floats, 16-byte aligned) zero-padded to the kernels' tile sizes; call it again whenever the weights change.
+ * d_actions[e] in [0, rows), d_logprobs[e] = its log-probability. */
+int bbx_pmlp_prepared_floats(int cols, int hidden);        /* < 0: shape not supported */
+int bbx_pmlp_prepare(const float* d_w1, const float* d_b1, const float* d_w2, float b2, int cols, int hidden, float* d_prepared, void* stream);
+int bbx_pmlp_act(const int32_t* d_obs, const int32_t* d_rows, int batch, int obs_rows, int cols, const float* d_prepared, int hidden,
+                 const float* d_u, int32_t* d_actions, float* d_logprobs, void* stream);
 /* One vector step with the policy in the loop: bbx_pmlp_act on the block the previous call left in d_obs / d_rows, then
  * bbx_step_device_autoreset with the sampled rows as actions, which rewrites d_obs / d_rows (the inner loop of
  * pg.py:451-503 run_episode, batched).  Where the step kernel has the policy built in (the register/LDS-resident class
- * with accounting off, hidden <= 128) this is ONE kernel launch; otherwise the two calls it stands for.  d_actions and
- * d_logprobs receive what was sampled; arguments as in those two calls. */
-int bbx_policy_step_device(bbx_batch* b, const float* d_w1, const float* d_b1, const float* d_w2, float b2, int hidden, const float* d_u,
-                           int32_t* d_actions, float* d_logprobs, double* d_rewards, uint8_t* d_dones, int32_t* d_rows, int32_t* d_obs,
-                           int obs_rows, int obs_fill, void* stream);
+ * with accounting off, 33..128 hidden units) this is ONE kernel launch; otherwise the two calls it stands for.
+ * d_actions and d_logprobs receive what was sampled; arguments as in those two calls. */
+int bbx_policy_step_device(bbx_batch* b, const float* d_prepared, int hidden, const float* d_u, int32_t* d_actions, float* d_logprobs,
+                           double* d_rewards, uint8_t* d_dones, int32_t* d_rows, int32_t* d_obs, int obs_rows, int obs_fill, void* stream);
 /* obs_every_step != 0 materialises the observation in d_obs after every step (what a device-side policy
  * would consume), otherwise only the state at the end of the rollout is written */
 int bbx_rollout_device(bbx_batch* b, int agent, int nsteps, int auto_reset, double* d_rewards, uint8_t* d_dones,

@@ -69,17 +69,12 @@ def test_pmlp_policy_masks_padding_like_the_reference():
 
 # ---- GPU ---------------------------------------------------------------------------------------------------------------------
 @pytest.mark.gpu
-@pytest.mark.parametrize("kernel", ["matrix", "vector"])
 @pytest.mark.parametrize("dist,k,hidden", [("3-20-10-weighted", 2, 128), ("5-10-5-uniform", 1, 64), ("3-20-10-uniform", 3, 200),
-                                           ("4-5-4-uniform", 1, 32), ("3-20-10-uniform", 1, 7)])
-def test_fused_policy_kernel_matches_torch_module(dist, k, hidden, kernel, monkeypatch):
-    """bbx_pmlp_act against the torch module: the matrix-core kernel (default: exact-f32 MFMA tiles) and the vector kernel
-    (BBX_PMLP_VALU=1, read at every launch), odd column counts and hidden sizes that do not fill a tile included."""
+                                           ("4-5-4-uniform", 1, 32), ("3-20-10-uniform", 1, 7), ("5-10-5-uniform", 3, 256)])
+def test_fused_policy_kernel_matches_torch_module(dist, k, hidden):
+    """bbx_pmlp_act (exact-f32 MFMA tiles over prepared weights) against the torch module: odd column counts, hidden sizes
+    that do not fill a tile, several unit-block groups and k-step counts."""
     import torch
-    if kernel == "vector":
-        monkeypatch.setenv("BBX_PMLP_VALU", "1")
-    else:
-        monkeypatch.delenv("BBX_PMLP_VALU", raising=False)
     from deepgroebner_amd import VecLeadMonomialsEnv
     from deepgroebner_amd.rollout import PMLPPolicy
     torch.manual_seed(1)
