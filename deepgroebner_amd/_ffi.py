@@ -70,6 +70,7 @@ SIGNATURES = {
     "bbx_pmlp_prepare": (C.c_int, [_vp, _vp, _vp, C.c_float, C.c_int, C.c_int, _vp, _vp]),
     "bbx_pmlp_act": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp]),
     "bbx_policy_step_device": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp]),
+    "bbx_policy_rollout_device": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_longlong, _vp]),
     "bbx_rollout_device": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "bbx_prefetch": (C.c_int, [_vp]),
     "bbx_accounting": (C.c_int, [_vp, C.c_int]),

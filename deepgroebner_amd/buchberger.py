@@ -247,6 +247,19 @@ class VecLeadMonomialsEnv:
         _ffi.check(_ffi.lib().bbx_policy_step_device(self._h, dp(prepared), int(hidden), dp(u), dp(actions), dp(logprobs), dp(rewards), dp(dones),
                                                     dp(rows), dp(obs), int(obs_rows), int(obs_fill), C.c_void_p(int(stream))))
 
+    def policy_rollout_device(self, prepared, hidden, nsteps, u, actions, logprobs, rewards=None, dones=None, rows=None, obs=None, obs_rows=0,
+                              obs_step_stride=0, stream=0):
+        """nsteps vector steps in one launch with the PMLP policy inside the step kernel (bbx_policy_rollout_device): all
+        per-step arrays are [nsteps, batch] device buffers; obs (optional) receives the observation of step t at element
+        offset t * obs_step_stride.  Raises BbxError(BBX_E_UNSUPPORTED) where the batch's kernel class has no built-in
+        policy."""
+        def dp(x):
+            if x is None or isinstance(x, C.c_void_p):
+                return x
+            return C.c_void_p(x.data_ptr() if hasattr(x, "data_ptr") else int(x))
+        _ffi.check(_ffi.lib().bbx_policy_rollout_device(self._h, dp(prepared), int(hidden), int(nsteps), dp(u), dp(actions), dp(logprobs), dp(rewards),
+                                                       dp(dones), dp(rows), dp(obs), int(obs_rows), int(obs_step_stride), C.c_void_p(int(stream))))
+
     def sync(self):
         _ffi.check(_ffi.lib().bbx_sync(self._h))
 

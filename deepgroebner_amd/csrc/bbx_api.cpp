@@ -136,6 +136,7 @@ struct bbx_batch {
   BbxParams last{};
   hipStream_t last_stream = 0;
   bool in_flight = false;
+  bool policy_rollout = false;           // the launch in flight is a policy rollout (bbx_policy_rollout_device)
   int staged = 0, fast = 0, envs_per_block = 4;
   int wide = 0;                       // > 0: waves per environment of the wide (one workgroup per environment) class
   int wide_terms = 0;                 // forced LDS capacity of the wide class (caps.wide_lds_terms), 0 = automatic
@@ -328,7 +329,9 @@ int enqueue(bbx_batch* b, const BbxParams& p0, bool resume, hipStream_t stream) 
   for (int i = 0; i < nk; i++) {
     if (resume) { p.set_budget = 0; p.pass = 1; }
     else if (i > 0) { p.set_budget = 0; p.pass = 1; }
-    if (resume || i > 0 || kinds[i] != 3) p.policy = nullptr;       // only the first pass of the fast class evaluates the policy
+    // a per-step policy call: only the first pass of the fast class evaluates the policy (the follow-up reads its actions);
+    // a policy rollout: the HBM-resident continuation pass has the policy too
+    if (p.policy && !(p.policy->rollout ? (!resume && (kinds[i] == 3 || kinds[i] == 0)) : (!resume && i == 0 && kinds[i] == 3))) p.policy = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     const bool timed = b->timing && i == 0 && kinds[i] != 2;   // the primary (dominant) kernel of the sequence
     if (timed) {
@@ -415,6 +418,11 @@ int finish(bbx_batch* b, hipStream_t stream) {
       }
       if (st == BBX_ST_GEN_ZERO) { if (err == BBX_OK) note(fail(BBX_E_GENERATOR, "random polynomial cancelled to zero (undefined in the reference)")); }
       else if (st == BBX_ST_GEN_FAIL) { if (err == BBX_OK) note(fail(BBX_E_GENERATOR, "failed to generate two distinct random monomials after 1000 trials")); }
+      else if ((st == BBX_ST_STARVED || st == BBX_ST_SPILL) && b->policy_rollout) {
+        // (the continuation pass runs right behind the first one; what is still unfinished here cannot be resumed: the
+        // policy arguments belonged to the caller's frame)
+        if (err == BBX_OK) note(fail(BBX_E_CAPACITY, "environment %d could not finish its policy rollout (%s)", e, status_name(st)));
+      }
       else if (st == BBX_ST_STARVED || st == BBX_ST_SPILL) again = true;
       else if (st == BBX_ST_BAD_ACTION) { if (err == BBX_OK) note(fail(BBX_E_ACTION, "environment %d: %s", e, status_name(st))); }
       else if (st != BBX_ST_OK && err == BBX_OK) {
@@ -444,6 +452,7 @@ int launch(bbx_batch* b, BbxParams& p, hipStream_t stream, bool obs_external = f
   int rc = fill_queues(b, 1, stream);
   if (rc) return rc;
   b->last = p;
+  b->policy_rollout = p.policy && p.policy->rollout;
   b->last.policy = nullptr;                 // (a host pointer of the caller's frame: never kept)
   b->last_stream = stream;
   b->in_flight = true;
@@ -1009,13 +1018,36 @@ int bbx_policy_step_device(bbx_batch* b, const float* d_prepared, int hidden, co
     return step_device(b, d_actions, d_rewards, d_dones, d_rows, d_obs, obs_rows, obs_fill, stream, 1);
   }
   HIPCHK(hipSetDevice(b->device));
-  BbxPolicy pol{d_prepared, hidden, d_u, d_actions, d_logprobs};
+  BbxPolicy pol{d_prepared, hidden, d_u, d_actions, d_logprobs, 0, nullptr, nullptr, nullptr, 0};
   BbxParams p; fill_params(b, &p);
   p.nsteps = 1; p.set_budget = 1; p.agent = BBX_AGENT_EXTERNAL; p.auto_reset = 1; p.actions = d_actions;   // (the follow-up pass reads them)
   p.rewards = d_rewards; p.dones = d_dones; p.rows = d_rows; p.obs = d_obs; p.obs_rows = obs_rows; p.obs_fill = obs_fill;
   p.trace = nullptr;
   p.policy = &pol;
   return launch(b, p, (hipStream_t)stream, true, true);
+}
+
+int bbx_policy_rollout_device(bbx_batch* b, const float* d_prepared, int hidden, int nsteps, const float* d_u, int32_t* d_actions,
+                              float* d_logprobs, double* d_rewards, uint8_t* d_dones, int32_t* d_rows, int32_t* d_obs, int obs_rows,
+                              long long obs_step_stride, void* stream) {
+  if (!b || !d_prepared || !d_u || !d_actions || !d_logprobs) return fail(BBX_E_ARG, "null argument");
+  if (nsteps < 1 || (d_obs && obs_rows < 1) || obs_step_stride < 0) return fail(BBX_E_ARG, "bad rollout arguments");
+  const int cols = 2 * b->nvars * b->k;
+  if (bbx_pmlp_prepared_floats(cols, hidden) < 0) return BBX_E_UNSUPPORTED;
+  if (!(b->fast && b->staged) || b->nvars != 3 || b->k != 2 || (pmlp_nb(hidden) != 2 && pmlp_nb(hidden) != 4))
+    return fail(BBX_E_UNSUPPORTED, "policy rollouts are built into the register/LDS-resident class only (<= 3 variables, binomial ideals, k = 2, "
+                                   "33..128 hidden units); drive this batch with bbx_policy_step_device");
+  if (b->accounting) return fail(BBX_E_UNSUPPORTED, "policy rollouts run the lean kernel: call bbx_accounting(b, 0) first");
+  if (b->d_trace && b->trace_cap >= 1) return fail(BBX_E_UNSUPPORTED, "policy rollouts are not traced");
+  if (d_obs && obs_step_stride != 0 && obs_step_stride < (long long)b->B * obs_rows * cols) return fail(BBX_E_ARG, "obs_step_stride smaller than one block");
+  HIPCHK(hipSetDevice(b->device));
+  BbxPolicy pol{d_prepared, hidden, d_u, d_actions, d_logprobs, 1, d_rewards, d_dones, d_rows, obs_step_stride};
+  BbxParams p; fill_params(b, &p);
+  p.nsteps = nsteps; p.set_budget = 1; p.agent = BBX_AGENT_EXTERNAL; p.auto_reset = 1;
+  p.obs = d_obs; p.obs_rows = obs_rows; p.obs_fill = 0;
+  p.trace = nullptr;
+  p.policy = &pol;
+  return launch(b, p, (hipStream_t)stream, d_obs != nullptr, true);
 }
 
 int bbx_rollout_device(bbx_batch* b, int agent, int nsteps, int auto_reset, double* d_rewards, uint8_t* d_dones,

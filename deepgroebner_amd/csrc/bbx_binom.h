@@ -188,11 +188,12 @@ __device__ bool bin_reset(BEnv<W>& e, const BbxParams& p, const BbxLayout& L, in
 
 // observation rows (buchberger.cpp:354-370, 391-394): one lane per monomial slot of the matrix
 template <int W, bool HASH>
-__device__ uint64_t bin_obs(const BEnv<W>& e, const BbxParams& p, int env, int nP, bool write, bool want_hash, char* stage_lds = nullptr) {
+__device__ uint64_t bin_obs(const BEnv<W>& e, const BbxParams& p, int env, int nP, bool write, bool want_hash, char* stage_lds = nullptr,
+                            size_t obs_off = 0) {
   const int lane = lane_id();
   const int n = p.nvars, k = p.k;
   const int cols = 2 * n * k;
-  int32_t* out = (write && p.obs) ? p.obs + (size_t)env * p.obs_rows * cols : nullptr;
+  int32_t* out = (write && p.obs) ? p.obs + obs_off + (size_t)env * p.obs_rows * cols : nullptr;
   const int rows = out ? (nP < p.obs_rows ? nP : p.obs_rows) : nP;
   // lane -> (row within the sweep, half, term) is fixed for the launch: no division inside the loop
   const int per_row = 2 * k;
@@ -285,8 +286,10 @@ __device__ uint64_t bin_poly_hash(const BEnv<W>& e, int g) {
   return wave_sum64(h);
 }
 
-template <int W, bool STAGED, bool TRACE>
-__device__ __forceinline__ void binom_body(const BbxParams& p, char* smem) {
+// POL > 0 (W = 2, HBM-resident instantiation only): the continuation of a policy rollout (fast_body POL, bbx_fast.h) for
+// environments that outgrew the register/LDS-resident class — the same per-step protocol, rows gathered from the record
+template <int W, bool STAGED, bool TRACE, int POL = 0>
+__device__ __forceinline__ void binom_body(const BbxParams& p, char* smem, const BbxPolicy* pol = nullptr) {
   const int lane = lane_id();
   const int wave_in_block = uni((int)(threadIdx.x / WAVE));
   const int env = blockIdx.x * (blockDim.x / WAVE) + wave_in_block;
@@ -348,6 +351,35 @@ __device__ __forceinline__ void binom_body(const BbxParams& p, char* smem) {
     BSTAMP(0);
     // ---- choose the pair ------------------------------------------------------------------------
     int action;
+    int pol_tt = 0;
+    if constexpr (POL > 0) {
+      pol_tt = uni(p.nsteps - budget);                       // (a continuation: the budget carries on from the first pass)
+      const size_t tb = (size_t)pol_tt * (size_t)p.B + (size_t)env;
+      const float uu = pol->u[tb];
+      if (p.obs) { bin_obs<W, false>(e, p, env, nP, true, false, nullptr, (size_t)pol_tt * (size_t)pol->obs_tstride); obs_trunc |= nP > p.obs_rows ? 1 : 0; }
+      if (lane == 0 && pol->rows_t) pol->rows_t[tb] = nP;
+      int n = nP < PMLP_MAXROWS ? nP : PMLP_MAXROWS;
+      if (p.obs) n = n < p.obs_rows ? n : p.obs_rows;
+      const float* wp = pol->wp;
+      const int plr = lane & 31, plk = lane >> 5;
+      float* lg = (float*)peel_lds;                          // (the update's scratch is idle here: PMLP_MAXROWS floats)
+      const float b2 = wp[(size_t)(2 * 6 + 2) * 32 * POL];
+      for (int r0 = 0; r0 < n; r0 += 32) {
+        const int r = r0 + plr;
+        const uint32_t prw = r < n ? e.pairs[r] : 0u;
+        const Mono<W> a0 = e.lm[prw & 0xffffu], a1 = e.tm[prw & 0xffffu], c0 = e.lm[prw >> 16], c1 = e.tm[prw >> 16];
+        const uint32_t ev[6] = {plk ? a0.w[0] >> 16 : a0.w[0] & 0xffffu,  plk ? a1.w[0] & 0xffffu : a0.w[1] & 0xffffu,
+                                plk ? a1.w[1] & 0xffffu : a1.w[0] >> 16,  plk ? c0.w[0] >> 16 : c0.w[0] & 0xffffu,
+                                plk ? c1.w[0] & 0xffffu : c0.w[1] & 0xffffu, plk ? c1.w[1] & 0xffffu : c1.w[0] >> 16};
+        float xa[6];
+#pragma unroll
+        for (int s2 = 0; s2 < 6; s2++) xa[s2] = (float)ev[s2];
+        const float logit = pmlp_tile<POL, 6, 1>(xa, wp, plr, plk);
+        if (plk == 0 && r < n) lg[r] = logit + b2;
+      }
+      wave_sync();
+      action = pmlp_sample(lg, n, env, uu, pol->actions + (size_t)pol_tt * (size_t)p.B, pol->logprobs + (size_t)pol_tt * (size_t)p.B);
+    } else
     if (p.agent == BBX_AGENT_EXTERNAL) action = p.actions[env];
     else if (p.agent == BBX_AGENT_HASH) action = (int)bbx_agent_action32(agent_seed, (uint32_t)t_agent, (uint32_t)nP);
     else if (p.agent == BBX_AGENT_FIRST) action = 0;
@@ -482,7 +514,14 @@ __device__ __forceinline__ void binom_body(const BbxParams& p, char* smem) {
     const bool done = nP == 0;
 
     BSTAMP(5);
-    if (p.obs_every_step && p.obs) { bin_obs<W, false>(e, p, env, nP, true, false, peel_lds); obs_trunc |= nP > p.obs_rows ? 1 : 0; }
+    if (POL == 0 && p.obs_every_step && p.obs) { bin_obs<W, false>(e, p, env, nP, true, false, peel_lds); obs_trunc |= nP > p.obs_rows ? 1 : 0; }
+    if constexpr (POL > 0) {
+      if (lane == 0) {
+        const size_t tb = (size_t)pol_tt * (size_t)p.B + (size_t)env;
+        if (pol->rewards_t) pol->rewards_t[tb] = reward;
+        if (pol->dones_t) pol->dones_t[tb] = done ? 1 : 0;
+      }
+    }
     BSTAMP(6);
     if (TRACE && tracing) {
       uint64_t oh = bin_obs<W, true>(e, p, env, nP, false, true);
@@ -506,7 +545,7 @@ __device__ __forceinline__ void binom_body(const BbxParams& p, char* smem) {
   if (lane == 0) for (int i = 0; i < 32; i++) if (bprof[i]) atomicAdd(&bbx_bin_prof_acc[i], bprof[i]);
 #endif
   const bool handoff = status == BBX_ST_SPILL;
-  if (p.obs && status == BBX_ST_OK) { bin_obs<W, false>(e, p, env, nP, true, false, peel_lds); obs_trunc |= nP > p.obs_rows ? 1 : 0; }
+  if (POL == 0 && p.obs && status == BBX_ST_OK) { bin_obs<W, false>(e, p, env, nP, true, false, peel_lds); obs_trunc |= nP > p.obs_rows ? 1 : 0; }
   if (STAGED && staged_in) {
     wave_sync();
     bstage_copy<W>(ge, e, nG, nP);
@@ -533,6 +572,11 @@ template <int W, bool STAGED, bool TRACE>
 __global__ __launch_bounds__(256, 4) void bbx_binom_kernel(BbxParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   binom_body<W, STAGED, TRACE>(p, smem);
+}
+template <int NB>
+__global__ __launch_bounds__(256, 4) void bbx_binom_policy_kernel(BbxParams p, BbxPolicy pol) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  binom_body<2, false, false, NB>(p, smem, &pol);
 }
 template <int W>
 __global__ __launch_bounds__(256) void bbx_binom_aux_kernel(BbxParams p) {

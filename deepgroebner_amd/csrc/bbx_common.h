@@ -114,6 +114,10 @@ struct BbxPolicy {
   const float* wp; int32_t hidden;     // prepared weights (bbx_pmlp_prepare) of a [cols] -> [hidden] -> 1 network
   const float* u;                      // [B] uniforms in [0, 1) for the inverse-CDF draw
   int32_t* actions; float* logprobs;   // [B] outputs: the sampled row and its log-probability
+  // policy ROLLOUT (nsteps > 1 inside one launch): the arrays above are [nsteps][B] and so are these; the observation
+  // the policy saw at step t goes to obs + t * obs_tstride (0: one block, overwritten every step)
+  int32_t rollout;
+  double* rewards_t; uint8_t* dones_t; int32_t* rows_t; long long obs_tstride;
 };
 struct BbxParams {
   char* recs;

@@ -91,6 +91,15 @@ __device__ __forceinline__ FColdParams f_cold_params() {
   return q;
 }
 
+// the policy kernels' arguments: the step parameters first (f_cold_params() reads them at offset 0), then the policy
+struct BbxFastPolicyParams { BbxFastParams f; BbxPolicy pol; };
+typedef const __attribute__((address_space(4))) BbxPolicy* FColdPolicy;
+__device__ __forceinline__ FColdPolicy f_cold_policy() {
+  const __attribute__((address_space(4))) BbxFastPolicyParams* q = (const __attribute__((address_space(4))) BbxFastPolicyParams*)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(q));
+  return &q->pol;
+}
+
 struct FastState {                 // reducer-order arrays, lane l <-> reducers l (A) and l + 64 (B)
   M2 slmA, slmB, stmA, stmB;
   uint2 sinA, sinB;                // .x = tc | (1/lc) << 16 ; .y = sugar | basis index << 16
@@ -108,7 +117,11 @@ struct FastState {                 // reducer-order arrays, lane l <-> reducers 
 // HL: the headline rollout shape as compile-time constants (random-hash agent, 3 variables, k = 2, the observation
 // written after every step without fill, auto-reset): no dispatch on launch parameters inside the step loop and fewer
 // scalar registers live across it.  The launcher picks it when the parameters say exactly that.
-template <bool TRACE, bool ACCT, bool PROF = false, bool HL = false>
+// POL > 0: a policy ROLLOUT (the kernel's arguments are BbxFastPolicyParams): every step starts by writing the
+// observation, evaluates the PMLP policy (POL unit blocks of 32, 3 variables and k = 2: 12 columns) on the rows — taken
+// straight from the pair list and the monomial arrays in LDS, exactly the values the observation holds — and samples
+// its action; per-step outputs go to [nsteps][B] arrays (BbxPolicy).  Waves never wait for each other between steps.
+template <bool TRACE, bool ACCT, bool PROF = false, bool HL = false, int POL = 0>
 __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem, int ext_action = -1) {
   unsigned long long prof_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long prof_last = PROF ? __builtin_amdgcn_s_memtime() : 0;
@@ -138,7 +151,7 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem, in
   uint2* g_gi = (uint2*)(grec_ + 128 + 40 * HG); uint2* g_si = (uint2*)(grec_ + 128 + 48 * HG); \
   uint32_t* g_pr = (uint32_t*)(grec_ + 128 + 56 * HG);
   // LDS working arrays at compile-time offsets
-  char* lbase = smem + wave_in_block * FLDS_BYTES;
+  char* lbase = smem + wave_in_block * (FLDS_BYTES + (POL > 0 ? 4 * FP : 0));   // (POL: + the logits of up to FP rows)
   M2* lm = (M2*)(lbase + FOFF_LM); M2* tm = (M2*)(lbase + FOFF_TM);
   uint2* gi = (uint2*)(lbase + FOFF_GI); uint32_t* pairs = (uint32_t*)(lbase + FOFF_PR);
   const int limG = p.lim_G < FG ? p.lim_G : FG, limP = p.lim_P < FP ? p.lim_P : FP;
@@ -182,7 +195,7 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem, in
   // (obs_fill == 1: unknown contents, so the first write pads the whole block), or — obs_fill == 2, the caller vouches
   // that block and rows[] still hold what the previous call left — everything beyond the row count written then
   int filled_to = (!HL && p.obs_fill == 2 && p.rows) ? uni(p.rows[env]) : 0x7fffffff;
-  const bool obs_step = HL ? true : (p.obs_every_step && p.obs);
+  const bool obs_step = HL ? true : (POL > 0 ? false : (p.obs_every_step && p.obs));
   const int per_row = 2 * kk;
   const int obs_row_bytes = 4 * per_row * n;
   // lane -> (row within a sweep, slot) of the observation matrix, fixed for the launch
@@ -198,6 +211,7 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem, in
   const int o3_row = lane >> 2, o3_hi = (lane >> 1) & 1;
   const char* o3_mono = lbase + ((lane & 1) ? FOFF_TM : FOFF_LM);
   int32_t* const o3_out = obs32 ? p.obs + (size_t)env * p.obs_rows * 12 + lane * 3 : nullptr;
+  size_t o3_toff = 0;                                    // POL: the step's slice of a [nsteps][B][rows][12] block
   auto write_obs32 = [&]() {
     const int rows = nP < p.obs_rows ? nP : p.obs_rows;
     for (int r0 = 0; r0 < rows; r0 += 32) {
@@ -206,8 +220,8 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem, in
       const uint32_t pa = oa ? pairs[ra] : 0u, pb = ob ? pairs[rb] : 0u;
       const uint32_t ga = o3_hi ? pa >> 16 : pa & 0xffffu, gb = o3_hi ? pb >> 16 : pb & 0xffffu;
       const M2 ma = *(const M2*)(o3_mono + ga * 8), mb = *(const M2*)(o3_mono + gb * 8);
-      if (oa) *(ObsI3*)(o3_out + r0 * 12) = ObsI3{(int32_t)(ma.w[0] & 0xffffu), (int32_t)(ma.w[0] >> 16), (int32_t)(ma.w[1] & 0xffffu)};
-      if (ob) *(ObsI3*)(o3_out + r0 * 12 + 192) = ObsI3{(int32_t)(mb.w[0] & 0xffffu), (int32_t)(mb.w[0] >> 16), (int32_t)(mb.w[1] & 0xffffu)};
+      if (oa) *(ObsI3*)(o3_out + o3_toff + r0 * 12) = ObsI3{(int32_t)(ma.w[0] & 0xffffu), (int32_t)(ma.w[0] >> 16), (int32_t)(ma.w[1] & 0xffffu)};
+      if (ob) *(ObsI3*)(o3_out + o3_toff + r0 * 12 + 192) = ObsI3{(int32_t)(mb.w[0] & 0xffffu), (int32_t)(mb.w[0] >> 16), (int32_t)(mb.w[1] & 0xffffu)};
     }
     if (obs_fill) {
       int32_t* out = p.obs + (size_t)env * p.obs_rows * 12;
@@ -472,6 +486,35 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem, in
 
     // ---- choose the pair -----------------------------------------------------------------------------------------
     int action;
+    int pol_tt = 0;
+    if constexpr (POL > 0) {
+      const FColdPolicy pol = f_cold_policy();
+      pol_tt = uni(p.nsteps - budget);                       // step of this launch (the budget was set to nsteps)
+      const size_t tb = (size_t)pol_tt * (size_t)p.B + (size_t)env;
+      const float uu = pol->u[tb];                           // (requested before the observation goes out)
+      if (p.obs) { o3_toff = (size_t)pol_tt * (size_t)pol->obs_tstride; write_obs32(); obs_trunc |= nP > p.obs_rows ? 1 : 0; }
+      if (lane == 0 && pol->rows_t) pol->rows_t[tb] = nP;
+      const float* wp = pol->wp;
+      const int plr = lane & 31, plk = lane >> 5;
+      float* lg = (float*)(lbase + FLDS_BYTES);
+      const float b2 = wp[(size_t)(2 * 6 + 2) * 32 * POL];
+      for (int r0 = 0; r0 < nP; r0 += 32) {
+        const int r = r0 + plr;
+        const uint32_t prw = r < nP ? pairs[r] : 0u;
+        const M2 a0 = lm[prw & 0xffffu], a1 = tm[prw & 0xffffu], c0 = lm[prw >> 16], c1 = tm[prw >> 16];
+        // row = [lm_i | tm_i | lm_j | tm_j] x (e0, e1, e2); my k-step operands are columns 2 s + (lane >> 5)
+        const uint32_t ev[6] = {plk ? a0.w[0] >> 16 : a0.w[0] & 0xffffu,  plk ? a1.w[0] & 0xffffu : a0.w[1] & 0xffffu,
+                                plk ? a1.w[1] & 0xffffu : a1.w[0] >> 16,  plk ? c0.w[0] >> 16 : c0.w[0] & 0xffffu,
+                                plk ? c1.w[0] & 0xffffu : c0.w[1] & 0xffffu, plk ? c1.w[1] & 0xffffu : c1.w[0] >> 16};
+        float xa[6];
+#pragma unroll
+        for (int s2 = 0; s2 < 6; s2++) xa[s2] = (float)ev[s2];
+        const float logit = pmlp_tile<POL, 6, 1>(xa, wp, plr, plk);
+        if (plk == 0 && r < nP) lg[r] = logit + b2;
+      }
+      wave_sync();
+      action = pmlp_sample(lg, nP, env, uu, pol->actions + (size_t)pol_tt * (size_t)p.B, pol->logprobs + (size_t)pol_tt * (size_t)p.B);
+    } else
     if (agent == BBX_AGENT_HASH) action = (int)(((uint64_t)f_readlane(hv, t_agent & 63) * (uint32_t)nP) >> 32);   // bbx_agent_action32
     else if (agent == BBX_AGENT_EXTERNAL) action = ext_action >= 0 ? ext_action : uni(f_cold_params()->actions[env]);
     else if (agent == BBX_AGENT_FIRST) action = 0;
@@ -656,6 +699,14 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem, in
         tr.obs_hash = oh; tr.pairs_hash = ph; tr.newpoly_hash = nh;
       }
     }
+    if constexpr (POL > 0) {
+      const FColdPolicy pol = f_cold_policy();
+      if (lane == 0) {
+        const size_t tb = (size_t)pol_tt * (size_t)p.B + (size_t)env;
+        if (pol->rewards_t) pol->rewards_t[tb] = p.rewards_mode == BBX_REW_ADDITIONS ? (-1.0 - (double)nred) : -1.0;
+        if (pol->dones_t) pol->dones_t[tb] = done ? 1 : 0;
+      }
+    }
     budget--; if (TRACE) trace_pos++;
     done_last = done ? 1 : 0;
     if (done) { episodes++; if (auto_reset) need_reset = 1; }
@@ -665,7 +716,7 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem, in
   if (PROF && cz->prof && lane == 0) for (int i = 0; i < 8; i++) cz->prof[(size_t)env * 8 + i] = prof_sum[i];
 
   const bool handoff = status == BBX_ST_SPILL;
-  if (p.obs && status == BBX_ST_OK) { if (obs32) write_obs32(); else write_obs(true, false); obs_trunc |= nP > p.obs_rows ? 1 : 0; }
+  if (POL == 0 && p.obs && status == BBX_ST_OK) { if (obs32) write_obs32(); else write_obs(true, false); obs_trunc |= nP > p.obs_rows ? 1 : 0; }
   if (staged_in) {                                                   // write the live prefixes back to the HBM record
     wave_sync();
     F_HBM_PTRS(cz)
@@ -711,7 +762,6 @@ __global__ __launch_bounds__(256) void bbx_fast_headline_kernel(BbxFastParams p)
 // then takes the step with the sampled row as its action.  The two phases use the same registers and the same LDS one
 // after the other; a vector step costs one kernel's launch, ramp and drain instead of two.  The struct starts with the
 // step parameters: f_cold_params() reads them at offset 0 of the kernel arguments.
-struct BbxFastPolicyParams { BbxFastParams f; BbxPolicy pol; };
 template <int NB, int KS>
 __global__ __launch_bounds__(256, 4) void bbx_fast_policy_kernel(BbxFastPolicyParams q) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -720,6 +770,12 @@ __global__ __launch_bounds__(256, 4) void bbx_fast_policy_kernel(BbxFastPolicyPa
                                            q.pol.actions, q.pol.logprobs);
   __syncthreads();                                     // the policy's LDS scratch becomes the step's state
   fast_body<false, false>(q.f, smem, action);
+}
+// policy rollout: nsteps steps per launch with the policy inside the step loop (fast_body POL)
+template <int NB>
+__global__ __launch_bounds__(256, 4) void bbx_fast_policy_rollout_kernel(BbxFastPolicyParams q) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  fast_body<false, false, false, false, NB>(q.f, smem);
 }
 #ifdef BBX_PROF_BUILD
 // diagnostic build with s_memtime stamps between the phases of a step (never timed, never shipped as a result)

@@ -1290,8 +1290,8 @@ __global__ __launch_bounds__(256) void bbx_step_prof_kernel(BbxParams p, unsigne
 
 #endif
 
-#include "bbx_binom.h"
 #include "bbx_pmlp.h"
+#include "bbx_binom.h"
 #include "bbx_fast.h"
 #include "bbx_wide.h"
 
@@ -1495,6 +1495,14 @@ static int launch_w(const BbxParams* p, int kind, int blocks, int threads, size_
 #endif
   if (binom) {
     lds = (size_t)(threads / WAVE) * update_lds_bytes<W>();           // Gebauer-Moeller peel scratch, one per wave
+    if constexpr (W == 2) {
+      if (p->policy && p->policy->rollout) {               // the continuation pass of a policy rollout
+        BbxParams q = *p; q.policy = nullptr; q.actions = nullptr; q.rewards = nullptr; q.dones = nullptr; q.rows = nullptr; q.obs_every_step = 0;
+        if (pmlp_nb_for(p->policy->hidden) == 2) hipLaunchKernelGGL((bbx_binom_policy_kernel<2>), dim3(blocks), dim3(threads), lds, stream, q, *p->policy);
+        else hipLaunchKernelGGL((bbx_binom_policy_kernel<4>), dim3(blocks), dim3(threads), lds, stream, q, *p->policy);
+        return 0;
+      }
+    }
     if (trace) BBX_LAUNCH((bbx_binom_kernel<W, false, true>)); else BBX_LAUNCH((bbx_binom_kernel<W, false, false>));
   } else {
     lds = (size_t)(threads / WAVE) * merge_lds_bytes<W>();          // merge-path tile scratch, one per wave
@@ -1540,6 +1548,13 @@ static int launch_fast(const BbxParams* p, int blocks, int threads, int envs_per
   if (p->policy) {                                         // policy + step in one launch (bbx_api.cpp checked the shapes)
     BbxFastPolicyParams q; q.f = f; q.pol = *p->policy;
     q.f.agent = BBX_AGENT_EXTERNAL; q.f.actions = q.pol.actions;
+    if (q.pol.rollout) {                                   // nsteps steps, the policy inside the step loop (3 variables, k = 2)
+      q.f.actions = nullptr; q.f.rewards = nullptr; q.f.dones = nullptr; q.f.rows = nullptr; q.f.obs_every_step = 0; q.f.auto_reset = 1;
+      const size_t rl = (size_t)envs_per_block * (FLDS_BYTES + 4 * FP);
+      if (pmlp_nb_for(q.pol.hidden) == 2) hipLaunchKernelGGL((bbx_fast_policy_rollout_kernel<2>), dim3(blocks), dim3(threads), rl, stream, q);
+      else hipLaunchKernelGGL((bbx_fast_policy_rollout_kernel<4>), dim3(blocks), dim3(threads), rl, stream, q);
+      return 0;
+    }
     const int nb = pmlp_nb_for(q.pol.hidden), ks = pmlp_ks_for(2 * f.k * f.nvars);
     const size_t pl = pmlp_lds_bytes(envs_per_block), ll = pl > lds ? pl : lds;
     if (ks == 3) { if (nb == 2) hipLaunchKernelGGL((bbx_fast_policy_kernel<2, 3>), dim3(blocks), dim3(threads), ll, stream, q);

@@ -92,23 +92,62 @@ __global__ void bbx_pmlp_prepare_kernel(const float* __restrict__ w1, const floa
     out[i] = v;
   }
 }
+// one tile: the logit (without b2) of row (lane & 31) from the lane's B operands xa[]; G unit blocks in flight together
+// (registers: 32 G + G KS)
+template <int NB, int KS, int G>
+__device__ __forceinline__ float pmlp_tile(const float (&xa)[KS], const float* __restrict__ wp, int lr, int lk) {
+  constexpr int HP = 32 * NB;
+  const float* b1p = wp + (size_t)2 * KS * HP;
+  const float* w2p = b1p + HP;
+  const float* wl = wp + (size_t)lk * HP + lr;              // my A-operand column: + 2 s HP + 32 nb
+  float part = 0.f;
+#pragma clang loop unroll(disable)
+  for (int g0 = 0; g0 < NB; g0 += G) {
+    bbx_f32x16 acc[G];
+    bbx_f32x4 wv[G][4];
+    float wa[G][KS];
+#pragma unroll
+    for (int j = 0; j < G; j++) {
+      const int ub = (g0 + j) * 32 + 4 * lk;                 // + (v & 3) + 8 (v >> 2): the units of my accumulator registers
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const bbx_f32x4 bq = *(const bbx_f32x4*)(b1p + ub + 8 * q);
+        acc[j][4 * q] = bq.x; acc[j][4 * q + 1] = bq.y; acc[j][4 * q + 2] = bq.z; acc[j][4 * q + 3] = bq.w;
+        wv[j][q] = *(const bbx_f32x4*)(w2p + ub + 8 * q);
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < KS; s2++) wa[j][s2] = wl[(size_t)2 * s2 * HP + (g0 + j) * 32];
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < KS; s2++)
+#pragma unroll
+      for (int j = 0; j < G; j++) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[j][s2], xa[s2], acc[j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < G; j++)
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const bbx_f32x4 w = wv[j][q];
+        const float h0 = acc[j][4 * q], h1 = acc[j][4 * q + 1], h2 = acc[j][4 * q + 2], h3 = acc[j][4 * q + 3];
+        part = fmaf(h0 > 0.f ? h0 : 0.f, w.x, part); part = fmaf(h1 > 0.f ? h1 : 0.f, w.y, part);
+        part = fmaf(h2 > 0.f ? h2 : 0.f, w.z, part); part = fmaf(h3 > 0.f ? h3 : 0.f, w.w, part);
+      }
+  }
+  return part + __shfl_xor(part, 32, WAVE);                  // the other half of the row's units
+}
 template <int NB, int KS>
 __device__ __forceinline__ int pmlp_act_wave(char* smem, int env, bool live, const int32_t* __restrict__ obs, const int32_t* __restrict__ rows,
                                              int obs_rows, int cols, const float* __restrict__ wp, const float* __restrict__ u,
                                              int32_t* __restrict__ actions, float* __restrict__ logprobs) {
   constexpr int HP = 32 * NB;
-  constexpr int G = (KS <= 10 ? 2 : 1) < NB ? (KS <= 10 ? 2 : 1) : NB;   // unit blocks in flight together (register budget: 32 G + G KS + KS)
+  constexpr int G = (KS <= 10 ? 2 : 1) < NB ? (KS <= 10 ? 2 : 1) : NB;   // unit blocks in flight together
   const int lane = lane_id(), wave = uni((int)(threadIdx.x / WAVE));
   float* lg = (float*)smem + (size_t)wave * PMLP_MAXROWS;   // logits of this wave's environment
   if (!live) return 0;
   const int lr = lane & 31, lk = lane >> 5;
   const int nraw = rows[env];
   const float uu = u[env];
-  const float* b1p = wp + (size_t)2 * KS * HP;
-  const float* w2p = b1p + HP;
-  const float b2 = w2p[HP];
+  const float b2 = wp[(size_t)(2 * KS + 2) * HP];
   const int32_t* ob = obs + (size_t)env * obs_rows * cols;
-  const float* wl = wp + (size_t)lk * HP + lr;              // my A-operand column: + 2 s HP + 32 nb
   int n = 0;
   for (int r0 = 0;; r0 += 32) {
     int r = r0 + lr; r = r < obs_rows ? r : obs_rows - 1;    // inside the block whatever the row count is
@@ -120,41 +159,9 @@ __device__ __forceinline__ int pmlp_act_wave(char* smem, int env, bool live, con
       const int32_t xi = xr[k < cols ? k : 0];
       xa[s2] = k < cols ? (float)xi : 0.f;
     }
-    float part = 0.f;
-#pragma clang loop unroll(disable)
-    for (int g0 = 0; g0 < NB; g0 += G) {
-      bbx_f32x16 acc[G];
-      bbx_f32x4 wv[G][4];
-      float wa[G][KS];
-#pragma unroll
-      for (int j = 0; j < G; j++) {
-        const int ub = (g0 + j) * 32 + 4 * lk;               // + (v & 3) + 8 (v >> 2): the units of my accumulator registers
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-          const bbx_f32x4 bq = *(const bbx_f32x4*)(b1p + ub + 8 * q);
-          acc[j][4 * q] = bq.x; acc[j][4 * q + 1] = bq.y; acc[j][4 * q + 2] = bq.z; acc[j][4 * q + 3] = bq.w;
-          wv[j][q] = *(const bbx_f32x4*)(w2p + ub + 8 * q);
-        }
-#pragma unroll
-        for (int s2 = 0; s2 < KS; s2++) wa[j][s2] = wl[(size_t)2 * s2 * HP + (g0 + j) * 32];
-      }
-#pragma unroll
-      for (int s2 = 0; s2 < KS; s2++)
-#pragma unroll
-        for (int j = 0; j < G; j++) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[j][s2], xa[s2], acc[j], 0, 0, 0);
-#pragma unroll
-      for (int j = 0; j < G; j++)
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-          const bbx_f32x4 w = wv[j][q];
-          const float h0 = acc[j][4 * q], h1 = acc[j][4 * q + 1], h2 = acc[j][4 * q + 2], h3 = acc[j][4 * q + 3];
-          part = fmaf(h0 > 0.f ? h0 : 0.f, w.x, part); part = fmaf(h1 > 0.f ? h1 : 0.f, w.y, part);
-          part = fmaf(h2 > 0.f ? h2 : 0.f, w.z, part); part = fmaf(h3 > 0.f ? h3 : 0.f, w.w, part);
-        }
-    }
-    part += __shfl_xor(part, 32, WAVE);                      // the other half of the row's units
+    const float logit = pmlp_tile<NB, KS, G>(xa, wp, lr, lk);
     if (r0 == 0) { n = uni(nraw); n = n < obs_rows ? n : obs_rows; n = n < PMLP_MAXROWS ? n : PMLP_MAXROWS; }
-    if (lk == 0 && r0 + lr < n) lg[r0 + lr] = part + b2;
+    if (lk == 0 && r0 + lr < n) lg[r0 + lr] = logit + b2;
     if (r0 + 32 >= n) break;
   }
   if (n <= 0) { if (lane == 0) { actions[env] = 0; logprobs[env] = 0.f; } return 0; }

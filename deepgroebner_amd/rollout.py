@@ -187,6 +187,44 @@ class DeviceTrajectoryBuffer:
 
 
 @torch.no_grad()
+def run_rollout_fused(env, policy, nsteps, buffer=None, obs_rows=256, generator=None, chunk=64):
+    """run_rollout with the policy INSIDE the step kernel (bbx_policy_rollout_device): `chunk` vector steps per launch,
+    environments never wait for each other between steps.  Per-step outputs land in the trajectory buffer's own arrays
+    (no copies).  Raises BbxError (BBX_E_UNSUPPORTED) where the batch's kernel class has no built-in policy — callers
+    fall back to run_rollout.  Returns (total reward per environment, finished episodes) like run_rollout."""
+    B, cols = env.batch, env.cols
+    dev = torch.device("cuda", torch.cuda.current_device())
+    stream = torch.cuda.current_stream()
+    w = policy._fused_weights()
+    keep_states = buffer is not None and buffer.states is not None
+    if keep_states:
+        obs_rows = buffer.states.shape[2]
+    if buffer is None:
+        act = torch.empty((chunk, B), dtype=torch.int32, device=dev); logp = torch.empty((chunk, B), dtype=torch.float32, device=dev)
+    obs1 = None if keep_states else torch.empty((B, obs_rows, cols), dtype=torch.int32, device=dev)
+    st0 = env.stats()
+    for t0 in range(0, nsteps, chunk):
+        n = min(chunk, nsteps - t0)
+        u = torch.rand((n, B), device=dev, generator=generator)
+        if buffer is not None:
+            t = buffer.t
+            obs = buffer.states[t:t + n] if keep_states else obs1
+            if keep_states:
+                obs.fill_(-1)                           # the kernel writes the live rows only; the rest is the reference's padding
+            env.policy_rollout_device(w["prepared"], w["hidden"], n, u, buffer.actions[t:t + n], buffer.logprobs[t:t + n], buffer.rewards[t:t + n],
+                                      buffer.dones[t:t + n], buffer.rows[t:t + n], obs, obs_rows, B * obs_rows * cols if keep_states else 0,
+                                      stream.cuda_stream)
+            buffer.t += n
+        else:
+            env.policy_rollout_device(w["prepared"], w["hidden"], n, u, act, logp, None, None, None, obs1, obs_rows, 0, stream.cuda_stream)
+        env.sync()
+    d = env.stats() - st0
+    total = torch.tensor(-d[:, 1].astype(np.float64), device=dev)
+    episodes = torch.tensor(d[:, 2], device=dev)
+    return total, episodes
+
+
+@torch.no_grad()
 def run_rollout(env, policy, nsteps, buffer=None, obs_rows=128, generator=None, sync_every=64):
     """nsteps vector steps of `env` (a VecLeadMonomialsEnv already reset) under `policy`, everything on the device:
     observation block -> policy.act (log-softmax + inverse-CDF draw) -> bbx_step_device_autoreset -> next block.  The

@@ -178,6 +178,19 @@ int bbx_pmlp_act(const int32_t* d_obs, const int32_t* d_rows, int batch, int obs
  * d_actions and d_logprobs receive what was sampled; arguments as in those two calls. */
 int bbx_policy_step_device(bbx_batch* b, const float* d_prepared, int hidden, const float* d_u, int32_t* d_actions, float* d_logprobs,
                            double* d_rewards, uint8_t* d_dones, int32_t* d_rows, int32_t* d_obs, int obs_rows, int obs_fill, void* stream);
+/* nsteps vector steps in ONE launch with the policy inside the step kernel (pg.py:451-503 run_episode for a whole batch, no
+ * host in the loop and no waiting between environments): at step t every environment writes the observation the policy
+ * is about to see to d_obs + t * obs_step_stride (int32 elements; 0 = a single block overwritten every step; rows beyond
+ * d_rows[t][e] are not written) and its row count to d_rows[t][e], evaluates the policy, draws the action with d_u[t][e]
+ * -> d_actions[t][e], d_logprobs[t][e], takes the step -> d_rewards[t][e], d_dones[t][e]; finished episodes restart
+ * (auto-reset).  All per-step arrays are [nsteps][batch]; d_rewards / d_dones / d_rows / d_obs may be null.  Built into the
+ * register/LDS-resident class (<= 3 variables, binomial ideals, k = 2, accounting off, 33..128 hidden units); other
+ * batches: BBX_E_UNSUPPORTED (use bbx_policy_step_device).  Environments that outgrow that class inside the rollout
+ * (|G| > 128 or |P| > 256) are continued, policy included, by the HBM-resident kernel launched right behind.
+ * Asynchronous like bbx_rollout_device. */
+int bbx_policy_rollout_device(bbx_batch* b, const float* d_prepared, int hidden, int nsteps, const float* d_u, int32_t* d_actions,
+                              float* d_logprobs, double* d_rewards, uint8_t* d_dones, int32_t* d_rows, int32_t* d_obs, int obs_rows,
+                              long long obs_step_stride, void* stream);
 /* obs_every_step != 0 materialises the observation in d_obs after every step (what a device-side policy
  * would consume), otherwise only the state at the end of the rollout is written */
 int bbx_rollout_device(bbx_batch* b, int agent, int nsteps, int auto_reset, double* d_rewards, uint8_t* d_dones,

@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 from deepgroebner_amd import VecLeadMonomialsEnv
-from deepgroebner_amd.rollout import DeviceTrajectoryBuffer, PMLPPolicy, run_rollout
+from deepgroebner_amd.rollout import DeviceTrajectoryBuffer, PMLPPolicy, run_rollout, run_rollout_fused
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--dist", default="3-20-10-weighted")
@@ -24,7 +24,10 @@ ap.add_argument("--k", type=int, default=2)
 ap.add_argument("--hidden", type=int, default=128)
 ap.add_argument("--obs-rows", type=int, default=128)
 ap.add_argument("--store", action="store_true", help="also record the trajectory (actions, rewards, log-probabilities, dones) on the device")
-ap.add_argument("--graph", action="store_true", help="capture the two-kernel step in a hipGraph")
+ap.add_argument("--per-step", action="store_true", help="one library call per vector step (bbx_policy_step_device) instead of the policy rollout "
+                                                       "kernel (bbx_policy_rollout_device: --chunk steps per launch, policy inside the step loop)")
+ap.add_argument("--chunk", type=int, default=64)
+ap.add_argument("--store-states", action="store_true", help="--store plus the observation block of every step")
 a = ap.parse_args()
 torch.manual_seed(0)
 B = a.batch
@@ -32,18 +35,25 @@ env = VecLeadMonomialsEnv(a.dist, batch=B, k=a.k)
 env.seed(np.arange(B) + 1000); env.reset()
 env.accounting(False)
 policy = PMLPPolicy(env.cols, [a.hidden]).cuda()
-run_rollout(env, policy, 300, obs_rows=a.obs_rows)                 # steady state + warm-up
+def go(nsteps, buf):
+    if a.per_step:
+        return run_rollout(env, policy, nsteps, buffer=buf, obs_rows=a.obs_rows)
+    return run_rollout_fused(env, policy, nsteps, buffer=buf, obs_rows=a.obs_rows, chunk=a.chunk)
+go(300, None)                                                      # steady state + warm-up
 st0 = env.stats()
-buf = DeviceTrajectoryBuffer(a.steps, B, obs_shape=None) if a.store else None
+store = a.store or a.store_states
+buf = DeviceTrajectoryBuffer(a.steps, B, obs_shape=(a.obs_rows, env.cols) if a.store_states else None) if store else None
 torch.cuda.synchronize()
 t0 = time.perf_counter()
-total, episodes = run_rollout(env, policy, a.steps, buffer=buf, obs_rows=a.obs_rows)
+total, episodes = go(a.steps, buf)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 st = env.stats()
 d = st - st0
 assert (d[:, 0] == a.steps).all() and (st[:, 4] == 0).all()
 assert int(episodes.sum()) == int(d[:, 2].sum()) and float(total.sum()) == -float(d[:, 1].sum())
-print(json.dumps({"dist": a.dist, "batch": B, "steps": a.steps, "policy": "PMLP([%d]) fused act kernel" % a.hidden, "store": bool(a.store),
+print(json.dumps({"dist": a.dist, "batch": B, "steps": a.steps, "policy": "PMLP([%d])" % a.hidden,
+                  "mode": "one call per step (bbx_policy_step_device)" if a.per_step else "policy rollout kernel, %d steps per launch" % a.chunk,
+                  "store": "trajectory + states" if a.store_states else ("trajectory" if a.store else "nothing"),
                   "env_steps_per_s": B * a.steps / dt, "us_per_vector_step": dt / a.steps * 1e6,
                   "mean_return_per_episode": float(total.sum()) / max(1, int(episodes.sum())), "episodes": int(episodes.sum())}))

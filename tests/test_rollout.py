@@ -147,3 +147,74 @@ def test_device_rollout_with_policy_in_the_loop_replays_on_the_oracle():
         assert float(total[e]) == tot and int(episodes[e]) == eps
     ret, adv, comp = buf.finish()
     assert bool(comp.any()) and torch.isfinite(ret).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hidden", [128, 48])
+def test_policy_rollout_in_one_launch_equals_the_per_step_loop(hidden):
+    """bbx_policy_rollout_device (policy inside the step kernel, T steps per launch) against T calls of
+    bbx_policy_step_device on a copy of the same batch with the same uniform numbers: actions, log-probabilities, rewards,
+    dones, row counts and the observation of every step are identical (the logits come from the same tile code in the
+    same summation order), and so are the environments' counters afterwards."""
+    import torch
+    from deepgroebner_amd import VecLeadMonomialsEnv
+    from deepgroebner_amd.rollout import PMLPPolicy
+    torch.manual_seed(3)
+    B, T, R = 500, 70, 256
+    env = VecLeadMonomialsEnv("3-20-10-weighted", batch=B, k=2)
+    env.seed(np.arange(B) + 77); env.reset(); env.accounting(False)
+    twin = env.copy(); twin.accounting(False)
+    policy = PMLPPolicy(env.cols, [hidden]).cuda()
+    with torch.no_grad():
+        for lin in list(policy.embedding) + [policy.deciding]:
+            lin.weight.mul_(0.3)
+    w = policy._fused_weights()
+    s = torch.cuda.current_stream().cuda_stream
+    u = torch.rand((T, B), device="cuda")
+    # reference: one call per step
+    obs = torch.full((B, R, env.cols), -1, dtype=torch.int32, device="cuda")
+    rew = torch.zeros(B, dtype=torch.float64, device="cuda"); done = torch.zeros(B, dtype=torch.uint8, device="cuda")
+    rows = torch.zeros(B, dtype=torch.int32, device="cuda"); act = torch.zeros(B, dtype=torch.int32, device="cuda")
+    logp = torch.zeros(B, dtype=torch.float32, device="cuda")
+    env.rollout_device("first", 0, False, s, rew, done, rows, obs, R, True, False); env.sync()
+    want = {k: [] for k in ("obs", "rows", "act", "logp", "rew", "done")}
+    for t in range(T):
+        want["obs"].append(obs.clone()); want["rows"].append(rows.clone())
+        env.policy_step_device(w["prepared"], w["hidden"], u[t], act, logp, rew, done, rows, obs, R, 1, s)
+        env.sync()
+        for k, v in (("act", act), ("logp", logp), ("rew", rew), ("done", done)):
+            want[k].append(v.clone())
+    # one launch (two, to cross a launch boundary)
+    A = torch.zeros((T, B), dtype=torch.int32, device="cuda"); L = torch.zeros((T, B), dtype=torch.float32, device="cuda")
+    Rw = torch.zeros((T, B), dtype=torch.float64, device="cuda"); D = torch.zeros((T, B), dtype=torch.uint8, device="cuda")
+    N = torch.zeros((T, B), dtype=torch.int32, device="cuda")
+    O = torch.full((T, B, R, env.cols), -1, dtype=torch.int32, device="cuda")
+    cut = 29
+    twin.policy_rollout_device(w["prepared"], w["hidden"], cut, u[:cut], A[:cut], L[:cut], Rw[:cut], D[:cut], N[:cut], O[:cut], R, B * R * env.cols, s)
+    twin.sync()
+    twin.policy_rollout_device(w["prepared"], w["hidden"], T - cut, u[cut:], A[cut:], L[cut:], Rw[cut:], D[cut:], N[cut:], O[cut:], R, B * R * env.cols, s)
+    twin.sync()
+    for t in range(T):
+        assert torch.equal(N[t], want["rows"][t]), t
+        assert torch.equal(A[t], want["act"][t]), t
+        assert torch.equal(L[t], want["logp"][t]), t
+        assert torch.equal(Rw[t], want["rew"][t]) and torch.equal(D[t], want["done"][t]), t
+        live = torch.arange(R, device="cuda")[None, :] < N[t][:, None]
+        assert torch.equal(O[t][live], want["obs"][t][live]), t
+        assert (O[t][~live] == -1).all()
+    assert (D.sum() > 0) and np.array_equal(env.stats(), twin.stats())
+
+
+@pytest.mark.gpu
+def test_policy_rollout_rejects_what_the_kernel_class_cannot_do():
+    import torch
+    from deepgroebner_amd import VecLeadMonomialsEnv, _ffi
+    from deepgroebner_amd.rollout import PMLPPolicy
+    env = VecLeadMonomialsEnv("5-10-5-uniform", batch=8, k=2)
+    env.reset(); env.accounting(False)
+    policy = PMLPPolicy(env.cols, [64]).cuda()
+    w = policy._fused_weights()
+    z = torch.zeros((4, 8), device="cuda")
+    with pytest.raises(_ffi.BbxError) as ei:
+        env.policy_rollout_device(w["prepared"], w["hidden"], 4, z, z.int(), z.clone(), stream=torch.cuda.current_stream().cuda_stream)
+    assert ei.value.code == -5                               # BBX_E_UNSUPPORTED (include/bbx.h)
