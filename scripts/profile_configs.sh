@@ -13,3 +13,10 @@ run() {  # name kernel args...
 }
 run cyclic7 bbx_wide_kernel cyclic-7 --batch 512 --steps 512
 run u5 bbx_binom_kernel 5-10-5-uniform --batch 4096 --steps 2048 --obs-rows 2048
+# the policy in the loop (scripts/bench_policy.py): kernel-trace stats of the rollout kernel and of the per-step path, and the lines
+for mode in rollout per_step; do
+  flag=""; [ $mode = per_step ] && flag="--per-step"
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_policy_$mode -o pol -- python3 scripts/bench_policy.py --steps 512 $flag > gpurun_out/prof_policy_$mode.log 2>&1 || echo "policy stats $mode failed"
+  timeout -k 10 300 python3 scripts/bench_policy.py $flag > gpurun_out/policy_${tag}_$mode.json 2>/dev/null || echo "policy line $mode failed"
+done
+timeout -k 10 300 python3 scripts/bench_policy.py --store > gpurun_out/policy_${tag}_rollout_store.json 2>/dev/null || true
