@@ -1162,7 +1162,8 @@ int resort_reducers_if_tied(bbx_batch* b, char* vrec, const BbxHdr& h) {
       const int g = ord[r];
       memcpy(&stm[(size_t)r * W], &tm[(size_t)g * W], (size_t)W * 4);
       const uint32_t tc = gi[2 * g] >> 16, inv = gi[2 * g + 1] & 0xffffu, sug = gi[2 * g + 1] >> 16;
-      si[2 * r] = tc | (inv << 16); si[2 * r + 1] = sug | ((uint32_t)g << 16);
+      const uint32_t kq = (32003u - (tc * inv) % 32003u) % 32003u;                    // -tc / lc mod p (bbx_binom.h: bin_add_poly)
+      si[2 * r] = tc | (kq << 16); si[2 * r + 1] = sug | ((uint32_t)g << 16);
     }
     HIPCHK(hipMemcpy(vrec + b->L.off_stm, stm.data(), stm.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(vrec + b->L.off_sinfo, si.data(), si.size() * 4, hipMemcpyHostToDevice));

@@ -110,7 +110,7 @@ __device__ bool bin_add_poly(BEnv<W>& e, const BbxParams& p, const BbxLayout& L,
   }
   if (lane == 0) {
     e.slm[pos] = t0.m; e.stm[pos] = t1.m;
-    e.sinfo[pos] = make_uint2(t1.c | (inv << 16), (uint32_t)sugar | ((uint32_t)g << 16));
+    e.sinfo[pos] = make_uint2(t1.c | (negmod(mulmod(t1.c, inv)) << 16), (uint32_t)sugar | ((uint32_t)g << 16));   // .x = tc | (-tc / lc) << 16
   }
   wave_sync();
   nG = g + 1;
@@ -467,11 +467,10 @@ __device__ __forceinline__ void binom_body(const BbxParams& p, char* smem, const
       if (found >= 0) {                                                 // h <- h - (LT h / LT f) f
         const uint2 si = e.sinfo[found];
         const Mono<W> tmg = e.stm[found];
-        const uint32_t tcg = si.x & 0xffffu, invg = si.x >> 16;
+        const uint32_t tcg = si.x & 0xffffu, kg = si.x >> 16;       // kg = -tc / lc mod p (0 without a tail)
         const Mono<W> q = m_div(h0.m, lmg);
-        const uint32_t c = mulmod(h0.c, invg);
         BTerm<W> b;
-        b.c = tcg ? negmod(mulmod(c, tcg)) : 0u;
+        b.c = mulmod(h0.c, kg);
         b.m = m_mul(tmg, q);
         int fs = (int)(si.y & 0xffffu) + (int)m_deg(q);
         hsug = uni(fs > hsug ? fs : hsug);

@@ -80,7 +80,7 @@ struct BbxLayout {
   uint32_t rec_bytes;
   // binomial class (kind == 1): every basis polynomial has <= 2 terms, so there is no arena; the
   // record holds, in BASIS order, lm[] / tm[] (lead and tail monomial) and ginfo[] = {lc | tc<<16,
-  // 1/lc | sugar<<16}, and in REDUCER order slm[] / stm[] and sinfo[] = {tc | (1/lc)<<16, sugar | g<<16},
+  // 1/lc | sugar<<16}, and in REDUCER order slm[] / stm[] and sinfo[] = {tc | (-tc/lc mod p)<<16, sugar | g<<16},
   // so that one reduction round needs the scan of slm[] plus two independent loads.  tc == 0: no tail.
   uint32_t kind;
   uint32_t off_tm, off_stm, off_ginfo, off_sinfo;

@@ -102,7 +102,7 @@ __device__ __forceinline__ FColdPolicy f_cold_policy() {
 
 struct FastState {                 // reducer-order arrays, lane l <-> reducers l (A) and l + 64 (B)
   M2 slmA, slmB, stmA, stmB;
-  uint2 sinA, sinB;                // .x = tc | (1/lc) << 16 ; .y = sugar | basis index << 16
+  uint2 sinA, sinB;                // .x = tc | (-tc/lc) << 16 ; .y = sugar | basis index << 16
 };
 
 // TRACE: per-step parity hashes (tests).  ACCT: count the algorithmic bytes of every step (roofline numerator;
@@ -370,7 +370,7 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem, in
       if (!SMALL && g >= 64) pos += __popcll(ballot64(!m_gt(S.slmB, f)));
       const uint32_t inv = inv_raw;
       if (lane == 0) gi[g] = make_uint2(t0.c | (t1.c << 16), inv | ((uint32_t)sugar << 16));
-      const uint2 ns = make_uint2(t1.c | (inv << 16), (uint32_t)sugar | ((uint32_t)g << 16));
+      const uint2 ns = make_uint2(t1.c | (negmod(mulmod(t1.c, inv)) << 16), (uint32_t)sugar | ((uint32_t)g << 16));   // .x = tc | (-tc / lc) << 16
       if (SMALL || pos < 64) {
         const uint32_t c0 = f_insert(S.slmA.w[0], f.w[0], pos, lane), c1 = f_insert(S.slmA.w[1], f.w[1], pos, lane);
         const uint32_t c2 = f_insert(S.stmA.w[0], tail.w[0], pos, lane), c3 = f_insert(S.stmA.w[1], tail.w[1], pos, lane);
@@ -602,15 +602,14 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem, in
         }
       }
       if (found >= 0) {                                              // h <- h - (LT h / LT f) f
-        const uint32_t tcg = sx & 0xffffu, invg = sx >> 16;
+        const uint32_t tcg = sx & 0xffffu, kg = sx >> 16;            // kg = -tc / lc mod p, formed once when f entered the basis
         const uint32_t q0 = h0a - lg0, q1 = h0b - lg1;               // LT h / LT f
-        const uint32_t c = mulmod(h0c, invg);
         const int fs = (int)(sy & 0xffffu) + (int)(q1 >> 16);
         hsug = fs > hsug ? fs : hsug;
         if (hsug > 65535) break;                                     // reported below; nothing has been modified
         // the new term b = -(c tc) (tail f * q) takes the place of the cancelled lead term; then (b, h1) are put in
         // order (polynomials.cpp:148-177 on single optional terms) — in the common case nothing moves
-        h0c = negmod(mulmod(c, tcg));                                // 0 when f has no tail
+        h0c = mulmod(h0c, kg);                                       // -(c_h / lc) tc; 0 when f has no tail
         h0a = tg0 + q0; h0b = tg1 + q1;
         if (ACCT) bytes += 8 * (found + 1) + 12 * (tcg ? 2 : 1) + 12 * hn;
         if (h0c == 0) { h0c = h1c; h0a = h1a; h0b = h1b; h1c = 0; }

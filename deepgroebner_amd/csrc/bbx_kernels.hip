@@ -180,19 +180,31 @@ template <int W> __device__ __forceinline__ uint32_t m_exp(const Mono<W>& a, int
 // allows (dwordx4 / dwordx2 / dword) instead of n single dwords: the observation is the largest output of a step
 struct __attribute__((aligned(4))) ObsI4 { int32_t a, b, c, d; };
 struct __attribute__((aligned(4))) ObsI2 { int32_t a, b; };
+// Observation rows are written once and read by a later kernel (or the host): non-temporal stores, so that the stream
+// of rows (tens of MB per batch step in the HBM-resident classes) does not push the environments' records out of the
+// caches the gathers of the next step hit.  BBX_OBS_TEMPORAL restores plain stores (A/B experiments).
+typedef int32_t bbx_obs_i4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef int32_t bbx_obs_i2 __attribute__((ext_vector_type(2), aligned(4)));
+#ifdef BBX_OBS_TEMPORAL
+#define BBX_OBS_ST(P, V) (*(P) = (V))
+#else
+#define BBX_OBS_ST(P, V) __builtin_nontemporal_store((V), (P))
+#endif
 template <int W> __device__ __forceinline__ void obs_store(int32_t* dst, const Mono<W>& mm, int n) {
   int32_t x[2 * W > 8 ? 2 * W : 8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
   for (int i = 0; i < W; i++) { x[2 * i] = (int32_t)(mm.w[i] & 0xffffu); x[2 * i + 1] = (int32_t)(mm.w[i] >> 16); }
+  const bbx_obs_i4 lo = {x[0], x[1], x[2], x[3]}, hi = {x[4], x[5], x[6], x[7]};
+  const bbx_obs_i2 l2 = {x[0], x[1]}, h2 = {x[4], x[5]};
   switch (n) {                                             // wave-uniform
-    case 1: dst[0] = x[0]; break;
-    case 2: *(ObsI2*)dst = ObsI2{x[0], x[1]}; break;
-    case 3: *(ObsI2*)dst = ObsI2{x[0], x[1]}; dst[2] = x[2]; break;
-    case 4: *(ObsI4*)dst = ObsI4{x[0], x[1], x[2], x[3]}; break;
-    case 5: *(ObsI4*)dst = ObsI4{x[0], x[1], x[2], x[3]}; dst[4] = x[4]; break;
-    case 6: *(ObsI4*)dst = ObsI4{x[0], x[1], x[2], x[3]}; *(ObsI2*)(dst + 4) = ObsI2{x[4], x[5]}; break;
-    case 7: *(ObsI4*)dst = ObsI4{x[0], x[1], x[2], x[3]}; *(ObsI2*)(dst + 4) = ObsI2{x[4], x[5]}; dst[6] = x[6]; break;
-    default: *(ObsI4*)dst = ObsI4{x[0], x[1], x[2], x[3]}; *(ObsI4*)(dst + 4) = ObsI4{x[4], x[5], x[6], x[7]}; break;   // 8 variables
+    case 1: BBX_OBS_ST(dst, x[0]); break;
+    case 2: BBX_OBS_ST((bbx_obs_i2*)dst, l2); break;
+    case 3: BBX_OBS_ST((bbx_obs_i2*)dst, l2); BBX_OBS_ST(dst + 2, x[2]); break;
+    case 4: BBX_OBS_ST((bbx_obs_i4*)dst, lo); break;
+    case 5: BBX_OBS_ST((bbx_obs_i4*)dst, lo); BBX_OBS_ST(dst + 4, x[4]); break;
+    case 6: BBX_OBS_ST((bbx_obs_i4*)dst, lo); BBX_OBS_ST((bbx_obs_i2*)(dst + 4), h2); break;
+    case 7: BBX_OBS_ST((bbx_obs_i4*)dst, lo); BBX_OBS_ST((bbx_obs_i2*)(dst + 4), h2); BBX_OBS_ST(dst + 6, x[6]); break;
+    default: BBX_OBS_ST((bbx_obs_i4*)dst, lo); BBX_OBS_ST((bbx_obs_i4*)(dst + 4), hi); break;   // 8 variables
   }
 }
 
