@@ -584,33 +584,38 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem, in
       const int hn = h1c ? 2 : 1;
       M2 hm; hm.w[0] = h0a; hm.w[1] = h0b;
       int found = -1;
-      uint32_t lg0 = 0, lg1 = 0, tg0 = 0, tg1 = 0, sx = 0, sy = 0;
+      uint32_t nb0 = 0, nb1 = 0, sx = 0;
+      int fs = 0;
+      // Every lane prepares what the round needs from ITS reducer, should it be the divisor — the quotient LT h / LT f,
+      // the monomial of the new term tail(f) * quotient, the sugar candidate: vector work the SIMDs have room for — and
+      // the chosen lane's results travel by v_readlane: 4 words instead of 6 plus their arithmetic on the scalar unit,
+      // which is the unit this kernel is bound by.  (Garbage in lanes that do not divide: unused.)
+      const uint32_t qA1 = h0b - S.slmA.w[1];
+      const uint32_t bA0 = S.stmA.w[0] + (h0a - S.slmA.w[0]), bA1 = S.stmA.w[1] + qA1;
+      const uint32_t fA = (S.sinA.y & 0xffffu) + (qA1 >> 16);
       const uint64_t mA = ballot64(m_divides(S.slmA, hm));          // sentinels never divide
       if (mA) {
         found = __builtin_ctzll(mA);
-        lg0 = f_readlane(S.slmA.w[0], found); lg1 = f_readlane(S.slmA.w[1], found);
-        tg0 = f_readlane(S.stmA.w[0], found); tg1 = f_readlane(S.stmA.w[1], found);
-        sx = f_readlane(S.sinA.x, found); sy = f_readlane(S.sinA.y, found);
+        nb0 = f_readlane(bA0, found); nb1 = f_readlane(bA1, found);
+        sx = f_readlane(S.sinA.x, found); fs = (int)f_readlane(fA, found);
       } else if (nG > 64) {
         const uint64_t mB = ballot64(m_divides(S.slmB, hm));
         if (mB) {
           const int l = __builtin_ctzll(mB);
           found = 64 + l;
-          lg0 = f_readlane(S.slmB.w[0], l); lg1 = f_readlane(S.slmB.w[1], l);
-          tg0 = f_readlane(S.stmB.w[0], l); tg1 = f_readlane(S.stmB.w[1], l);
-          sx = f_readlane(S.sinB.x, l); sy = f_readlane(S.sinB.y, l);
+          const uint32_t qB1 = h0b - S.slmB.w[1];
+          nb0 = f_readlane(S.stmB.w[0] + (h0a - S.slmB.w[0]), l); nb1 = f_readlane(S.stmB.w[1] + qB1, l);
+          sx = f_readlane(S.sinB.x, l); fs = (int)f_readlane((S.sinB.y & 0xffffu) + (qB1 >> 16), l);
         }
       }
       if (found >= 0) {                                              // h <- h - (LT h / LT f) f
         const uint32_t tcg = sx & 0xffffu, kg = sx >> 16;            // kg = -tc / lc mod p, formed once when f entered the basis
-        const uint32_t q0 = h0a - lg0, q1 = h0b - lg1;               // LT h / LT f
-        const int fs = (int)(sy & 0xffffu) + (int)(q1 >> 16);
         hsug = fs > hsug ? fs : hsug;
         if (hsug > 65535) break;                                     // reported below; nothing has been modified
         // the new term b = -(c tc) (tail f * q) takes the place of the cancelled lead term; then (b, h1) are put in
         // order (polynomials.cpp:148-177 on single optional terms) — in the common case nothing moves
         h0c = mulmod(h0c, kg);                                       // -(c_h / lc) tc; 0 when f has no tail
-        h0a = tg0 + q0; h0b = tg1 + q1;
+        h0a = nb0; h0b = nb1;
         if (ACCT) bytes += 8 * (found + 1) + 12 * (tcg ? 2 : 1) + 12 * hn;
         if (h0c == 0) { h0c = h1c; h0a = h1a; h0b = h1b; h1c = 0; }
         else if (h1c != 0) {
