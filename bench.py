@@ -133,8 +133,11 @@ def main():
         launch(Wm); env.sync()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    launch(K); env.sync(); torch.cuda.synchronize()  # calibration launch (also untimed warm-up of this launch shape)
-    t_launch = time.perf_counter() - t0
+    ncal = 8 if chain else 1                         # calibration (also the untimed warm-up of this launch shape): chained
+    for _ in range(ncal):                             # launches, so that the synchronisation is not mistaken for launch time
+        launch(K)
+    env.sync(); torch.cuda.synchronize()
+    t_launch = (time.perf_counter() - t0) / ncal
     R = args.repeats if args.repeats > 0 else int(min(4096, max(3, MIN_REGION_MS * 1e-3 / max(t_launch, 1e-6) + 1)))
     if world > 1:
         r_all = [None] * world
