@@ -498,9 +498,10 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem, in
       const int plr = lane & 31, plk = lane >> 5;
       float* lg = (float*)(lbase + FLDS_BYTES);
       const float b2 = wp[(size_t)(2 * 6 + 2) * 32 * POL];
-      for (int r0 = 0; r0 < nP; r0 += 32) {
+      const int pn = (p.obs && nP > p.obs_rows) ? p.obs_rows : nP;   // the rows the policy sees = the rows of the block
+      for (int r0 = 0; r0 < pn; r0 += 32) {
         const int r = r0 + plr;
-        const uint32_t prw = r < nP ? pairs[r] : 0u;
+        const uint32_t prw = r < pn ? pairs[r] : 0u;
         const M2 a0 = lm[prw & 0xffffu], a1 = tm[prw & 0xffffu], c0 = lm[prw >> 16], c1 = tm[prw >> 16];
         // row = [lm_i | tm_i | lm_j | tm_j] x (e0, e1, e2); my k-step operands are columns 2 s + (lane >> 5)
         const uint32_t ev[6] = {plk ? a0.w[0] >> 16 : a0.w[0] & 0xffffu,  plk ? a1.w[0] & 0xffffu : a0.w[1] & 0xffffu,
@@ -510,10 +511,10 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem, in
 #pragma unroll
         for (int s2 = 0; s2 < 6; s2++) xa[s2] = (float)ev[s2];
         const float logit = pmlp_tile<POL, 6, 1>(xa, wp, plr, plk);
-        if (plk == 0 && r < nP) lg[r] = logit + b2;
+        if (plk == 0 && r < pn) lg[r] = logit + b2;
       }
       wave_sync();
-      action = pmlp_sample(lg, nP, env, uu, pol->actions + (size_t)pol_tt * (size_t)p.B, pol->logprobs + (size_t)pol_tt * (size_t)p.B);
+      action = pmlp_sample(lg, pn, env, uu, pol->actions + (size_t)pol_tt * (size_t)p.B, pol->logprobs + (size_t)pol_tt * (size_t)p.B);
     } else
     if (agent == BBX_AGENT_HASH) action = (int)(((uint64_t)f_readlane(hv, t_agent & 63) * (uint32_t)nP) >> 32);   // bbx_agent_action32
     else if (agent == BBX_AGENT_EXTERNAL) action = ext_action >= 0 ? ext_action : uni(f_cold_params()->actions[env]);

@@ -350,6 +350,9 @@ __device__ unsigned long long bbx_wide_prof_acc[32];
 #define WSTAMP(slot) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); wprof[WSLOT(slot)] += t_ - wlast; wlast = t_; } while (0)
 #define WCSLOT(slot) ((slot) == 10 ? 0 : (slot) == 13 ? 1 : (slot) == 23 ? 2 : (slot) == 24 ? 3 : (slot) == 25 ? 4 : (slot) == 15 ? 5 : 6)
 #define WCOUNT(slot, v) (wcnt[WCSLOT(slot)] += (unsigned long long)(v))
+#elif defined(BBX_MARK)
+#define WSTAMP(slot) asm volatile("; WMARK " #slot)      // assembly listings only: phase boundaries for instruction counts
+#define WCOUNT(slot, v) do {} while (0)
 #else
 #define WSTAMP(slot) do {} while (0)
 #define WCOUNT(slot, v) do {} while (0)

@@ -150,18 +150,20 @@ def test_device_rollout_with_policy_in_the_loop_replays_on_the_oracle():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("hidden", [128, 48])
-def test_policy_rollout_in_one_launch_equals_the_per_step_loop(hidden):
+@pytest.mark.parametrize("hidden,caps", [(128, None), (48, None), (128, {"lds_max_basis": 16}), (64, {"lds_max_basis": 16})])
+def test_policy_rollout_in_one_launch_equals_the_per_step_loop(hidden, caps):
     """bbx_policy_rollout_device (policy inside the step kernel, T steps per launch) against T calls of
     bbx_policy_step_device on a copy of the same batch with the same uniform numbers: actions, log-probabilities, rewards,
     dones, row counts and the observation of every step are identical (the logits come from the same tile code in the
-    same summation order), and so are the environments' counters afterwards."""
+    same summation order), and so are the environments' counters afterwards.  With the register/LDS class capped at 16
+    basis elements most environments outgrow it inside the rollout: the HBM-resident continuation pass (policy included)
+    takes them over mid-launch."""
     import torch
     from deepgroebner_amd import VecLeadMonomialsEnv
     from deepgroebner_amd.rollout import PMLPPolicy
     torch.manual_seed(3)
     B, T, R = 500, 70, 256
-    env = VecLeadMonomialsEnv("3-20-10-weighted", batch=B, k=2)
+    env = VecLeadMonomialsEnv("3-20-10-weighted", batch=B, k=2, caps=caps)
     env.seed(np.arange(B) + 77); env.reset(); env.accounting(False)
     twin = env.copy(); twin.accounting(False)
     policy = PMLPPolicy(env.cols, [hidden]).cuda()
@@ -202,7 +204,9 @@ def test_policy_rollout_in_one_launch_equals_the_per_step_loop(hidden):
         live = torch.arange(R, device="cuda")[None, :] < N[t][:, None]
         assert torch.equal(O[t][live], want["obs"][t][live]), t
         assert (O[t][~live] == -1).all()
-    assert (D.sum() > 0) and np.array_equal(env.stats(), twin.stats())
+    # steps, additions, episodes, zero reductions, status (the algorithmic-byte column is only kept by the HBM-resident
+    # kernel when accounting is off, and the two drivers hand environments over to it at different moments)
+    assert (D.sum() > 0) and np.array_equal(env.stats()[:, :5], twin.stats()[:, :5])
 
 
 @pytest.mark.gpu
