@@ -140,6 +140,28 @@ class VecLeadMonomialsEnv:
             return np.zeros((0, self.cols), dtype=np.int32), off
         return view(io["obs"])[:total * self.cols].copy().reshape(total, self.cols), off
 
+    def _step_one(self, action):
+        """The single-environment step of CLeadMonomialsEnv.step with nothing the batch interface needs: one library
+        call, one copy of the observation out of the pinned buffer -> (state, reward, done)."""
+        io = self.__dict__.get("_io1")
+        if io is None:
+            obs, off = C.POINTER(C.c_int32)(), C.POINTER(C.c_int32)()
+            act = np.zeros(1, dtype=np.int32)
+            io = self._io1 = {"obs": obs, "off": off, "act": act, "fn": _ffi.lib().bbx_step_obs, "view": None, "addr": None,
+                              "args": (self._h, _ffi.ptr(act), 0, _ffi.ptr(self._rewards), _ffi.ptr(self._dones), _ffi.ptr(self.rows),
+                                       C.byref(obs), C.byref(off))}
+        io["act"][0] = action
+        rc = io["fn"](*io["args"])
+        if rc:
+            _ffi.check(rc)
+        total = io["off"][1]
+        addr = C.cast(io["obs"], C.c_void_p).value
+        if addr != io["addr"]:                               # (the pinned buffer moves only when it has to grow)
+            io["addr"] = addr
+            io["view"] = np.ctypeslib.as_array(C.cast(io["obs"], C.POINTER(C.c_int32 * (1 << 28))).contents)
+        cols = self.cols
+        return io["view"][:total * cols].reshape(total, cols).copy(), float(self._rewards[0]), bool(self._dones[0])
+
     def _as_list(self, flat, off):
         return [flat] if self.batch == 1 else np.split(flat, off[1:-1])
 
@@ -321,8 +343,8 @@ class CLeadMonomialsEnv:
         return self._vec.reset()[0]
 
     def step(self, action):
-        obs, r, d, _ = self._vec.step(int(action))   # accepts numpy / python scalars like action.numpy()
-        return obs[0], float(r[0]), bool(d[0]), {}
+        obs, r, d = self._vec._step_one(int(action))  # accepts numpy / python scalars like action.numpy()
+        return obs, r, d, {}
 
     def seed(self, seed=None):
         if seed is not None:

@@ -150,6 +150,8 @@ struct BbxParams {
   const uint16_t* inv_table; // [32003] inverses in GF(32003) (L2-resident), binomial class
   const uint32_t* gen;      // device-side generator table (BBX_GEN_* layout below) or null: ideals come from the queue
   int32_t* lite;            // [B][4] {status, q_head, budget, |P|}: what the host polls after a launch, or null
+  int32_t done_seq;         // != 0: lite lives in host memory and the host spins on it — the status word carries this
+                            // number in bits 17.., written behind a system-scope fence after every other output
   BbxTraceRec* trace;       // [B, trace_stride] or null
   int32_t trace_stride;
   int32_t wide_hc, wide_fc, wide_rc, wide_sc;   // wide class: LDS capacities (terms) of the polynomial being reduced, the

@@ -38,6 +38,7 @@ struct BbxFastParams {
   int32_t B, nsteps, obs_rows, trace_stride, k, nvars, lim_G, lim_P;
   int32_t agent, auto_reset, set_budget, pass, obs_every_step, obs_fill, rewards_mode;
   int32_t* lite;                                      // [B][4] {status, q_head, budget, |P|} for the host, or null
+  int32_t done_seq;                                   // see BbxParams::done_seq
   const uint32_t* gen;                                // device-side ideal generator table or null (ideals come from the queue)
   int32_t sort_input;                                 // device-drawn ideals enter in ascending lead-monomial order
   unsigned long long* prof;                           // diagnostic build only: [B][8] cycle sums per phase
@@ -742,13 +743,19 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem, in
     h->budget = budget; h->rollout_pos = rollout_pos; h->done_last = done_last; h->alg_bytes += bytes_total;
     const int trunc_all = (cz->set_budget ? 0 : h->obs_trunc) | obs_trunc;
     h->obs_trunc = trunc_all;
-    if (cz->lite) *(int4*)(cz->lite + 4 * (size_t)env) = make_int4(status | (trunc_all ? BBX_LITE_OBS_TRUNC : 0), q_head, budget, nP);
     if (!handoff) {
       double* rw = cz->rewards; uint8_t* dn = cz->dones; int32_t* rws = cz->rows;
       if (rw && (steps_done > 0 || cz->pass == 0))
         rw[env] = last_nred < 0 ? 0.0 : (cz->rewards_mode == BBX_REW_ADDITIONS ? (-1.0 - (double)last_nred) : -1.0);
       if (dn) dn[env] = (uint8_t)((done_last || (nP == 0 && !need_reset)) ? 1 : 0);
       if (rws) rws[env] = nP;
+    }
+    if (cz->lite) {
+      // the host may be spinning on this word (done_seq): everything else this wave wrote — rewards, rows, the observation
+      // block in host memory — has to be visible first
+      const int seq = cz->done_seq;
+      if (seq) __threadfence_system();
+      *(int4*)(cz->lite + 4 * (size_t)env) = make_int4(status | (trunc_all ? BBX_LITE_OBS_TRUNC : 0) | (seq << 17), q_head, budget, nP);
     }
   }
 }

@@ -1536,7 +1536,7 @@ static int launch_fast(const BbxParams* p, int blocks, int threads, int envs_per
   f.lim_G = (int)p->LL.maxG; f.lim_P = (int)p->LL.maxP;
   f.agent = p->agent; f.auto_reset = p->auto_reset; f.set_budget = p->set_budget; f.pass = p->pass;
   f.obs_every_step = p->obs_every_step; f.obs_fill = p->obs_fill; f.rewards_mode = p->rewards_mode;
-  f.lite = p->lite;
+  f.lite = p->lite; f.done_seq = p->done_seq;
   f.gen = p->gen;
   f.sort_input = p->sort_input;
   const size_t lds = (size_t)envs_per_block * FLDS_BYTES;
