@@ -29,7 +29,7 @@ enum bbx_status {
   BBX_E_DEVICE = -2,      /* HIP error or no device */
   BBX_E_CAPACITY = -3,    /* an environment exceeded its configured capacity (see bbx_env_status) */
   BBX_E_GENERATOR = -4,   /* the ideal generator failed (the reference would have thrown) */
-  BBX_E_UNSUPPORTED = -5, /* e.g. 8 variables, poisson mean >= 12 */
+  BBX_E_UNSUPPORTED = -5, /* the library has no code for the request (e.g. more than 8 variables, a policy shape or kernel class without a built-in policy) */
   BBX_E_ACTION = -6       /* an action index was outside [0, rows) */
 };
 
