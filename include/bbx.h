@@ -187,6 +187,9 @@ int bbx_policy_step_device(bbx_batch* b, const float* d_prepared, int hidden, co
  * register/LDS-resident class (<= 3 variables, binomial ideals, k = 2, accounting off, 33..128 hidden units); other
  * batches: BBX_E_UNSUPPORTED (use bbx_policy_step_device).  Environments that outgrow that class inside the rollout
  * (|G| > 128 or |P| > 256) are continued, policy included, by the HBM-resident kernel launched right behind.
+ * Batches whose ideals come from the host-side queue (BBX_HOST_GEN, sort_input with more than 16 generators) must hold
+ * enough queued ideals for the episodes that end inside the launch (bbx_caps.queue_slots, bbx_prefetch): the host cannot
+ * refill in the middle of a launch, and an environment left waiting makes bbx_sync report BBX_E_CAPACITY.
  * Asynchronous like bbx_rollout_device. */
 int bbx_policy_rollout_device(bbx_batch* b, const float* d_prepared, int hidden, int nsteps, const float* d_u, int32_t* d_actions,
                               float* d_logprobs, double* d_rewards, uint8_t* d_dones, int32_t* d_rows, int32_t* d_obs, int obs_rows,
