@@ -322,12 +322,13 @@ int enqueue(bbx_batch* b, const BbxParams& p0, bool resume, hipStream_t stream) 
   if (p.nsteps == 0 && !resume) kinds[nk++] = 2;
   else if (b->wide) kinds[nk++] = 4;
   else {   // the hand-tuned kernel knows the external / random / degree / first agents; the others take the class kernel
-    if (b->staged) kinds[nk++] = (b->fast && p.agent <= BBX_AGENT_FIRST) ? 3 : 1;
+    const bool pol_hbm_only = p.policy && p.policy->rollout == 2;     // a policy rollout outside the register/LDS class
+    if (b->staged && !pol_hbm_only) kinds[nk++] = (b->fast && p.agent <= BBX_AGENT_FIRST) ? 3 : 1;
     // the HBM-resident pass behind the LDS-resident one serves environments that outgrow the LDS class inside a
     // rollout; a single host-driven step does without it: an environment that spills reports BBX_ST_SPILL and
     // finish() continues it (one launch less on the latency path)
     // (asynchronous calls on caller buffers always get it: nobody polls their status words between steps)
-    if (!b->staged || resume || p.nsteps > 1 || b->obs_external || b->device_async) kinds[nk++] = 0;
+    if (!b->staged || pol_hbm_only || resume || p.nsteps > 1 || b->obs_external || b->device_async) kinds[nk++] = 0;
   }
   // a host-driven zero-copy step whose only kernel is the hand-tuned one: the host spins on the status words in pinned
   // memory instead of waiting for the runtime's completion signal (read_lite)
@@ -1055,9 +1056,12 @@ int bbx_policy_rollout_device(bbx_batch* b, const float* d_prepared, int hidden,
   if (nsteps < 1 || (d_obs && obs_rows < 1) || obs_step_stride < 0) return fail(BBX_E_ARG, "bad rollout arguments");
   const int cols = 2 * b->nvars * b->k;
   if (bbx_pmlp_prepared_floats(cols, hidden) < 0) return BBX_E_UNSUPPORTED;
-  if (!(b->fast && b->staged) || b->nvars != 3 || b->k != 2 || (pmlp_nb(hidden) != 2 && pmlp_nb(hidden) != 4))
-    return fail(BBX_E_UNSUPPORTED, "policy rollouts are built into the register/LDS-resident class only (<= 3 variables, binomial ideals, k = 2, "
-                                   "33..128 hidden units); drive this batch with bbx_policy_step_device");
+  // where the policy is built into the step kernels: binomial classes with 8- or 16-byte monomials, 33..128 hidden units,
+  // observation widths whose prepared weights have 6 k-steps (or 10 with 16-byte monomials)
+  const int ks = pmlp_ks(cols);
+  if (!b->binom || b->wide || (b->W != 2 && b->W != 4) || (pmlp_nb(hidden) != 2 && pmlp_nb(hidden) != 4) || !(ks == 6 || (b->W == 4 && ks == 10)))
+    return fail(BBX_E_UNSUPPORTED, "policy rollouts are built into the binomial kernel classes only (<= 7 variables, 2nk <= 12 columns, or <= 20 with "
+                                   "more than 3 variables; 33..128 hidden units); drive this batch with bbx_policy_step_device");
   if (b->accounting) return fail(BBX_E_UNSUPPORTED, "policy rollouts run the lean kernel: call bbx_accounting(b, 0) first");
   if (b->d_trace && b->trace_cap >= 1) return fail(BBX_E_UNSUPPORTED, "policy rollouts are not traced");
   if (d_obs && obs_step_stride != 0 && obs_step_stride < (long long)b->B * obs_rows * cols) return fail(BBX_E_ARG, "obs_step_stride smaller than one block");
@@ -1068,6 +1072,9 @@ int bbx_policy_rollout_device(bbx_batch* b, const float* d_prepared, int hidden,
   p.obs = d_obs; p.obs_rows = obs_rows; p.obs_fill = 0;
   p.trace = nullptr;
   p.policy = &pol;
+  // the register/LDS-resident kernel has the policy for 3 variables and k = 2; every other admitted shape runs in the
+  // HBM-resident binomial kernel from the start
+  pol.rollout = (b->fast && b->staged && b->nvars == 3 && b->k == 2) ? 1 : 2;
   return launch(b, p, (hipStream_t)stream, d_obs != nullptr, true);
 }
 

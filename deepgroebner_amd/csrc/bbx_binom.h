@@ -286,9 +286,11 @@ __device__ uint64_t bin_poly_hash(const BEnv<W>& e, int g) {
   return wave_sum64(h);
 }
 
-// POL > 0 (W = 2, HBM-resident instantiation only): the continuation of a policy rollout (fast_body POL, bbx_fast.h) for
-// environments that outgrew the register/LDS-resident class — the same per-step protocol, rows gathered from the record
-template <int W, bool STAGED, bool TRACE, int POL = 0>
+// POL > 0 (HBM-resident instantiation only): a policy rollout (bbx_policy_rollout_device) — the per-step protocol of
+// fast_body POL (bbx_fast.h), rows gathered from the record — either as the continuation pass for environments that
+// outgrew the register/LDS-resident class or as the rollout kernel of a batch that is not in that class.  POL = unit
+// blocks of 32 of the hidden layer, PKS = the k-steps of the prepared weights (pmlp_ks_for(2 n k)).
+template <int W, bool STAGED, bool TRACE, int POL = 0, int PKS = 6>
 __device__ __forceinline__ void binom_body(const BbxParams& p, char* smem, const BbxPolicy* pol = nullptr) {
   const int lane = lane_id();
   const int wave_in_block = uni((int)(threadIdx.x / WAVE));
@@ -363,18 +365,31 @@ __device__ __forceinline__ void binom_body(const BbxParams& p, char* smem, const
       const float* wp = pol->wp;
       const int plr = lane & 31, plk = lane >> 5;
       float* lg = (float*)peel_lds;                          // (the update's scratch is idle here: PMLP_MAXROWS floats)
-      const float b2 = wp[(size_t)(2 * 6 + 2) * 32 * POL];
+      const float b2 = wp[(size_t)(2 * PKS + 2) * 32 * POL];
+      // column c = 2 s + (lane >> 5) of a row = exponent (c mod n) of term (c / n) of [lead_i, tail_i, .., lead_j, tail_j, ..]
+      // (k terms per polynomial, zeros beyond a binomial's two): decoded once, the same for every row
+      const int pn_ = p.nvars, pk_ = p.k;
+      int csel[PKS];
+#pragma unroll
+      for (int s2 = 0; s2 < PKS; s2++) {
+        const int c = 2 * s2 + plk;
+        const int t = c / pn_, v = c - t * pn_, member = t / pk_, which = t - member * pk_;
+        csel[s2] = (c < 2 * pn_ * pk_ && which < 2) ? (v | (which << 8) | (member << 9)) : -1;
+      }
       for (int r0 = 0; r0 < n; r0 += 32) {
         const int r = r0 + plr;
         const uint32_t prw = r < n ? e.pairs[r] : 0u;
         const Mono<W> a0 = e.lm[prw & 0xffffu], a1 = e.tm[prw & 0xffffu], c0 = e.lm[prw >> 16], c1 = e.tm[prw >> 16];
-        const uint32_t ev[6] = {plk ? a0.w[0] >> 16 : a0.w[0] & 0xffffu,  plk ? a1.w[0] & 0xffffu : a0.w[1] & 0xffffu,
-                                plk ? a1.w[1] & 0xffffu : a1.w[0] >> 16,  plk ? c0.w[0] >> 16 : c0.w[0] & 0xffffu,
-                                plk ? c1.w[0] & 0xffffu : c0.w[1] & 0xffffu, plk ? c1.w[1] & 0xffffu : c1.w[0] >> 16};
-        float xa[6];
+        float xa[PKS];
 #pragma unroll
-        for (int s2 = 0; s2 < 6; s2++) xa[s2] = (float)ev[s2];
-        const float logit = pmlp_tile<POL, 6, 1>(xa, wp, plr, plk);
+        for (int s2 = 0; s2 < PKS; s2++) {
+          const int cs = csel[s2];
+          Mono<W> mm;
+#pragma unroll
+          for (int q = 0; q < W; q++) { const uint32_t wi = (cs & 256) ? a1.w[q] : a0.w[q], wj = (cs & 256) ? c1.w[q] : c0.w[q]; mm.w[q] = (cs & 512) ? wj : wi; }
+          xa[s2] = cs < 0 ? 0.f : (float)m_exp(mm, cs & 255);
+        }
+        const float logit = pmlp_tile<POL, PKS, 1>(xa, wp, plr, plk);
         if (plk == 0 && r < n) lg[r] = logit + b2;
       }
       wave_sync();
@@ -572,10 +587,10 @@ __global__ __launch_bounds__(256, 4) void bbx_binom_kernel(BbxParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   binom_body<W, STAGED, TRACE>(p, smem);
 }
-template <int NB>
+template <int W, int NB, int KS>
 __global__ __launch_bounds__(256, 4) void bbx_binom_policy_kernel(BbxParams p, BbxPolicy pol) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  binom_body<2, false, false, NB>(p, smem, &pol);
+  binom_body<W, false, false, NB, KS>(p, smem, &pol);
 }
 template <int W>
 __global__ __launch_bounds__(256) void bbx_binom_aux_kernel(BbxParams p) {

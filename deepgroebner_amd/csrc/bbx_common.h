@@ -116,7 +116,7 @@ struct BbxPolicy {
   int32_t* actions; float* logprobs;   // [B] outputs: the sampled row and its log-probability
   // policy ROLLOUT (nsteps > 1 inside one launch): the arrays above are [nsteps][B] and so are these; the observation
   // the policy saw at step t goes to obs + t * obs_tstride (0: one block, overwritten every step)
-  int32_t rollout;
+  int32_t rollout;                     // 0: per-step call; 1: rollout, register/LDS-resident kernel first; 2: rollout, HBM-resident kernel only
   double* rewards_t; uint8_t* dones_t; int32_t* rows_t; long long obs_tstride;
 };
 struct BbxParams {

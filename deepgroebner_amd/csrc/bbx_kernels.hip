@@ -1507,11 +1507,15 @@ static int launch_w(const BbxParams* p, int kind, int blocks, int threads, size_
 #endif
   if (binom) {
     lds = (size_t)(threads / WAVE) * update_lds_bytes<W>();           // Gebauer-Moeller peel scratch, one per wave
-    if constexpr (W == 2) {
-      if (p->policy && p->policy->rollout) {               // the continuation pass of a policy rollout
+    if constexpr (W == 2 || W == 4) {
+      if (p->policy && p->policy->rollout) {               // a policy rollout: its continuation pass, or the whole of it
         BbxParams q = *p; q.policy = nullptr; q.actions = nullptr; q.rewards = nullptr; q.dones = nullptr; q.rows = nullptr; q.obs_every_step = 0;
-        if (pmlp_nb_for(p->policy->hidden) == 2) hipLaunchKernelGGL((bbx_binom_policy_kernel<2>), dim3(blocks), dim3(threads), lds, stream, q, *p->policy);
-        else hipLaunchKernelGGL((bbx_binom_policy_kernel<4>), dim3(blocks), dim3(threads), lds, stream, q, *p->policy);
+        const int nb = pmlp_nb_for(p->policy->hidden), ks = pmlp_ks_for(2 * p->nvars * p->k);
+#define BBX_BPOL(NBV, KSV) hipLaunchKernelGGL((bbx_binom_policy_kernel<W, NBV, KSV>), dim3(blocks), dim3(threads), lds, stream, q, *p->policy)
+        if (ks == 6) { if (nb == 2) BBX_BPOL(2, 6); else BBX_BPOL(4, 6); }
+        else if (W == 4 && ks == 10) { if (nb == 2) BBX_BPOL(2, 10); else BBX_BPOL(4, 10); }
+        else return (int)hipErrorInvalidValue;             // (bbx_api.cpp admits only the built-in shapes)
+#undef BBX_BPOL
         return 0;
       }
     }

@@ -184,9 +184,11 @@ int bbx_policy_step_device(bbx_batch* b, const float* d_prepared, int hidden, co
  * d_rows[t][e] are not written) and its row count to d_rows[t][e], evaluates the policy, draws the action with d_u[t][e]
  * -> d_actions[t][e], d_logprobs[t][e], takes the step -> d_rewards[t][e], d_dones[t][e]; finished episodes restart
  * (auto-reset).  All per-step arrays are [nsteps][batch]; d_rewards / d_dones / d_rows / d_obs may be null.  Built into the
- * register/LDS-resident class (<= 3 variables, binomial ideals, k = 2, accounting off, 33..128 hidden units); other
- * batches: BBX_E_UNSUPPORTED (use bbx_policy_step_device).  Environments that outgrow that class inside the rollout
- * (|G| > 128 or |P| > 256) are continued, policy included, by the HBM-resident kernel launched right behind.
+ * binomial kernel classes (binomial ideals in up to 7 variables, 2nk <= 12 observation columns — <= 20 with more than 3
+ * variables —, accounting off, 33..128 hidden units); other batches: BBX_E_UNSUPPORTED (use bbx_policy_step_device).
+ * 3 variables with k = 2 run in the register/LDS-resident kernel; environments that outgrow it inside the rollout
+ * (|G| > 128 or |P| > 256) are continued, policy included, by the HBM-resident kernel launched right behind, which is
+ * also the rollout kernel of every other admitted shape.
  * Batches whose ideals come from the host-side queue (BBX_HOST_GEN, sort_input with more than 16 generators) must hold
  * enough queued ideals for the episodes that end inside the launch (bbx_caps.queue_slots, bbx_prefetch): the host cannot
  * refill in the middle of a launch, and an environment left waiting makes bbx_sync report BBX_E_CAPACITY.
