@@ -4,11 +4,13 @@ device, replacing the per-step host round trip of the reference's agents.
     PMLPPolicy                 ParallelMultilayerPerceptron           networks.py:522-571 (:49-95, :414-460)
     discount_rewards, compute_advantages                              pg.py:20-76
     DeviceTrajectoryBuffer     TrajectoryBuffer (store/finish/get)    pg.py:79-240
-    run_rollout                PGAgent.run_episode(s)                 pg.py:451-503
+    run_rollout                PGAgent.run_episode(s)                 pg.py:451-503   (one library call per vector step)
+    run_rollout_fused          the same with the policy INSIDE the step kernel, 64 vector steps per launch
 
-PyTorch is the plumbing here (device memory, autograd for training); the per-step policy evaluation + sampling of the
-default one-hidden-layer network runs in a hand-written HIP kernel of libbbx (bbx_pmlp_act) fed by the padded
-observation block the step kernel leaves in HBM; deeper networks take the torch path.  Actions never visit the host.
+PyTorch is the plumbing here (device memory, autograd for training); the policy evaluation + sampling of the default
+one-hidden-layer network runs in hand-written HIP: on the matrix cores, either as a kernel of its own fed by the padded
+observation block (bbx_pmlp_act), in front of the step in the same launch (bbx_policy_step_device), or inside the step
+loop (bbx_policy_rollout_device); deeper networks take the torch path.  Actions never visit the host.
 """
 import ctypes as C
 
