@@ -76,6 +76,11 @@ def main():
         raise SystemExit("--gpus and --steps must be positive, --warmup non-negative")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))               # nothing has touched the GPU in this process
+    # Exactly ONE line goes to stdout: whatever libraries print there from native code (gloo announces its rendezvous on
+    # stdout) is sent to stderr for the rest of the run, and the result line is written to the saved descriptor.
+    sys.stdout.flush()
+    out_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -241,8 +246,8 @@ def main():
             "roofline": roof,
             "cpu_baseline": cpu,
         }
-        print(json.dumps(out))
         sys.stdout.flush()
+        os.write(out_fd, (json.dumps(out) + "\n").encode())
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
