@@ -410,7 +410,7 @@ __device__ __noinline__ void wide_leader_trace(const BbxParams* pp, BBX_AS3 Wide
   }
 }
 
-template <int W, bool TRACE, bool LAZY>
+template <int W, bool TRACE, bool LAZY, bool ACCT = !LAZY>
 __device__ __forceinline__ void wide_body(char* smem) {
 #ifdef BBX_PROF_BUILD
   unsigned long long wprof[6] = {0, 0, 0, 0, 0, 0}, wcnt[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -834,7 +834,7 @@ __device__ __forceinline__ void wide_body(char* smem) {
       }
       if (TRACE && p.trace != nullptr && leader) wide_leader_trace<W>(&wide_params(), x.ctl, env, nP, nG, nG_before, action, done ? 1 : 0, reward);
       if (x.tid == 0) {                                                       // bookkeeping (single writer)
-        if (!LAZY) st->alg_bytes += step_bytes;                                // (the accumulator hides the canonical length of h)
+        if (ACCT && !LAZY) st->alg_bytes += step_bytes;                        // (the accumulator hides the canonical length of h)
         st->last_reward = reward;
         if (p.value_mode) { double vr = st->vret, vd = st->vdisc; value_accumulate(vr, vd, reward, p.gamma); st->vret = vr; st->vdisc = vd; }
         st->total_steps += 1; st->total_adds += 1 + nsteps_red; st->episode_steps += 1; st->steps_done += 1;
@@ -882,16 +882,24 @@ __device__ __forceinline__ void wide_body(char* smem) {
 #undef WIDE_SACC
 }
 
-// LAZY = false: the accounting variant (h eagerly merged every round: its exact length enters the algorithmic bytes);
-// LAZY = true: the lean variant (bbx_accounting(b, 0)) with the accumulator
+// LAZY = false: h eagerly merged every round — with ACCT its exact length enters the algorithmic bytes (the accounting
+// variant), without it this is the lean kernel of the ordering strategies (First / Degree / Normal / Sugar and their
+// reversals: runs in which h stays short, where the accumulator's bookkeeping is pure overhead: 6.2 s instead of 7.4 s
+// for the single cyclic-7 run to completion).
+// LAZY = true: the lean variant with the accumulator (random and external agents: h grows long; 2x at cyclic-7 random).
 template <int W, bool TRACE, bool LAZY>
 __global__ __launch_bounds__(512, 4) void bbx_wide_kernel(BbxParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   wide_body<W, TRACE, LAZY>(smem);
 }
+template <int W>
+__global__ __launch_bounds__(512, 4) void bbx_wide_eager_kernel(BbxParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  wide_body<W, false, false, false>(smem);
+}
 // the same code for batches of at most one workgroup per CU (two waves per SIMD): no 128-register cap, no spills
-template <int W, bool LAZY>
+template <int W, bool LAZY, bool ACCT>
 __global__ __launch_bounds__(512, 2) void bbx_wide_kernel_1cu(BbxParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  wide_body<W, false, LAZY>(smem);
+  wide_body<W, false, LAZY, ACCT>(smem);
 }
