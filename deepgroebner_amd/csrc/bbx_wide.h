@@ -54,6 +54,7 @@ struct __attribute__((aligned(16))) WideCtl {             // LDS control block (
   int wfound[2][WNWMAX];                                  // per-wave first divisor of a scan chunk (absent waves: INT_MAX)
   int wcount[2][WNWMAX];                                  // per-wave output count of a merge tile (absent waves: 0)
   int wend[2][WNWMAX][2];                                 // per-wave last merge-path boundary of a tile
+  int wany[2][WNWMAX];                                    // per-wave mask of scan candidates with a divisor (absent waves: 0)
   int bc[16];                                             // values the leader wave publishes to the workgroup
   WideCold st;
 };
@@ -316,6 +317,33 @@ __device__ int wide_find_divisor(const WideTable<W>& R, int rcl_, const Mono<W>*
   return -1;
 }
 
+// Which of the nc <= 4 monomials c[] have a divisor among the reducers at all?  (bit k of the result.)  One pass over the
+// table and ONE exchange for all of them: a run of irreducible terms — terms that go to the remainder one after the
+// other, buchberger.cpp:41-44 — costs one scan per four terms instead of one each.
+template <int W>
+__device__ __forceinline__ int wide_reducible_mask(const WideTable<W>& R, int rcl_, const Mono<W>* slm, int nG_, const Mono<W> (&c)[4], int nc,
+                                                   const WideCtx& x, int& par_any) {
+  const int rcl = uni(rcl_), nG = uni(nG_);
+  int mine = 0;
+  for (int base = 0; base < nG; base += x.NT) {
+    const int k = base + x.tid;
+    if (k < nG) {
+      Mono<W> s;
+      if (k < rcl) s = R.mono(k); else s = slm[k];
+#pragma unroll
+      for (int j = 0; j < 4; j++) mine |= (j < nc && m_divides(s, c[j])) ? (1 << j) : 0;
+    }
+  }
+  int wmask = 0;
+#pragma unroll
+  for (int j = 0; j < 4; j++) wmask |= ballot64((mine >> j) & 1) ? (1 << j) : 0;
+  const int pa = par_any; par_any ^= 1;
+  if (x.lane == 0) x.ctl->wany[pa][x.wave] = wmask;
+  __syncthreads();
+  const bbx_i32x4 a0 = *(BBX_AS3 bbx_i32x4*)&x.ctl->wany[pa][0], a1 = *(BBX_AS3 bbx_i32x4*)&x.ctl->wany[pa][4];
+  return uni(a0.x | a0.y | a0.z | a0.w | a1.x | a1.y | a1.z | a1.w);
+}
+
 // lead-monomial observation (buchberger.cpp:354-370, 391-394), all threads: one item = one monomial slot of the matrix
 // kernel arguments are re-read from the kernarg segment where they are used, through a pointer the optimiser cannot see
 // through (constant address space + uniform address = s_load from the scalar cache): otherwise every field is loaded at
@@ -421,6 +449,7 @@ __device__ __forceinline__ void wide_body(char* smem) {
   x.tid = (int)threadIdx.x; x.lane = x.tid & (WAVE - 1); x.wave = uni(x.tid / WAVE);
   x.NT = uni((int)blockDim.x); x.NW = x.NT / WAVE;
   x.par_found = x.par_count = x.par_end = 0;
+  int par_any = 0;                                         // (eager variants only: the run scan's exchange slot)
 #ifdef BBX_PROF_BUILD
   x.prof_trips = 0;
 #endif
@@ -466,7 +495,7 @@ __device__ __forceinline__ void wide_body(char* smem) {
       if (p.set_budget) { st->rollout_pos = 0; st->done_last = 0; st->vret = 0.0; st->vdisc = 1.0; st->obs_trunc = 0; }
     }
   }
-  if (x.tid < 2 * WNWMAX) { (&x.ctl->wfound[0][0])[x.tid] = 0x7fffffff; (&x.ctl->wcount[0][0])[x.tid] = 0; }
+  if (x.tid < 2 * WNWMAX) { (&x.ctl->wfound[0][0])[x.tid] = 0x7fffffff; (&x.ctl->wcount[0][0])[x.tid] = 0; (&x.ctl->wany[0][0])[x.tid] = 0; }
   __syncthreads();
   bool table_dirty = true;
   int rcl = 0;                                                                // reducers staged in LDS
@@ -763,6 +792,40 @@ __device__ __forceinline__ void wide_body(char* smem) {
           rsug = d > rsug ? d : rsug;
           rn++;
           WCOUNT(13, 1);
+          // A run of irreducible terms (eager variants: under the ordering strategies a term that goes to r is usually
+          // followed by more; with the accumulator variant's random-agent workloads the extra scan was measured to cost
+          // 15 %): while the next terms of h sit in LDS as keys, four of them are tested per scan; the leading irreducible
+          // ones move to r together, the first reducible one is left to the next round.
+          while (!LAZY && in_lds && (W == 2 || hsug <= 255) && hn - hoff >= 2 && rn + 4 <= maxT) {
+            const LdsKeys Hc = T.off(cur * HC);
+            const int nc = hn - hoff < 4 ? hn - hoff : 4;
+            Mono<W> cm[4]; uint64_t ck[4]; uint32_t cc[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+              const int at = hoff + (j < nc ? j : 0);
+              ck[j] = Hc.key(at); cc[j] = Hc.coef(at);
+              cm[j] = wide_unkey<W>(ck[j]);
+#pragma unroll
+              for (int q = 0; q < W; q++) cm[j].w[q] = (uint32_t)uni((int)cm[j].w[q]);
+            }
+            const int red = wide_reducible_mask<W>(R, rcl, slm_g, nG, cm, nc, x, par_any);
+            int mv = red ? __builtin_ctz((unsigned)red) : 4;                  // leading irreducible candidates
+            mv = mv < nc ? mv : nc;
+            if (mv == 0) break;
+            if (rn - rflushed + mv > WRB) flush_r();
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+              if (j < mv) {
+                if (x.tid == 0) RB.put(rn - rflushed + j, ck[j], cc[j]);
+                const int dj = (int)m_deg(cm[j]);
+                rsug = dj > rsug ? dj : rsug;
+                step_bytes += 8LL * nG + 12LL * (2 * ((hn - hoff - 1 - j) + 1) - 1);
+              }
+            }
+            rn += mv; hoff += mv;
+            WCOUNT(13, mv);
+            if (mv < nc) break;
+          }
           WSTAMP(3);
           continue;
         }
