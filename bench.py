@@ -13,13 +13,14 @@ finished episodes draw their next ideal on the device).  Workload = BASELINE.jso
 Measurement protocol (so that the line means the same at --steps 20 and at --steps 1024):
   * pre-roll: every environment runs `preroll_steps` (>= 256) untimed steps first, so that the batch is in its steady
     state (a mix of episode phases) rather than all environments in their first episode;
-  * W warm-up steps (one launch), then one calibration launch of K steps;
-  * timed region: R back-to-back launches of K steps each (`repeats`; R is chosen so that the region lasts >= 50 ms),
+  * W warm-up steps (one launch), then eight chained calibration launches of K steps (untimed);
+  * timed region: R back-to-back launches of K steps each (`repeats`; R is chosen so that the region lasts >= 60 ms),
     enqueued asynchronously on one stream, bracketed by barrier + synchronize on both sides; `ms_per_step` is the
     region's wall time / (R*K), `value` = batch * R * K / wall time (max over ranks);
   * `roofline.kernel_ms_per_launch` = HIP-event time of the region on the launch stream / R.
 
-Prints ONE JSON line on rank 0 with `roofline` and `cpu_baseline` objects.  With --gpus N > 1 and no launcher
+Prints ONE JSON line on rank 0 with `roofline` and `cpu_baseline` objects (the only thing that reaches stdout: everything
+else, native libraries' chatter included, is sent to stderr).  With --gpus N > 1 and no launcher
 environment, the ranks are started here as fresh child processes (before anything touches the GPU).
 """
 import argparse
@@ -49,7 +50,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=64)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--dist", default=DIST)
-    ap.add_argument("--repeats", type=int, default=0, help="launches of K steps in the timed region (0 = enough for >= 50 ms)")
+    ap.add_argument("--repeats", type=int, default=0, help="launches of K steps in the timed region (0 = enough for >= 60 ms)")
     ap.add_argument("--preroll", type=int, default=PREROLL)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--generic-kernel", action="store_true",
