@@ -116,7 +116,7 @@ struct bbx_batch {
   // small batches (the single-environment drop-in): the kernels read the actions from and write their outputs and the
   // observation straight into pinned host memory — no copy calls on the latency path, one stream synchronisation per step
   bool zero_copy = false, zc_active = false;
-  bool poll_active = false; int poll_seq = 0; unsigned polled_launches = 0;                   // the launch in flight signals completion through h_io (done_seq)
+  bool poll_active = false; int poll_seq = 0, poll_misses = 0; unsigned polled_launches = 0;                   // the launch in flight signals completion through h_io (done_seq)
   char* zc_io_dev = nullptr; int32_t* zc_act_dev = nullptr;     // device-side addresses of h_io / h_act
   int32_t* h_zobs = nullptr; int32_t* zc_obs_dev = nullptr; size_t zobs_rows_cap = 0;
   // ragged observations (bbx_step_obs): device offsets [B+1] + packed rows, and their pinned mirror handed to the caller
@@ -332,7 +332,7 @@ int enqueue(bbx_batch* b, const BbxParams& p0, bool resume, hipStream_t stream) 
   }
   // a host-driven zero-copy step whose only kernel is the hand-tuned one: the host spins on the status words in pinned
   // memory instead of waiting for the runtime's completion signal (read_lite)
-  b->poll_active = !resume && nk == 1 && kinds[0] == 3 && b->zc_active && p.lite != nullptr && !b->timing && !getenv("BBX_NO_POLL");
+  b->poll_active = !resume && nk == 1 && kinds[0] == 3 && b->zc_active && p.lite != nullptr && !b->timing && b->poll_misses < 3 && !getenv("BBX_NO_POLL");
   if (b->poll_active) { b->poll_seq = (b->poll_seq % 16000) + 1; p.done_seq = b->poll_seq; } else p.done_seq = 0;
   for (int i = 0; i < nk; i++) {
     if (resume) { p.set_budget = 0; p.pass = 1; }
@@ -380,7 +380,12 @@ int alloc_io(bbx_batch* b, int batch) {
   b->d_rewards = (double*)(b->d_out + (size_t)batch * 16);
   b->d_rows = (int32_t*)(b->d_out + (size_t)batch * 24);
   b->d_dones = (uint8_t*)(b->d_out + (size_t)batch * 28);
-  HIPCHK(hipHostMalloc((void**)&b->h_io, b->io_bytes, hipHostMallocDefault));
+  // (the block the step kernels write their outputs and status words to in zero-copy launches, and the host may spin on:
+  // fine-grained, so that device writes are visible while the kernel is still running)
+  if (hipHostMalloc((void**)&b->h_io, b->io_bytes, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) {
+    (void)hipGetLastError();
+    HIPCHK(hipHostMalloc((void**)&b->h_io, b->io_bytes, hipHostMallocDefault));
+  }
   HIPCHK(hipHostMalloc((void**)&b->h_act, (size_t)batch * sizeof(int32_t), hipHostMallocDefault));
   memset(b->h_io, 0, b->io_bytes);
   b->zero_copy = batch <= 8 && !getenv("BBX_NO_ZERO_COPY");
@@ -402,10 +407,11 @@ int read_lite(bbx_batch* b, hipStream_t stream) {
     for (int spins = 0;; spins++) {
       bool all = true;
       for (int e = 0; e < b->B; e++) all = all && (((uint32_t)w[(size_t)e * 4]) >> 17) == (uint32_t)b->poll_seq;
-      if (all) { seen = true; break; }
+      if (all) { seen = true; b->poll_misses = 0; break; }
       if ((spins & 255) == 255 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
     }
     std::atomic_thread_fence(std::memory_order_acquire);
+    if (!seen) b->poll_misses++;                  // (three in a row: the writes do not arrive early on this system; stop spinning)
     b->poll_active = false;
   }
   // (every so often the runtime gets its wait as well, so that it can retire the commands it queued)
@@ -884,7 +890,7 @@ int bbx_step_obs(bbx_batch* b, const int32_t* actions, int auto_reset, double* r
   if (zc) {
     if (!b->h_zobs) {
       b->zobs_rows_cap = 128;
-      HIPCHK(hipHostMalloc((void**)&b->h_zobs, (size_t)b->B * b->zobs_rows_cap * cols * sizeof(int32_t), hipHostMallocDefault));
+      HIPCHK(hipHostMalloc((void**)&b->h_zobs, (size_t)b->B * b->zobs_rows_cap * cols * sizeof(int32_t), hipHostMallocCoherent | hipHostMallocMapped));
       HIPCHK(hipHostGetDevicePointer((void**)&b->zc_obs_dev, b->h_zobs, 0));
     }
   } else {
@@ -921,7 +927,7 @@ int bbx_step_obs(bbx_batch* b, const int32_t* actions, int auto_reset, double* r
       while (ncap < (size_t)maxr) ncap *= 2;
       if (zc) {
         (void)hipHostFree(b->h_zobs); b->h_zobs = nullptr;
-        HIPCHK(hipHostMalloc((void**)&b->h_zobs, (size_t)b->B * ncap * cols * sizeof(int32_t), hipHostMallocDefault));
+        HIPCHK(hipHostMalloc((void**)&b->h_zobs, (size_t)b->B * ncap * cols * sizeof(int32_t), hipHostMallocCoherent | hipHostMallocMapped));
         HIPCHK(hipHostGetDevicePointer((void**)&b->zc_obs_dev, b->h_zobs, 0));
         b->zobs_rows_cap = ncap;
       } else {
