@@ -1604,7 +1604,11 @@ extern "C" int bbx_launch_step(const BbxParams* p, int kind, int envs_per_block,
     if (const char* ev = getenv("BBX_WIDE_EAGER")) lazy = !q.accounting && ev[0] == '0';
     const bool acct = q.accounting != 0;
     bool one_per_cu = false;
-    if (q.wide_hc > 0) { q.wide_hc = (q.wide_hc + 7) & ~7; q.wide_fc = q.wide_hc; q.wide_rc = q.wide_hc; q.wide_sc = lazy ? q.wide_hc : 0; }
+    if (q.wide_hc > 0) {                                   // forced capacities (tests, experiments): as asked, as far as 160 KB go
+      q.wide_hc = (q.wide_hc + 7) & ~7;
+      while (q.wide_hc > 8 && wide_lds_bytes(W_, q.wide_hc, q.wide_hc, q.wide_hc, lazy ? q.wide_hc : 0) > 160u * 1024u) q.wide_hc -= 8;
+      q.wide_fc = q.wide_hc; q.wide_rc = q.wide_hc; q.wide_sc = lazy ? q.wide_hc : 0;
+    }
     else {
       static int ncu = 0;
       if (!ncu) { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount; if (ncu <= 0) ncu = 256; }

@@ -460,7 +460,8 @@ def test_headline_kernel_variant_vs_oracle():
 
 
 @pytest.mark.parametrize("wide,lds_terms,lean", [(0, 0, 0), (-1, 0, 0), (3, 0, 0), (8, 256, 0), (5, 1000, 0),
-                                                 (0, 0, 1), (8, 256, 1), (4, 64, 1), (5, 1000, 1)])
+                                                 (0, 0, 1), (8, 256, 1), (4, 64, 1), (5, 1000, 1),
+                                                 (0, 3000, 0), (0, 4096, 1)])     # (more than 160 KB of LDS asked for: clamped)
 def test_long_polynomials_cyclic7_all_merge_paths(wide, lds_terms, lean):
     """cyclic-7 far enough into an episode that polynomials have hundreds to thousands of terms: exercises the
     merge-path tiled merge of the general class (one wave per environment, wide = -1) and the wide class (one
