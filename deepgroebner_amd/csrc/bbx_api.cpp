@@ -89,7 +89,7 @@ struct bbx_gen {
 struct bbx_batch {
   int B = 0, device = 0, k = 1, nvars = 0, W = 2;
   int elim = 0, rewards = 0, sort_input = 0, sort_reducers = 1;
-  bool fixed = false, binom = false;
+  bool fixed = false, binom = false, listed = false;   // listed: the ideals come from a caller's list (bbx_create_ideals)
   BbxLayout L{}, LL{};
   uint16_t* d_inv = nullptr;           // GF(32003) inverse table
   std::vector<std::unique_ptr<bbx::IdealGen>> gens;   // one per environment (one shared when fixed)
@@ -303,7 +303,7 @@ void fill_params(bbx_batch* b, BbxParams* p) {
   memset(p, 0, sizeof *p);
   p->recs = b->d_recs; p->L = b->L; p->LL = b->LL; p->B = b->B;
   p->q.words = b->d_q; p->q.env_stride = b->fixed ? 0 : b->nslots * b->slot_words; p->q.slot_words = b->slot_words;
-  p->q.nslots = b->nslots; p->q.fixed = b->fixed ? 1 : 0; p->q.tail = b->d_tail;
+  p->q.nslots = b->nslots; p->q.fixed = b->fixed ? 1 : 0; p->q.no_redraw = b->listed ? 1 : 0; p->q.tail = b->d_tail;
   p->elim = b->elim; p->rewards_mode = b->rewards; p->sort_reducers = b->sort_reducers; p->k = b->k; p->nvars = b->nvars;
   p->sort_input = (b->device_gen && b->sort_input) ? 1 : 0;
   p->trace = b->d_trace; p->trace_stride = b->trace_cap;
@@ -521,6 +521,7 @@ int create_common(std::unique_ptr<bbx::IdealGen> proto, int nvars_obs, int elimi
   b->B = batch; b->device = device; b->k = k;
   b->elim = elimination; b->rewards = rewards; b->sort_input = sort_input ? 1 : 0; b->sort_reducers = sort_reducers ? 1 : 0;
   b->fixed = proto->fixed();
+  b->listed = list != nullptr;
   b->nvars = nvars_obs > 0 ? nvars_obs : proto->nvars();
   // ring variables actually used: probe one ideal from a clone (does not disturb the prototype's stream)
   int maxvar = 0;
@@ -716,7 +717,7 @@ int bbx_copy(const bbx_batch* s, bbx_batch** out) {
   auto b = std::make_unique<bbx_batch>();
   b->B = s->B; b->device = s->device; b->k = s->k; b->nvars = s->nvars; b->W = s->W;
   b->elim = s->elim; b->rewards = s->rewards; b->sort_input = s->sort_input; b->sort_reducers = s->sort_reducers;
-  b->fixed = s->fixed; b->binom = s->binom; b->L = s->L; b->LL = s->LL; b->slot_words = s->slot_words; b->nslots = s->nslots;
+  b->fixed = s->fixed; b->listed = s->listed; b->binom = s->binom; b->L = s->L; b->LL = s->LL; b->slot_words = s->slot_words; b->nslots = s->nslots;
   b->h_q = s->h_q; b->h_tail = s->h_tail; b->h_head = s->h_head; b->q_dirty = true;
   b->wide = s->wide; b->wide_terms = s->wide_terms; b->accounting = s->accounting; b->staged = s->staged; b->fast = s->fast; b->envs_per_block = s->envs_per_block;
   if (s->device_gen) {

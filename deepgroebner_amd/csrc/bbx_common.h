@@ -94,6 +94,8 @@ struct BbxQueue {
   uint32_t slot_words;
   uint32_t nslots;
   uint32_t fixed;
+  uint32_t no_redraw;       // ideal lists (bbx_create_ideals): an ideal whose pair set starts empty IS the episode (buchberger() of it
+                            // returns at once, make_strat.cpp:62-66); BuchbergerEnv::reset would draw another (buchberger.cpp:313-314)
   const int32_t* tail;      // [B] ideals produced so far per environment (host-written)
 };
 

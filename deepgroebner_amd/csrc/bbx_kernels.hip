@@ -911,7 +911,7 @@ __device__ bool wave_reset(Env<W>& e, const BbxParams& p, const BbxLayout& L, in
     }
     if (!p.q.fixed) q_head++;
     if (nP != 0) return true;                  // 313-314: redraw while the pair set is empty
-    if (p.q.fixed) return true;                // a fixed ideal with no pairs can never change
+    if (p.q.fixed || p.q.no_redraw) return true;   // a fixed ideal with no pairs can never change; a listed one is its own (empty) run
   }
 }
 

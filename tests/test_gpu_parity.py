@@ -516,6 +516,26 @@ def test_strategy_stats_like_make_strat():
     assert got[0].tolist() == [69, 41, 1442]                  # cyclic-5, Degree
 
 
+def test_strategy_stats_of_ideals_without_pairs():
+    """buchberger(F) of an ideal whose generators leave no pair (coprime lead monomials, a single generator) returns at once
+    with zero statistics (buchberger.cpp:252-262); in a list such an ideal is its own finished run — BuchbergerEnv::reset's
+    redraw (buchberger.cpp:313-314) has no say there — and the ideals next to it are not affected."""
+    from deepgroebner_amd import strategy_stats
+    bo = ffi.load("bo")
+    x, y, z = (1, 0, 0), (0, 1, 0), (0, 0, 1)
+    coprime = [[(1, x), (5, (0, 0, 0))], [(1, y), (7, (0, 0, 0))]]
+    single = [[(1, (2, 1, 0)), (3, z)]]
+    g = bo.generator("3-8-5-weighted"); g.seed(11)
+    others = [[[(c, e[:3]) for c, e in f] for f in g.next()] for _ in range(2)]
+    ideals = [coprime, others[0], single, others[1], coprime]
+    for strategy in ("degree", "first", "spice"):
+        got = strategy_stats(ideals, strategy)
+        for n, F in enumerate(ideals):
+            _, st = bo.buchberger(F, selection=strategy, want_basis=False)
+            assert got[n].tolist() == [st["zero_reductions"], st["nonzero_reductions"], st["polynomial_additions"]], (strategy, n)
+        assert got[0].tolist() == [0, 0, 0] and got[2].tolist() == [0, 0, 0] and got[4].tolist() == [0, 0, 0]
+
+
 def test_strategy_stats_reversed_and_seeded_random():
     """The remaining SelectionType values of make_strat.cpp:49-59: Last / Codegree / Strange / Spice (maximum instead
     of minimum, buchberger.cpp:207-240) and Random drawn from std::default_random_engine seeded per run
