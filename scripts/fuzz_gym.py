@@ -1,0 +1,83 @@
+"""Randomised parity sweep of the host-stepped (Gym-style) surface (test infrastructure, GPU box): VecLeadMonomialsEnv.reset /
+step / masked reset / auto-reset and the single-environment classes with uniformly random actions, every observation matrix,
+reward and done flag against the CPU restatement's environment objects.   python scripts/fuzz_gym.py [ROUNDS] [SEED]"""
+import os, sys, random, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from deepgroebner_amd import CLeadMonomialsEnv, LeadMonomialsEnv, VecLeadMonomialsEnv
+from oracle import ffi
+
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+bo = ffi.load("bo")
+t0 = time.time()
+
+
+def fail(msg):
+    print("MISMATCH " + msg); sys.exit(1)
+
+
+for it in range(rounds):
+    n = rng.choice([2, 3, 3, 3, 4, 5, 6, 8])
+    if rng.random() < 0.7:
+        dist = "%d-%d-%d-%s" % (n, rng.randint(2, 10 if n <= 3 else 5), rng.randint(2, 8 if n <= 3 else 4), rng.choice(["uniform", "weighted", "maximum"]))
+    else:
+        dist = "%d-%d-%d-%s-uniform" % (min(n, 5), rng.randint(2, 3), rng.randint(2, 3), rng.choice(["0.3", "0.5"]))
+    k = rng.choice([1, 2, 3])
+    B = rng.choice([1, 1, 2, 5, 9, 40])                  # (<= 8: the zero-copy path with status-word polling)
+    T = rng.choice([20, 60, 150]) if dist.count("-") == 3 and n <= 3 else rng.choice([10, 30])
+    elim = rng.choice(["gebauermoeller", "gebauermoeller", "lcm", "none"])
+    rewards = rng.choice(["additions", "reductions"])
+    auto = rng.random() < 0.5
+    caps = rng.choice([None, None, {"lds_max_basis": 16}, {"lds_max_basis": -1}, {"general_class": 1}])
+    seed0 = rng.randint(0, 10 ** 6)
+    arng = np.random.default_rng(seed0)
+    tag = "%s k=%d B=%d T=%d elim=%s rewards=%s auto=%d caps=%s seed0=%d" % (dist, k, B, T, elim, rewards, auto, caps, seed0)
+    try:
+        env = VecLeadMonomialsEnv(dist, B, elim, rewards, False, True, k, 0, caps, "python")
+        env.seed(np.arange(B) + seed0)
+        oracles = []
+        for e in range(B):
+            o = bo.env(dist, elimination=elim, rewards=rewards); o.seed(seed0 + e); o.reset(); oracles.append(o)
+        obs = env.reset()
+        for t in range(T):
+            for e in range(B):
+                if not np.array_equal(obs[e], oracles[e].obs(k)):
+                    fail(tag + ": observation of env %d at step %d" % (e, t))
+            acts = np.array([arng.integers(0, max(1, oracles[e].nP)) for e in range(B)], dtype=np.int32)
+            live = [oracles[e].nP > 0 for e in range(B)]
+            if not any(live):
+                break
+            if auto:
+                obs, r, d, _ = env.step(acts, auto_reset=True)
+            else:
+                obs, r, d, _ = env.step(acts)
+            mask = np.zeros(B, dtype=np.uint8)
+            for e in range(B):
+                if not live[e]:
+                    continue
+                want_r = oracles[e].step(int(acts[e]))
+                done = oracles[e].nP == 0
+                if r[e] != want_r or bool(d[e]) != done:
+                    fail(tag + ": reward/done of env %d at step %d: device (%s, %s) oracle (%s, %s)" % (e, t, r[e], d[e], want_r, done))
+                if done:
+                    if auto:
+                        oracles[e].reset()
+                    elif arng.random() < 0.7:
+                        mask[e] = 1
+            if not auto and mask.any():
+                obs = env.reset(mask)
+                for e in np.flatnonzero(mask):
+                    oracles[e].reset()
+    except SystemExit:
+        raise
+    except Exception as ex:
+        msg = str(ex)
+        if "error -3" in msg:
+            print("capacity  %s: %s" % (tag, msg[:90])); continue
+        if "error -4" in msg or "error -5" in msg or "bad distribution" in msg:
+            print("generator %s: %s" % (dist, msg[:90])); continue
+        print("ERROR %s: %s" % (tag, msg[:300])); sys.exit(1)
+    print("ok " + tag)
+    del env
+print("fuzz_gym: %d rounds, %.0f s, no mismatch" % (rounds, time.time() - t0))
