@@ -333,7 +333,13 @@ int enqueue(bbx_batch* b, const BbxParams& p0, bool resume, hipStream_t stream) 
   // a host-driven zero-copy step whose only kernel is the hand-tuned one: the host spins on the status words in pinned
   // memory instead of waiting for the runtime's completion signal (read_lite)
   b->poll_active = !resume && nk == 1 && kinds[0] == 3 && b->zc_active && p.lite != nullptr && !b->timing && b->poll_misses < 3 && !getenv("BBX_NO_POLL");
-  if (b->poll_active) { b->poll_seq = (b->poll_seq % 16000) + 1; p.done_seq = b->poll_seq; } else p.done_seq = 0;
+  if (b->poll_active) {
+    b->poll_seq = (b->poll_seq % 16000) + 1; p.done_seq = b->poll_seq;
+    // the words the host is going to watch start out cleared: pinned memory is handed out uninitialised and may still hold
+    // the status words — sequence numbers included — of a handle that was destroyed
+    for (int e = 0; e < b->B; e++) ((volatile int32_t*)b->h_io)[(size_t)e * 4] = 0;
+    std::atomic_thread_fence(std::memory_order_release);
+  } else p.done_seq = 0;
   for (int i = 0; i < nk; i++) {
     if (resume) { p.set_budget = 0; p.pass = 1; }
     else if (i > 0) { p.set_budget = 0; p.pass = 1; }
@@ -386,6 +392,7 @@ int alloc_io(bbx_batch* b, int batch) {
     (void)hipGetLastError();
     HIPCHK(hipHostMalloc((void**)&b->h_io, b->io_bytes, hipHostMallocDefault));
   }
+  memset(b->h_io, 0, b->io_bytes);
   HIPCHK(hipHostMalloc((void**)&b->h_act, (size_t)batch * sizeof(int32_t), hipHostMallocDefault));
   memset(b->h_io, 0, b->io_bytes);
   b->zero_copy = batch <= 8 && !getenv("BBX_NO_ZERO_COPY");

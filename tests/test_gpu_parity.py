@@ -109,6 +109,33 @@ def test_gym_surface_single_env_vs_oracle():
             t += 1
 
 
+def test_short_lived_handles_reuse_pinned_memory_safely():
+    """Many small handles created, stepped and destroyed one after the other (what a hyper-parameter sweep or a test-suite
+    does): the host-stepped path of batches <= 8 watches status words in pinned memory, and pinned memory comes back from
+    the allocator with the words of the handle that owned it before — every step of every handle against the oracle."""
+    from deepgroebner_amd import VecLeadMonomialsEnv
+    bo = ffi.load("bo")
+    for rnd in range(40):
+        B, k = 1 + rnd % 3, 1 + rnd % 2
+        dist = ("3-6-3-uniform", "3-7-4-uniform", "3-20-10-weighted")[rnd % 3]
+        env = VecLeadMonomialsEnv(dist, batch=B, k=k)
+        env.seed(np.arange(B) + 500 + rnd)
+        oracles = []
+        for e in range(B):
+            o = bo.env(dist); o.seed(500 + rnd + e); o.reset(); oracles.append(o)
+        obs = env.reset()
+        for t in range(25):
+            for e in range(B):
+                assert np.array_equal(obs[e], oracles[e].obs(k)), (rnd, t, e)
+            acts = np.array([ffi.agent_hash(e + rnd, t) % max(1, oracles[e].nP) for e in range(B)], dtype=np.int32)
+            obs, r, d, _ = env.step(acts, auto_reset=True)
+            for e in range(B):
+                assert r[e] == oracles[e].step(int(acts[e])) and bool(d[e]) == (oracles[e].nP == 0), (rnd, t, e)
+                if oracles[e].nP == 0:
+                    oracles[e].reset()
+        del env
+
+
 def test_vec_step_matches_oracle_and_masked_reset():
     from deepgroebner_amd import VecLeadMonomialsEnv
     bo = ffi.load("bo")
