@@ -754,8 +754,13 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem, in
       // the host may be spinning on this word (done_seq): everything else this wave wrote — rewards, rows, the observation
       // block in host memory — has to be visible first
       const int seq = cz->done_seq;
-      if (seq) __threadfence_system();
-      *(int4*)(cz->lite + 4 * (size_t)env) = make_int4(status | (trunc_all ? BBX_LITE_OBS_TRUNC : 0) | (seq << 17), q_head, budget, nP);
+      int32_t* lw = cz->lite + 4 * (size_t)env;
+      const int word0 = status | (trunc_all ? BBX_LITE_OBS_TRUNC : 0) | (seq << 17);
+      if (seq) {                                       // the word the host watches goes last and alone, behind a system-scope fence
+        lw[1] = q_head; lw[2] = budget; lw[3] = nP;
+        __threadfence_system();
+        __hip_atomic_store(lw, word0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      } else *(int4*)lw = make_int4(word0, q_head, budget, nP);
     }
   }
 }
