@@ -1,6 +1,6 @@
 """Randomised parity sweep (test infrastructure, GPU box): random distribution strings, batch sizes, horizons, k and kernel
 capacities; every environment's counters and final state against the CPU restatement (oracle/, counter-hash agent).
-    python scripts/fuzz_parity.py [ROUNDS] [SEED]          (FUZZ_LARGE=1: batches of 1024 / 4096 environments)
+    python scripts/fuzz_parity.py [ROUNDS] [SEED]          (FUZZ_LARGE=1: batches of 1024 / 4096 environments; FUZZ_LONG=1: 10x horizons)
 Prints one line per case; exits non-zero at the first mismatch."""
 import os, sys, random, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -30,6 +30,8 @@ for it in range(rounds):
     for flag in ("consts", "homog", "pure"):
         if rng.random() < 0.15:
             dist += "-" + flag
+    if os.environ.get("FUZZ_LONG"):
+        T *= 10                                             # FUZZ_LONG=1: ten times the horizon
     k = rng.choice([1, 2, 2, 3])
     B = rng.choice([1024, 4096]) if os.environ.get("FUZZ_LARGE") else rng.choice([1, 3, 8, 33, 200])   # FUZZ_LARGE=1: full-size batches
     caps = rng.choice([None, None, {"lds_max_basis": 16}, {"lds_max_basis": -1}, {"general_class": 1}])
