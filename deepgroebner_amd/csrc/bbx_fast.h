@@ -129,6 +129,18 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem, in
   const int lane = lane_id();
   const int wave_in_block = uni((int)(threadIdx.x / WAVE));
   const int env = blockIdx.x * (blockDim.x / WAVE) + wave_in_block;
+  // POL: the prepared weights are the same at every step of the launch: the workgroup stages them in LDS once (behind the
+  // per-wave regions), every tile then reads them with ds_read instead of going to L1 / L2
+  typedef const __attribute__((address_space(3))) float* PolW;
+  PolW pol_w = nullptr;
+  if constexpr (POL > 0) {
+    const int nfl = (2 * 6 + 2) * 32 * POL + 4;
+    __attribute__((address_space(3))) float* wl_ = (__attribute__((address_space(3))) float*)(smem + (blockDim.x / WAVE) * (FLDS_BYTES + 4 * FP));
+    const float* wg = f_cold_policy()->wp;
+    for (int i = (int)threadIdx.x; i < nfl; i += (int)blockDim.x) wl_[i] = wg[i];
+    __syncthreads();                                     // (before any wave may leave)
+    pol_w = wl_;
+  }
   if (env >= p.B) return;
   char* grec = p.recs + (size_t)env * p.rec_bytes;
   BbxHdr* ghdr = (BbxHdr*)grec;
@@ -495,10 +507,10 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem, in
       const float uu = pol->u[tb];                           // (requested before the observation goes out)
       if (p.obs) { o3_toff = (size_t)pol_tt * (size_t)pol->obs_tstride; write_obs32(); obs_trunc |= nP > p.obs_rows ? 1 : 0; }
       if (lane == 0 && pol->rows_t) pol->rows_t[tb] = nP;
-      const float* wp = pol->wp;
+      const PolW wp = pol_w;
       const int plr = lane & 31, plk = lane >> 5;
       float* lg = (float*)(lbase + FLDS_BYTES);
-      const float b2 = wp[(size_t)(2 * 6 + 2) * 32 * POL];
+      const float b2 = wp[(2 * 6 + 2) * 32 * POL];
       const int pn = (p.obs && nP > p.obs_rows) ? p.obs_rows : nP;   // the rows the policy sees = the rows of the block
       for (int r0 = 0; r0 < pn; r0 += 32) {
         const int r = r0 + plr;
@@ -511,7 +523,7 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem, in
         float xa[6];
 #pragma unroll
         for (int s2 = 0; s2 < 6; s2++) xa[s2] = (float)ev[s2];
-        const float logit = pmlp_tile<POL, 6, 1>(xa, wp, plr, plk);
+        const float logit = pmlp_tile<POL, 6, 1, PolW>(xa, wp, plr, plk);
         if (plk == 0 && r < pn) lg[r] = logit + b2;
       }
       wave_sync();

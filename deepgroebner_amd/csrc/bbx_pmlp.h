@@ -94,12 +94,14 @@ __global__ void bbx_pmlp_prepare_kernel(const float* __restrict__ w1, const floa
 }
 // one tile: the logit (without b2) of row (lane & 31) from the lane's B operands xa[]; G unit blocks in flight together
 // (registers: 32 G + G KS)
-template <int NB, int KS, int G>
-__device__ __forceinline__ float pmlp_tile(const float (&xa)[KS], const float* __restrict__ wp, int lr, int lk) {
+// (WP: where the prepared weights live — `const float*` in memory, or an LDS pointer when a rollout kernel has staged them
+// once per launch)
+template <int NB, int KS, int G, class WP = const float*>
+__device__ __forceinline__ float pmlp_tile(const float (&xa)[KS], WP wp, int lr, int lk) {
   constexpr int HP = 32 * NB;
-  const float* b1p = wp + (size_t)2 * KS * HP;
-  const float* w2p = b1p + HP;
-  const float* wl = wp + (size_t)lk * HP + lr;              // my A-operand column: + 2 s HP + 32 nb
+  const WP b1p = wp + 2 * KS * HP;
+  const WP w2p = b1p + HP;
+  const WP wl = wp + lk * HP + lr;                          // my A-operand column: + 2 s HP + 32 nb
   float part = 0.f;
 #pragma clang loop unroll(disable)
   for (int g0 = 0; g0 < NB; g0 += G) {
@@ -111,12 +113,13 @@ __device__ __forceinline__ float pmlp_tile(const float (&xa)[KS], const float* _
       const int ub = (g0 + j) * 32 + 4 * lk;                 // + (v & 3) + 8 (v >> 2): the units of my accumulator registers
 #pragma unroll
       for (int q = 0; q < 4; q++) {
-        const bbx_f32x4 bq = *(const bbx_f32x4*)(b1p + ub + 8 * q);
-        acc[j][4 * q] = bq.x; acc[j][4 * q + 1] = bq.y; acc[j][4 * q + 2] = bq.z; acc[j][4 * q + 3] = bq.w;
-        wv[j][q] = *(const bbx_f32x4*)(w2p + ub + 8 * q);
+        const WP bp = b1p + ub + 8 * q, vp = w2p + ub + 8 * q;
+        acc[j][4 * q] = bp[0]; acc[j][4 * q + 1] = bp[1]; acc[j][4 * q + 2] = bp[2]; acc[j][4 * q + 3] = bp[3];   // (one 16-byte load)
+        bbx_f32x4 w4; w4.x = vp[0]; w4.y = vp[1]; w4.z = vp[2]; w4.w = vp[3];
+        wv[j][q] = w4;
       }
 #pragma unroll
-      for (int s2 = 0; s2 < KS; s2++) wa[j][s2] = wl[(size_t)2 * s2 * HP + (g0 + j) * 32];
+      for (int s2 = 0; s2 < KS; s2++) wa[j][s2] = wl[2 * s2 * HP + (g0 + j) * 32];
     }
 #pragma unroll
     for (int s2 = 0; s2 < KS; s2++)
