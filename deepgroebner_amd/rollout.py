@@ -5,7 +5,7 @@ device, replacing the per-step host round trip of the reference's agents.
     discount_rewards, compute_advantages                              pg.py:20-76
     DeviceTrajectoryBuffer     TrajectoryBuffer (store/finish/get)    pg.py:79-240
     run_rollout                PGAgent.run_episode(s)                 pg.py:451-503   (one library call per vector step)
-    run_rollout_fused          the same with the policy INSIDE the step kernel, 64 vector steps per launch
+    run_rollout_fused          the same with the policy INSIDE the step kernel, 256 vector steps per launch
 
 PyTorch is the plumbing here (device memory, autograd for training); the policy evaluation + sampling of the default
 one-hidden-layer network runs in hand-written HIP: on the matrix cores, either as a kernel of its own fed by the padded
@@ -189,7 +189,7 @@ class DeviceTrajectoryBuffer:
 
 
 @torch.no_grad()
-def run_rollout_fused(env, policy, nsteps, buffer=None, obs_rows=256, generator=None, chunk=64):
+def run_rollout_fused(env, policy, nsteps, buffer=None, obs_rows=256, generator=None, chunk=256):
     """run_rollout with the policy INSIDE the step kernel (bbx_policy_rollout_device): `chunk` vector steps per launch,
     environments never wait for each other between steps.  Per-step outputs land in the trajectory buffer's own arrays
     (no copies).  Raises BbxError (BBX_E_UNSUPPORTED) where the batch's kernel class has no built-in policy — callers

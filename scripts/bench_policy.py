@@ -26,7 +26,7 @@ ap.add_argument("--obs-rows", type=int, default=128)
 ap.add_argument("--store", action="store_true", help="also record the trajectory (actions, rewards, log-probabilities, dones) on the device")
 ap.add_argument("--per-step", action="store_true", help="one library call per vector step (bbx_policy_step_device) instead of the policy rollout "
                                                        "kernel (bbx_policy_rollout_device: --chunk steps per launch, policy inside the step loop)")
-ap.add_argument("--chunk", type=int, default=64)
+ap.add_argument("--chunk", type=int, default=256)
 ap.add_argument("--store-states", action="store_true", help="--store plus the observation block of every step")
 a = ap.parse_args()
 torch.manual_seed(0)
