@@ -28,7 +28,8 @@ class BbxError(RuntimeError):
 class Caps(C.Structure):
     _fields_ = [("max_basis", C.c_int32), ("max_pairs", C.c_int32), ("arena_terms", C.c_int32),
                 ("max_poly_terms", C.c_int32), ("queue_slots", C.c_int32), ("lds_max_basis", C.c_int32),
-                ("wide_waves", C.c_int32), ("general_class", C.c_int32), ("wide_lds_terms", C.c_int32)]
+                ("wide_waves", C.c_int32), ("general_class", C.c_int32), ("wide_lds_terms", C.c_int32),
+                ("no_growth", C.c_int32)]
 
 
 class TraceRec(C.Structure):
@@ -78,6 +79,7 @@ SIGNATURES = {
     "bbx_sync": (C.c_int, [_vp]),
     "bbx_stats": (C.c_int, [_vp, _vp]),
     "bbx_env_status": (C.c_int, [_vp, _vp]),
+    "bbx_capacities": (C.c_int, [_vp, _vp]),
     "bbx_state_sizes": (C.c_int, [_vp, C.c_int, _i32p, _i32p, _i32p]),
     "bbx_state_get": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     "bbx_reduced_basis": (C.c_int, [_vp, C.c_int, _i32p, _i32p, _vp, _vp, _vp]),

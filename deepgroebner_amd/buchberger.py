@@ -225,6 +225,12 @@ class VecLeadMonomialsEnv:
         _ffi.check(_ffi.lib().bbx_stats(self._h, _ffi.ptr(out)))
         return out
 
+    def capacities(self):
+        """Current per-environment capacities (they grow on demand unless caps['no_growth']) and how often they grew."""
+        out = np.zeros(5, dtype=np.int32)
+        _ffi.check(_ffi.lib().bbx_capacities(self._h, _ffi.ptr(out)))
+        return dict(zip(("max_basis", "max_pairs", "arena_terms", "max_poly_terms", "grown"), (int(v) for v in out)))
+
     def state(self, idx=0):
         """(basis, pairs, reducer_order): basis = list of (coefs[int32 n], exps[int32 n,8])."""
         nG, nP, nT = C.c_int32(), C.c_int32(), C.c_int32()

@@ -1,6 +1,6 @@
 // libbbx.so — host side of the C ABI declared in include/bbx.h.
 // Owns the device memory (environment records, ideal queues, output buffers), drives the HIP
-// kernels in bbx_kernels.hip and keeps the per-environment ideal generators (bbx_ideals.cpp).
+// kernels in bbx_*.hip and keeps the per-environment ideal generators (bbx_ideals.cpp).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -22,6 +22,7 @@
 extern "C" int bbx_launch_step(const BbxParams* p, int kind, int envs_per_block, hipStream_t stream);
 extern "C" int bbx_launch_clone(const char* src_recs, char* dst_recs, const BbxLayout* L, const int32_t* src, const int32_t* dst, int n,
                                 const uint32_t* seeds, int keep_counters, hipStream_t stream);
+extern "C" int bbx_launch_relayout(const char* src_recs, char* dst_recs, const BbxLayout* Ls, const BbxLayout* Ld, int B, hipStream_t stream);
 extern "C" int bbx_launch_gather_lite(const char* recs, uint32_t rec_bytes, int B, void* out, hipStream_t stream);
 extern "C" int bbx_launch_gather_hdr(const char* recs, uint32_t rec_bytes, int B, BbxHdr* out, hipStream_t stream);
 extern "C" int bbx_launch_scatter_queue(const uint32_t* stage, int n, uint32_t ring_words, uint32_t* q, int32_t* tail, hipStream_t stream);
@@ -146,6 +147,8 @@ struct bbx_batch {
   bool device_async = false;          // the launch in flight came through a *_device entry point (no host poll per step)
   bool obs_external = false;          // the launch in flight writes observations into a caller-owned block: rows cut for
                                       // lack of space are an error the caller must hear about (bbx_sync)
+  bool no_growth = false;             // bbx_caps.no_growth: the configured capacities are hard limits (BBX_E_CAPACITY)
+  int grow_events = 0;                // times the records were enlarged (bbx_capacities)
   bbx_batch() = default;
   bbx_batch(const bbx_batch&) = delete;
   bbx_batch& operator=(const bbx_batch&) = delete;
@@ -295,6 +298,7 @@ const char* status_name(int s) {
     case BBX_ST_DEG_OVERFLOW: return "degree above 65535";
     case BBX_ST_BAD_ACTION: return "action index outside [0, rows)";
     case BBX_ST_RUNAWAY: return "reduction did not terminate within 2^24 rounds";
+    case BBX_ST_POLY_LIMIT: return "a basis element with more than 65535 terms";
     default: return "unknown";
   }
 }
@@ -428,6 +432,68 @@ int read_lite(bbx_batch* b, hipStream_t stream) {
   return BBX_OK;
 }
 
+// Capacity is a performance cliff, not a failure (the reference's polynomials are heap vectors, polynomials.h:71-94, and
+// its basis and pair set grow without bound, buchberger.cpp:52-99): an environment whose next step does not fit its record
+// stops BEFORE that step (the kernels check every capacity ahead of the first persistent write, bbx_common.h) and reports
+// which array was full; here every such array doubles, all records move to the new layout (one kernel, live prefixes only)
+// and the launch is resumed.  `need`: bit s set = some environment reported status s.
+int grow_records(bbx_batch* b, unsigned need, int env, hipStream_t stream) {
+  uint32_t maxG = b->L.maxG, maxP = b->L.maxP, arena = b->L.arena, maxT = b->L.maxT;
+  const char* what = "";
+  if (need & (1u << BBX_ST_G_FULL)) {
+    what = status_name(BBX_ST_G_FULL);
+    if (maxG >= 65534u) return fail(BBX_E_CAPACITY, "environment %d: %s, and a basis cannot exceed 65534 elements (16-bit pair indices)", env, what);
+    maxG = std::min(65534u, maxG * 2u);
+  }
+  if (need & (1u << BBX_ST_P_FULL)) {
+    what = status_name(BBX_ST_P_FULL);
+    if (maxP >= (1u << 28)) return fail(BBX_E_CAPACITY, "environment %d: %s beyond 2^28 pairs", env, what);
+    maxP *= 2u;
+  }
+  if (need & (1u << BBX_ST_POLY_TOO_LONG)) {
+    what = status_name(BBX_ST_POLY_TOO_LONG);
+    if (b->binom || maxT >= (1u << 22)) return fail(BBX_E_CAPACITY, "environment %d: %s beyond 2^22 terms", env, what);
+    maxT *= 2u;
+  }
+  if (need & (1u << BBX_ST_ARENA_FULL)) { what = status_name(BBX_ST_ARENA_FULL); arena *= 2u; }
+  if (!b->binom) while (arena < 4u * maxT) arena *= 2u;     // every step wants room for one more element of up to maxT terms
+  if (!b->binom && arena > (1u << 27)) return fail(BBX_E_CAPACITY, "environment %d: %s beyond 2^27 terms", env, what);
+  // pairs of a Gebauer-Moeller step: at most |G| new ones
+  while (maxP < 2u * maxG) maxP *= 2u;
+  {                                                         // (the layout's offsets are 32-bit: size it in 64 bits first)
+    const uint64_t MW = 4ull * b->W;
+    const uint64_t est = b->binom ? 128ull + (5ull * MW + 17ull) * maxG + 4ull * maxP
+                                  : 128ull + (3ull * MW + 13ull) * maxG + 4ull * maxP + (MW + 2ull) * ((uint64_t)arena + 5ull * maxT);
+    if (est > 0xE0000000ull) return fail(BBX_E_CAPACITY, "environment %d: %s, and a record cannot exceed 3.5 GiB", env, what);
+  }
+  const BbxLayout NL = b->binom ? make_layout_binom(b->W, (int)maxG, (int)maxP) : make_layout(b->W, (int)maxG, (int)maxP, (int)arena, (int)maxT);
+  const size_t bytes = (size_t)b->B * NL.rec_bytes;
+  size_t freeb = 0, totalb = 0;
+  HIPCHK(hipStreamSynchronize(stream));
+  if (b->d_vrecs) {                                         // value() scratch is sized by the old layout: rebuilt on demand
+    void* old[] = {b->d_vrecs, b->d_vhdr, b->d_vsrc, b->d_vseeds, b->d_vvals};
+    for (void* q : old) (void)hipFree(q);
+    b->d_vrecs = nullptr; b->d_vhdr = nullptr; b->d_vsrc = nullptr; b->d_vseeds = nullptr; b->d_vvals = nullptr; b->vcap = 0;
+  }
+  HIPCHK(hipMemGetInfo(&freeb, &totalb));
+  if (bytes + (256u << 20) > freeb)
+    return fail(BBX_E_CAPACITY, "environment %d: %s, and the device has no room for larger records (%zu MiB needed, %zu MiB free)",
+                env, what, bytes >> 20, freeb >> 20);
+  char* nrecs = nullptr;
+  HIPCHK(hipMalloc((void**)&nrecs, bytes));
+  int lrc = bbx_launch_relayout(b->d_recs, nrecs, &b->L, &NL, b->B, stream);
+  if (lrc) { (void)hipFree(nrecs); return fail(BBX_E_DEVICE, "relayout launch failed: %s", hipGetErrorString((hipError_t)lrc)); }
+  HIPCHK(hipStreamSynchronize(stream));
+  HIPCHK(hipFree(b->d_recs));
+  b->d_recs = nrecs; b->L = NL;
+  b->last.recs = nrecs; b->last.L = NL;
+  b->grow_events++;
+  if (getenv("BBX_VERBOSE"))
+    fprintf(stderr, "[bbx] records enlarged (%s, environment %d): max_basis %u max_pairs %u arena_terms %u max_poly_terms %u, %zu MiB\n",
+            what, env, maxG, maxP, arena, maxT, bytes >> 20);
+  return BBX_OK;
+}
+
 // wait for the launch in flight; serve environments that ran out of queued ideals or outgrew the LDS class; surface
 // errors.  Whatever happens, the handle is left with nothing in flight: an error is reported once, not re-raised by
 // every later call, and environments that only needed service (STARVED / SPILL) have been served before the first
@@ -441,6 +507,7 @@ int finish(bbx_batch* b, hipStream_t stream) {
     rc = collect_events(b);
     if (rc) { b->in_flight = false; return rc; }
     bool again = false;
+    unsigned grow = 0; int grow_env = -1;
     for (int e = 0; e < b->B; e++) {
       const int st = b->h_lite[(size_t)e * 4] & 0xffff;
       if (st == BBX_ST_STARVED && !b->gen_error.empty() && !b->gen_error[e].empty() && b->h_tail[e] - b->h_head[e] <= 0) {
@@ -460,12 +527,23 @@ int finish(bbx_batch* b, hipStream_t stream) {
       }
       else if (st == BBX_ST_STARVED || st == BBX_ST_SPILL) again = true;
       else if (st == BBX_ST_BAD_ACTION) { if (err == BBX_OK) note(fail(BBX_E_ACTION, "environment %d: %s", e, status_name(st))); }
+      else if (bbx_st_capacity(st) && !b->no_growth) { grow |= 1u << st; if (grow_env < 0) grow_env = e; }
       else if (st != BBX_ST_OK && err == BBX_OK) {
         rc = read_headers(b, stream);
         if (rc) { b->in_flight = false; return rc; }
         note(fail(BBX_E_CAPACITY, "environment %d: %s (|G|=%d |P|=%d terms=%d)", e, status_name(st),
                   b->h_hdr[e].nG, b->h_hdr[e].nP, b->h_hdr[e].arena_used));
       }
+    }
+    if (grow) {                                       // enlarge what was full; the environments then take the step they stopped at
+      rc = grow_records(b, grow, grow_env, stream);
+      if (rc) { note(rc); break; }
+      if (b->policy_rollout) {                        // (its per-step arrays belonged to the caller's frame: cannot be resumed)
+        note(fail(BBX_E_CAPACITY, "environment %d could not finish its policy rollout (%s); the records have been enlarged, later rollouts have room",
+                  grow_env, status_name(__builtin_ctz(grow))));
+        break;
+      }
+      again = true;
     }
     if (!again) break;
     if (round > 100000) { note(fail(BBX_E_GENERATOR, "ideal queue starvation did not resolve")); break; }
@@ -570,6 +648,7 @@ int create_common(std::unique_ptr<bbx::IdealGen> proto, int nvars_obs, int elimi
   if ((b->fixed || list) && b->W <= 4 && !getenv("BBX_NO_WIDE")) b->wide = c.wide_waves > 0 ? std::min(8, c.wide_waves) : (c.wide_waves < 0 ? 0 : (batch <= 4096 ? 8 : 0));
   if (c.wide_lds_terms < 0 || c.wide_lds_terms > 4096) return fail(BBX_E_ARG, "wide_lds_terms out of range");
   b->wide_terms = c.wide_lds_terms;
+  b->no_growth = c.no_growth != 0;
   // LDS-resident class: small binomial environments work out of LDS for the whole launch; anything that
   // outgrows it continues in the HBM-resident pass of the same launch sequence
   b->staged = 0;
@@ -587,7 +666,7 @@ int create_common(std::unique_ptr<bbx::IdealGen> proto, int nvars_obs, int elimi
   b->L = b->binom ? make_layout_binom(b->W, c.max_basis, c.max_pairs)
                   : make_layout(b->W, c.max_basis, c.max_pairs, c.arena_terms, c.max_poly_terms);
   // random distributions: the ideals are drawn on the device (same seeded streams; see gen_binomial / gen_polynomial in
-  // bbx_kernels.hip) and the ideal queue shrinks to one unused slot.  sort_input: the device sorts up to 16 generators
+  // bbx_device.h) and the ideal queue shrinks to one unused slot.  sort_input: the device sorts up to 16 generators
   // (gen_sorted_rank; std::sort is a stable insertion sort up to there, beyond it the host's std::sort decides ties).  Not
   // for ideal lists.
   std::vector<uint32_t> gen_table;
@@ -726,6 +805,7 @@ int bbx_copy(const bbx_batch* s, bbx_batch** out) {
   b->elim = s->elim; b->rewards = s->rewards; b->sort_input = s->sort_input; b->sort_reducers = s->sort_reducers;
   b->fixed = s->fixed; b->listed = s->listed; b->binom = s->binom; b->L = s->L; b->LL = s->LL; b->slot_words = s->slot_words; b->nslots = s->nslots;
   b->h_q = s->h_q; b->h_tail = s->h_tail; b->h_head = s->h_head; b->q_dirty = true;
+  b->no_growth = s->no_growth;
   b->wide = s->wide; b->wide_terms = s->wide_terms; b->accounting = s->accounting; b->staged = s->staged; b->fast = s->fast; b->envs_per_block = s->envs_per_block;
   if (s->device_gen) {
     HIPCHK(hipMalloc((void**)&b->d_gen, s->gen_words * sizeof(uint32_t)));
@@ -1323,6 +1403,12 @@ int bbx_stats(bbx_batch* b, int64_t* out8) {
     o[0] = h.total_steps; o[1] = h.total_additions; o[2] = h.episodes; o[3] = h.zero_reductions; o[4] = h.status; o[5] = h.q_head;
     o[6] = h.alg_bytes; o[7] = h.nG;
   }
+  return BBX_OK;
+}
+
+int bbx_capacities(bbx_batch* b, int32_t* out5) {
+  if (!b || !out5) return fail(BBX_E_ARG, "null argument");
+  out5[0] = (int32_t)b->L.maxG; out5[1] = (int32_t)b->L.maxP; out5[2] = (int32_t)b->L.arena; out5[3] = (int32_t)b->L.maxT; out5[4] = b->grow_events;
   return BBX_OK;
 }
 

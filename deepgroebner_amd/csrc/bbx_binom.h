@@ -1,4 +1,4 @@
-// Binomial class of the step kernel (included by bbx_kernels.hip).
+// Binomial class of the step kernel (kernels; bbx_binom.hip holds the launcher).
 //
 // For the random binomial distributions (3-20-10-weighted, 5-10-5-uniform, ... ; reference
 // ideals.cpp:156-201) every basis element has at most two terms for the whole computation: an
@@ -13,7 +13,7 @@
 #pragma once
 
 #ifdef BBX_PROF_BUILD
-__device__ unsigned long long bbx_bin_prof_acc[32];
+static __device__ unsigned long long bbx_bin_prof_acc[32];
 #define BSTAMP(slot) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); bprof[slot] += t_ - blast; blast = t_; } while (0)
 #else
 #define BSTAMP(slot) do {} while (0)
@@ -313,7 +313,7 @@ __device__ __forceinline__ void binom_body(const BbxParams& p, char* smem, const
   if (status == BBX_ST_STARVED || status == BBX_ST_SPILL) status = BBX_ST_OK;
   double vret = ghdr->vret, vdisc = ghdr->vdisc;
   int obs_trunc = uni(ghdr->obs_trunc);
-  if (p.set_budget) { budget = p.nsteps; rollout_pos = 0; done_last = 0; vret = 0.0; vdisc = 1.0; obs_trunc = 0; }
+  if (p.set_budget) { budget = bbx_st_capacity(status) ? budget + p.nsteps : p.nsteps; rollout_pos = 0; done_last = 0; vret = 0.0; vdisc = 1.0; obs_trunc = 0; }   // (bbx_common.h: bbx_st_capacity)
   if (p.pass == 1 && !(status == BBX_ST_OK && (need_reset || (budget > 0 && nP > 0)))) return;
 
   BEnv<W> ge = benv_view<W>(grec, p.L);

@@ -1,4 +1,4 @@
-// Shared between the host side of libbbx (bbx_api.cpp) and the HIP kernels (bbx_kernels.hip).
+// Shared between the host side of libbbx (bbx_api.cpp) and the HIP kernels (bbx_*.hip, bbx_device.h).
 //
 // HBM layout
 // ----------
@@ -44,9 +44,20 @@ enum {
   BBX_ST_RUNAWAY = 9,       // a reduction exceeded 2^24 rounds (corrupt state guard; never seen in practice)
   BBX_ST_GEN_FAIL = 10,     // the ideal generator failed (no two distinct monomials after 1000 trials: the reference throws)
   BBX_ST_GEN_ZERO = 11,     // a random polynomial cancelled to zero (undefined in the reference)
+  BBX_ST_POLY_LIMIT = 12,   // a basis element would have more than 65535 terms (plen[] is 16 bits): a hard limit
   BBX_ST_SPILL = 8,         // transient: the state outgrew the LDS-resident class; the HBM-resident pass of the
                             // same launch sequence continues this environment
 };
+
+// Capacity statuses are not failures: the kernels leave the record consistent (the step that did not fit has not been
+// started: nothing persistent is modified before its last capacity check), the host enlarges the record layout
+// (bbx_api.cpp grow_records) and the environment continues.  A launch that finds an environment waiting like that adds
+// its steps to the environment's budget instead of replacing it, so no step is lost across asynchronous launches.
+static inline
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+int bbx_st_capacity(int st) { return st == BBX_ST_G_FULL || st == BBX_ST_P_FULL || st == BBX_ST_ARENA_FULL || st == BBX_ST_POLY_TOO_LONG; }
 
 // the status word of the `lite` block ({status, q_head, budget, |P|} per environment, polled by the host after a
 // launch) carries this flag on top of the status code: BbxHdr.obs_trunc != 0

@@ -1,4 +1,5 @@
-// Hand-written HIP for gfx950 (MI355X): the BuchbergerEnv step path.
+// Device code shared by the kernel classes of libbbx (gfx950 / MI355X): included by bbx_general.hip, bbx_binom.hip,
+// bbx_fast.hip, bbx_wide.hip and bbx_aux.hip.  Everything here is a template or an inline device function.
 //
 // One 64-lane wavefront owns one environment for the whole launch and runs
 // `nsteps` environment steps back to back:
@@ -20,6 +21,7 @@
 //  * kernel template STAGED keeps the whole environment record in LDS for the launch (small
 //    classes: 3-variable binomial ideals need ~6 KB); otherwise the record is worked on in HBM/L2.
 //  * no inter-workgroup communication at all: environments are independent.
+#pragma once
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include <stdint.h>
@@ -755,7 +757,7 @@ __device__ bool wave_add_poly(Env<W>& e, const BbxLayout& L, int& nG, int& nP, i
                               int elim, int sort_reducers, int* status, bool in_place = false) {
   const int lane = lane_id();
   if (nG >= (int)L.maxG) { *status = BBX_ST_G_FULL; return false; }
-  if (n > 65535) { *status = BBX_ST_POLY_TOO_LONG; return false; }       // plen[] is 16 bits
+  if (n > 65535) { *status = BBX_ST_POLY_LIMIT; return false; }          // plen[] is 16 bits
   if (arena_used + n > (int)L.arena) { *status = BBX_ST_ARENA_FULL; return false; }
   const int g = nG, off = arena_used;
   // in_place: the terms already sit at the arena's end (the wide class builds the remainder there)
@@ -1032,8 +1034,6 @@ __device__ __forceinline__ void value_accumulate(double& vret, double& vdisc, do
   vret = vret + term;
   vdisc = vdisc * gamma;
 }
-
-// ------------------------------------------------------------------ the step kernel
 // copy the live prefix of every persistent array between the HBM record and the LDS working copy
 template <int W>
 __device__ void stage_copy(const Env<W>& dst, const Env<W>& src, int nG, int nP, int nT) {
@@ -1044,617 +1044,4 @@ __device__ void stage_copy(const Env<W>& dst, const Env<W>& src, int nG, int nP,
   }
   for (int i = lane; i < nP; i += WAVE) dst.pairs[i] = src.pairs[i];
   for (int i = lane; i < nT; i += WAVE) { dst.am[i] = src.am[i]; dst.ac[i] = src.ac[i]; }
-}
-
-template <int W, bool STAGED, bool TRACE, bool PROF = false>
-__device__ __forceinline__ void step_body(const BbxParams& p, char* smem, unsigned long long* prof_out = nullptr) {
-  const int lane = lane_id();
-  unsigned long long ps[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // diagnostic build: cycles per phase
-  unsigned long long pl = PROF ? __builtin_amdgcn_s_memtime() : 0;
-#define GSTAMP(slot) do { if (PROF) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); ps[slot] += t_ - pl; pl = t_; } } while (0)
-  const int wave_in_block = uni((int)(threadIdx.x / WAVE));   // provably wave-uniform: record addresses live in SGPRs
-  const int env = (int)(blockIdx.x * (blockDim.x / WAVE) + wave_in_block);
-  if (env >= p.B) return;                       // whole wave exits together
-  char* grec = p.recs + (size_t)env * p.L.rec_bytes;
-  BbxHdr* ghdr = (BbxHdr*)grec;
-  const BbxLayout& L = STAGED ? p.LL : p.L;      // the layout this kernel works in
-
-  int nG = uni(ghdr->nG), nP = uni(ghdr->nP), arena_used = uni(ghdr->arena_used);
-  int status = uni(ghdr->status), need_reset = uni(ghdr->need_reset), q_head = uni(ghdr->q_head);
-  int t_agent = uni(ghdr->t), episode_steps = uni(ghdr->episode_steps);
-  int episodes = uni(ghdr->episodes), zero_red = uni(ghdr->zero_reductions);
-  long long total_steps = ghdr->total_steps, total_adds = ghdr->total_additions, alg_bytes = ghdr->alg_bytes;
-  const uint32_t agent_seed = uni((int)ghdr->agent_seed);
-  uint32_t std_rng = (uint32_t)uni((int)ghdr->std_rng);
-  uint32_t gen_state = ghdr->gen_rng;
-  int budget = uni(ghdr->budget), rollout_pos = uni(ghdr->rollout_pos);
-  int done_last = uni(ghdr->done_last);
-  if (status == BBX_ST_STARVED || status == BBX_ST_SPILL) status = BBX_ST_OK;   // transient states: try again
-  double vret = ghdr->vret, vdisc = ghdr->vdisc;
-  int obs_trunc = uni(ghdr->obs_trunc);
-  if (p.set_budget) { budget = p.nsteps; rollout_pos = 0; done_last = 0; vret = 0.0; vdisc = 1.0; obs_trunc = 0; }
-  if (p.pass == 1 && !(status == BBX_ST_OK && (need_reset || (budget > 0 && nP > 0)))) return;  // nothing left to do here
-
-  Env<W> ge = env_view<W>(grec, p.L);
-  // In the staged instantiation the working view is ALWAYS the LDS copy (never a select between an LDS and
-  // a global pointer), so that every access below compiles to ds_read/ds_write instead of flat_*.
-  Env<W> e = STAGED ? env_view<W>(smem + (size_t)wave_in_block * L.rec_bytes, L) : ge;
-  bool staged_in = false;
-  if (STAGED) {
-    if (status == BBX_ST_OK) {
-      if (nG > (int)L.maxG || nP > (int)L.maxP || arena_used > (int)L.arena) status = BBX_ST_SPILL;
-      else {
-        stage_copy<W>(e, ge, nG, nP, arena_used);
-        staged_in = true;
-        wave_sync();
-      }
-    }
-  }
-  int steps_done = 0;
-  double last_reward = 0.0;
-  const bool tracing = TRACE && p.trace != nullptr;   // hashing code exists only in the TRACE instantiations
-  // per-wave LDS tile scratch of the merge-path merge (HBM-resident class only; the launcher provides it)
-  char* mlds = (!STAGED && smem != nullptr) ? smem + (size_t)wave_in_block * merge_lds_bytes<W>() : nullptr;
-
-  // scratch polynomials
-  const int maxT = (int)L.maxT;
-  Mono<W>* hm0 = e.hm;            uint16_t* hc0 = e.hc;
-  Mono<W>* hm1 = e.hm + maxT;     uint16_t* hc1 = e.hc + maxT;
-  Mono<W>* rm = e.hm + 2 * maxT;  uint16_t* rc = e.hc + 2 * maxT;
-  Mono<W>* tm = e.hm + 3 * maxT;  uint16_t* tc = e.hc + 3 * maxT;   // 2*maxT staging
-
-  for (;;) {
-    if (status != BBX_ST_OK) break;
-    if (need_reset) {                           // also serves a reset left pending by the last step
-      if (!wave_reset<W>(e, p, L, env, nG, nP, arena_used, q_head, &status, gen_state)) {
-        // the reset restarts from the same queued ideal: in the LDS class a capacity miss is only a spill
-        if (STAGED && (status == BBX_ST_G_FULL || status == BBX_ST_P_FULL || status == BBX_ST_ARENA_FULL)) {
-          status = BBX_ST_SPILL; nG = 0; nP = 0; arena_used = 0;
-        }
-        break;
-      }
-      need_reset = 0; episode_steps = 0;
-    }
-    if (budget <= 0) break;
-    if (nP == 0) break;                         // finished episode and no auto-reset: nothing to do
-    // headroom for the worst case of this step, checked BEFORE anything is modified so that a miss leaves a
-    // consistent state: one new basis element of <= maxT terms and at most |G| new pairs
-    if (nG + 1 > (int)L.maxG || nP - 1 + nG > (int)L.maxP || arena_used + maxT > (int)L.arena) {
-      status = STAGED ? BBX_ST_SPILL : (nG + 1 > (int)L.maxG ? BBX_ST_G_FULL : (nP - 1 + nG > (int)L.maxP ? BBX_ST_P_FULL : BBX_ST_ARENA_FULL));
-      break;
-    }
-
-    // ---- choose the pair ------------------------------------------------------------------
-    int action;
-    if (p.agent == BBX_AGENT_EXTERNAL) action = p.actions[env];
-    else if (p.agent == BBX_AGENT_HASH) action = (int)bbx_agent_action32(agent_seed, (uint32_t)t_agent, (uint32_t)nP);
-    else if (p.agent == BBX_AGENT_FIRST) action = 0;
-    else if (p.agent == BBX_AGENT_LAST) action = nP - 1;
-    else if (p.agent == BBX_AGENT_STDRANDOM) action = std_choice(std_rng, nP);
-    else action = select_pair<W>(e, nP, p.agent, [&](int g) { return (int)e.psug[g]; });
-    action = uni(action);
-    if (action < 0 || action >= nP) { status = BBX_ST_BAD_ACTION; break; }
-    const uint32_t pr = (uint32_t)uni((int)e.pairs[action]);
-    const int gi = pr & 0xffffu, gj = pr >> 16;
-    // P.erase(remove(action))  buchberger.cpp:319 — stable
-    for (int base = action; base < nP - 1; base += WAVE) {
-      int k = base + lane;
-      uint32_t v = 0;
-      if (k < nP - 1) v = e.pairs[k + 1];
-      wave_sync();
-      if (k < nP - 1) e.pairs[k] = v;
-      wave_sync();
-    }
-    nP -= 1;
-
-    // ---- S-polynomial  buchberger.cpp:18-21 -----------------------------------------------------
-    int hn, hoff = 0, hsug;
-    Mono<W>* hm = hm0; uint16_t* hc = hc0;
-    {
-      const Mono<W> lmi = e.lm[gi], lmj = e.lm[gj];
-      const Mono<W> gamma = m_lcm(lmi, lmj);
-      const int offi = uni((int)e.poff[gi]), offj = uni((int)e.poff[gj]);
-      PView<W> A, Bv;
-      A.m = e.am + offi + 1; A.c = e.ac + offi + 1; A.n = uni((int)e.plen[gi]) - 1;
-      A.shift = m_div(gamma, lmi); A.scale = (uint32_t)uni((int)e.pinv[gi]);
-      Bv.m = e.am + offj + 1; Bv.c = e.ac + offj + 1; Bv.n = uni((int)e.plen[gj]) - 1;
-      Bv.shift = m_div(gamma, lmj); Bv.scale = negmod((uint32_t)uni((int)e.pinv[gj]));
-      int si = uni((int)e.psug[gi]) + (int)m_deg(A.shift), sj = uni((int)e.psug[gj]) + (int)m_deg(Bv.shift);
-      hsug = uni(si > sj ? si : sj);
-      if (hsug > 65535) { status = BBX_ST_DEG_OVERFLOW; break; }
-      if (A.n + Bv.n > 2 * maxT) { status = BBX_ST_POLY_TOO_LONG; break; }
-      GSTAMP(0);                                   // 0: loop top, agent, pair removal
-      const bool big = mlds && A.n > 0 && Bv.n > 0 && A.n + Bv.n > 64;
-      hn = big ? wave_merge_tiled<W>(A, Bv, mlds, hm, hc, maxT) : wave_merge<W>(A, Bv, tm, tc, hm, hc, maxT);
-      if (hn < 0) { status = BBX_ST_POLY_TOO_LONG; break; }
-      GSTAMP(1);                                   // 1: S-polynomial merge
-      alg_bytes += 12LL * (A.n + Bv.n + 2 + hn);   // both inputs read, S-polynomial written
-    }
-
-    // ---- reduce  buchberger.cpp:24-49 -----------------------------------------------------------
-    int nsteps_red = 0, rn = 0, rsug = 0;
-    bool overflow = false;
-    while (hn - hoff > 0) {
-      const Mono<W> lmh = hm[hoff];
-      int found = -1;
-      for (int base = 0; base < nG; base += WAVE) {   // first reducer (in G_ order) whose LM divides LM(h)
-        int k = base + lane;
-        bool d = k < nG && m_divides(e.slm[k], lmh);
-        uint64_t mask = ballot64(d);
-        if (mask) { found = base + __builtin_ctzll(mask); break; }
-      }
-      GSTAMP(2);                                  // 2: divisor scans
-      if (found >= 0) {                         // h <- h - (LT h / LT f) f     (34-36)
-        const int g = uni((int)e.sidx[found]);
-        const uint32_t c = mulmod((uint32_t)uni((int)hc[hoff]), (uint32_t)uni((int)e.pinv[g]));
-        const int offg = uni((int)e.poff[g]);
-        PView<W> A, Bv;
-        A.m = hm + hoff + 1; A.c = hc + hoff + 1; A.n = hn - hoff - 1; A.shift = m_zero<W>(); A.scale = 1;
-        Bv.m = e.am + offg + 1; Bv.c = e.ac + offg + 1; Bv.n = uni((int)e.plen[g]) - 1;
-        Bv.shift = m_div(lmh, e.lm[g]); Bv.scale = negmod(c);
-        int fs = uni((int)e.psug[g]) + (int)m_deg(Bv.shift);
-        hsug = uni(fs > hsug ? fs : hsug);
-        if (hsug > 65535) { status = BBX_ST_DEG_OVERFLOW; overflow = true; break; }
-        if (A.n + Bv.n > 2 * maxT) { status = BBX_ST_POLY_TOO_LONG; overflow = true; break; }
-        Mono<W>* nm = (hm == hm0) ? hm1 : hm0; uint16_t* nc = (hc == hc0) ? hc1 : hc0;
-        GSTAMP(3);                                // 3: reducer fetch / setup
-        const bool big = mlds && A.n > 0 && Bv.n > 0 && A.n + Bv.n > 64;
-        const int nn = big ? wave_merge_tiled<W>(A, Bv, mlds, nm, nc, maxT) : wave_merge<W>(A, Bv, tm, tc, nm, nc, maxT, PROF ? &ps[6] : nullptr);
-        if (nn < 0) { status = BBX_ST_POLY_TOO_LONG; overflow = true; break; }
-        GSTAMP(4);                                // 4: reduction merges (6/7: their pass 1 / pass 2)
-        alg_bytes += 8LL * (found + 1) + 12LL * (Bv.n + 1) + 12LL * (A.n + 1 + nn);
-        hm = nm; hc = nc; hn = nn; hoff = 0;
-        nsteps_red++;
-        if (nsteps_red > (1 << 24)) { status = BBX_ST_RUNAWAY; overflow = true; break; }
-      } else {                                  // r <- r + LT h ; h <- h - LT h   (41-44)
-        if (rn >= maxT) { status = BBX_ST_POLY_TOO_LONG; overflow = true; break; }
-        alg_bytes += 8LL * nG + 12LL * (2 * (hn - hoff) - 1);
-        if (lane == 0) { rm[rn] = lmh; rc[rn] = hc[hoff]; }
-        int d = uni((int)m_deg(lmh));
-        rsug = d > rsug ? d : rsug;
-        rn++; hoff++;
-        GSTAMP(5);                                // 5: tail moves
-      }
-    }
-    if (overflow) break;
-    wave_sync();
-    rsug = rsug > hsug ? rsug : hsug;            // sugar of r + h (48), h's sugar survives its terms
-
-    // ---- basis / pair-set update  buchberger.cpp:321-327 ---------------------------------------
-    const int nG_before = nG, nP_before = nP;
-    if (rn != 0) {
-      if (!wave_add_poly<W>(e, L, nG, nP, arena_used, rm, rc, rn, rsug, p.elim, p.sort_reducers, &status)) break;
-      alg_bytes += 12LL * rn + 8LL * nG_before + 8LL * (nP_before + nP);
-    } else zero_red++;
-    alg_bytes += 4LL * nP * 2 * p.nvars * p.k;      // the observation matrix of the new state
-    const double reward = (p.rewards_mode == BBX_REW_ADDITIONS) ? (-1.0 - (double)nsteps_red) : -1.0;  // 328
-    last_reward = reward;
-    if (p.value_mode) value_accumulate(vret, vdisc, reward, p.gamma);
-    total_steps++; total_adds += 1 + nsteps_red; t_agent++; episode_steps++; steps_done++;
-    const bool done = nP == 0;
-
-    // ---- the observation a policy would consume after this step ---------------------------------
-    if (p.obs_every_step && p.obs) { wave_obs<W>(e, p, env, nP, true, false); obs_trunc |= nP > p.obs_rows ? 1 : 0; }
-    // ---- parity trace (tests): hashes of the post-step observation / pair set / new element ---
-    if (TRACE && tracing) {
-      uint64_t oh = wave_obs<W, true>(e, p, env, nP, false, true);
-      uint64_t ph = wave_pairs_hash<W, Env<W>>(e, nP);
-      uint64_t nh = nG > nG_before ? wave_poly_hash<W>(e, nG - 1) : 0;
-      if (lane == 0) {
-        BbxTraceRec& tr = p.trace[(size_t)env * p.trace_stride + rollout_pos];
-        tr.action = action; tr.nP = nP; tr.nG = nG; tr.done = done ? 1 : 0; tr.reward = reward;
-        tr.obs_hash = oh; tr.pairs_hash = ph; tr.newpoly_hash = nh;
-      }
-    }
-    budget--; rollout_pos++;
-    done_last = done ? 1 : 0;
-    if (done) {
-      episodes++;
-      if (p.auto_reset) need_reset = 1;
-    }
-  }
-
-  if (PROF && prof_out && lane == 0) for (int i = 0; i < 10; i++) prof_out[(size_t)env * 10 + i] = ps[i];
-  // an environment that must continue in the follow-up pass reports nothing yet
-  const bool handoff = status == BBX_ST_SPILL;
-  // ---- observation of the state the caller sees next ------------------------------------------
-  if (p.obs && status == BBX_ST_OK) { wave_obs<W>(e, p, env, nP, true, false); obs_trunc |= nP > p.obs_rows ? 1 : 0; }
-
-  if (STAGED && staged_in) {
-    wave_sync();
-    stage_copy<W>(ge, e, nG, nP, arena_used);
-  }
-  if (lane == 0) {
-    BbxHdr* h = ghdr;
-    h->nG = nG; h->nP = nP; h->arena_used = arena_used; h->status = status; h->need_reset = need_reset;
-    h->q_head = q_head; h->t = t_agent; h->std_rng = std_rng; h->gen_rng = gen_state; h->episode_steps = episode_steps; h->total_steps = total_steps;
-    h->total_additions = total_adds; h->episodes = episodes; h->zero_reductions = zero_red; h->steps_done = steps_done;
-    h->budget = budget; h->rollout_pos = rollout_pos; h->done_last = done_last; h->alg_bytes = alg_bytes;
-    h->vret = vret; h->vdisc = vdisc; h->obs_trunc = obs_trunc;
-    if (p.lite) *(int4*)(p.lite + 4 * (size_t)env) = make_int4(status | (obs_trunc ? BBX_LITE_OBS_TRUNC : 0), q_head, budget, nP);
-    if (p.value_mode && p.values) p.values[env] = vret;
-    if (!handoff) {
-      if (p.rewards && (steps_done > 0 || p.pass == 0)) p.rewards[env] = last_reward;
-      if (p.dones) p.dones[env] = (uint8_t)((done_last || (nP == 0 && !need_reset)) ? 1 : 0);
-      if (p.rows) p.rows[env] = nP;
-    }
-  }
-}
-
-template <int W, bool STAGED, bool TRACE>
-__global__ __launch_bounds__(256) void bbx_step_kernel(BbxParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  step_body<W, STAGED, TRACE>(p, smem);
-}
-// the same body under its own name for launches that only reset / refresh observations (nsteps == 0), so that
-// profiles of bbx_step_kernel contain step launches only
-template <int W>
-__global__ __launch_bounds__(256) void bbx_aux_kernel(BbxParams p) {
-  step_body<W, false, false>(p, nullptr);
-}
-#ifdef BBX_PROF_BUILD
-// diagnostic build with s_memtime stamps (BBX_PROF=1), never used for reported numbers
-template <int W>
-__global__ __launch_bounds__(256) void bbx_step_prof_kernel(BbxParams p, unsigned long long* prof) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  step_body<W, false, false, true>(p, smem, prof);
-}
-
-#endif
-
-#include "bbx_pmlp.h"
-#include "bbx_binom.h"
-#include "bbx_fast.h"
-#include "bbx_wide.h"
-
-// ------------------------------------------------------------------ housekeeping kernels
-// zero the headers and set the per-environment agent seeds
-__global__ void bbx_init_kernel(char* recs, uint32_t rec_bytes, int B, const uint32_t* agent_seeds) {
-  int env = blockIdx.x * blockDim.x + threadIdx.x;
-  if (env >= B) return;
-  BbxHdr* h = (BbxHdr*)(recs + (size_t)env * rec_bytes);
-  BbxHdr z = {};
-  z.agent_seed = agent_seeds ? agent_seeds[env] : (uint32_t)env;
-  z.std_rng = 1u;                               // std::default_random_engine's default seed
-  *h = z;
-}
-// request a reset (mask == null: every environment); clears a sticky error so the slot can be reused
-__global__ void bbx_mark_reset_kernel(char* recs, uint32_t rec_bytes, int B, const uint8_t* mask) {
-  int env = blockIdx.x * blockDim.x + threadIdx.x;
-  if (env >= B) return;
-  if (mask && !mask[env]) return;
-  BbxHdr* h = (BbxHdr*)(recs + (size_t)env * rec_bytes);
-  h->need_reset = 1; h->status = BBX_ST_OK; h->nP = 0; h->nG = 0; h->arena_used = 0; h->done_last = 0;
-}
-// refill of the ideal queue: the host stages the rings of the environments it topped up ([n ids][n tails][n rings]) and
-// uploads them with one copy; this kernel moves every ring to its place (one workgroup per ring)
-__global__ void bbx_scatter_queue_kernel(const uint32_t* stage, int n, uint32_t ring_words, uint32_t* q, int32_t* tail) {
-  const int i = blockIdx.x;
-  if (i >= n) return;
-  const int env = (int)stage[i];
-  const uint32_t* src = stage + 2 * (size_t)n + (size_t)i * ring_words;
-  uint32_t* dst = q + (size_t)env * ring_words;
-  for (uint32_t w = threadIdx.x; w < ring_words; w += blockDim.x) dst[w] = src[w];
-  if (threadIdx.x == 0) tail[env] = (int32_t)stage[n + i];
-}
-extern "C" int bbx_launch_scatter_queue(const uint32_t* stage, int n, uint32_t ring_words, uint32_t* q, int32_t* tail, hipStream_t stream) {
-  hipLaunchKernelGGL(bbx_scatter_queue_kernel, dim3(n), dim3(256), 0, stream, stage, n, ring_words, q, tail);
-  return (int)hipGetLastError();
-}
-// ragged observation: the rows of every environment back to back (what a list of per-environment matrices needs),
-// packed on the device from the padded block a step launch leaves behind.  Kernel 1: off[e] = sum of min(rows, cap)
-// over the environments before e (one workgroup); kernel 2: one workgroup per environment copies its rows.
-__global__ __launch_bounds__(1024) void bbx_obs_offsets_kernel(const int32_t* rows, int B, int cap, int32_t* off) {
-  __shared__ int part[1024];
-  const int t = threadIdx.x, per = (B + 1023) / 1024;
-  int s = 0;
-  for (int i = 0; i < per; i++) { const int e = t * per + i; if (e < B) { const int r = rows[e]; s += r < cap ? r : cap; } }
-  part[t] = s;
-  __syncthreads();
-  for (int d = 1; d < 1024; d <<= 1) {                     // inclusive scan (Hillis-Steele)
-    const int v = t >= d ? part[t - d] : 0;
-    __syncthreads();
-    part[t] += v;
-    __syncthreads();
-  }
-  int base = t ? part[t - 1] : 0;
-  for (int i = 0; i < per; i++) {
-    const int e = t * per + i;
-    if (e < B) { off[e] = base; const int r = rows[e]; base += r < cap ? r : cap; }
-  }
-  if (t == 1023) off[B] = part[1023];
-}
-__global__ void bbx_obs_pack_kernel(const int32_t* padded, int cap, int cols, const int32_t* off, int B, int32_t* packed) {
-  const int e = blockIdx.x;
-  if (e >= B) return;
-  const int n = (off[e + 1] - off[e]) * cols;
-  const int32_t* src = padded + (size_t)e * cap * cols;
-  int32_t* dst = packed + (size_t)off[e] * cols;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
-}
-extern "C" int bbx_launch_obs_pack(const int32_t* padded, int cap, int cols, const int32_t* rows, int B, int32_t* off, int32_t* packed, hipStream_t stream) {
-  hipLaunchKernelGGL(bbx_obs_offsets_kernel, dim3(1), dim3(1024), 0, stream, rows, B, cap, off);
-  hipLaunchKernelGGL(bbx_obs_pack_kernel, dim3(B), dim3(64), 0, stream, padded, cap, cols, off, B, packed);
-  return (int)hipGetLastError();
-}
-extern "C" int bbx_launch_init(char* recs, uint32_t rec_bytes, int B, const uint32_t* agent_seeds, hipStream_t stream) {
-  hipLaunchKernelGGL(bbx_init_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, recs, rec_bytes, B, agent_seeds);
-  return (int)hipGetLastError();
-}
-extern "C" int bbx_launch_mark_reset(char* recs, uint32_t rec_bytes, int B, const uint8_t* mask, hipStream_t stream) {
-  hipLaunchKernelGGL(bbx_mark_reset_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, recs, rec_bytes, B, mask);
-  return (int)hipGetLastError();
-}
-
-// value(): clone environment src[k] of one record array into slot k of another (live prefixes only), optionally
-// re-seeding the built-in random agent of the clone
-template <int W>
-__global__ void bbx_clone_kernel(const char* src_recs, char* dst_recs, BbxLayout L, const int32_t* src, const int32_t* dst, int n,
-                                 const uint32_t* seeds, int keep_counters) {
-  const int k = blockIdx.x * (blockDim.x / WAVE) + (int)(threadIdx.x / WAVE);
-  if (k >= n) return;
-  char* s = const_cast<char*>(src_recs) + (size_t)src[k] * L.rec_bytes;
-  char* d = dst_recs + (size_t)(dst ? dst[k] : k) * L.rec_bytes;
-  BbxHdr h = *(const BbxHdr*)s;
-  if (L.kind == 1) bstage_copy<W>(benv_view<W>(d, L), benv_view<W>(s, L), h.nG, h.nP);
-  else stage_copy<W>(env_view<W>(d, L), env_view<W>(s, L), h.nG, h.nP, h.arena_used);
-  if (lane_id() == 0) {
-    if (!keep_counters) { h.need_reset = 0; h.budget = 0; h.rollout_pos = 0; h.t = 0; }
-    if (seeds) h.agent_seed = seeds[k];
-    *(BbxHdr*)d = h;
-  }
-}
-extern "C" int bbx_launch_clone(const char* src_recs, char* dst_recs, const BbxLayout* L, const int32_t* src, const int32_t* dst, int n,
-                                const uint32_t* seeds, int keep_counters, hipStream_t stream) {
-  const int blocks = (n + 3) / 4;
-  if (L->W == 2) hipLaunchKernelGGL((bbx_clone_kernel<2>), dim3(blocks), dim3(256), 0, stream, src_recs, dst_recs, *L, src, dst, n, seeds, keep_counters);
-  else if (L->W == 4) hipLaunchKernelGGL((bbx_clone_kernel<4>), dim3(blocks), dim3(256), 0, stream, src_recs, dst_recs, *L, src, dst, n, seeds, keep_counters);
-  else hipLaunchKernelGGL((bbx_clone_kernel<8>), dim3(blocks), dim3(256), 0, stream, src_recs, dst_recs, *L, src, dst, n, seeds, keep_counters);
-  return (int)hipGetLastError();
-}
-
-// compact copy of every header so the host reads them with one contiguous transfer
-__global__ void bbx_gather_hdr_kernel(const char* recs, uint32_t rec_bytes, int B, BbxHdr* out) {
-  int env = blockIdx.x * blockDim.x + threadIdx.x;
-  if (env >= B) return;
-  out[env] = *(const BbxHdr*)(recs + (size_t)env * rec_bytes);
-}
-// the four header words the host polls after every launch
-__global__ void bbx_gather_lite_kernel(const char* recs, uint32_t rec_bytes, int B, int4* out) {
-  int env = blockIdx.x * blockDim.x + threadIdx.x;
-  if (env >= B) return;
-  const BbxHdr* h = (const BbxHdr*)(recs + (size_t)env * rec_bytes);
-  out[env] = make_int4(h->status, h->q_head, h->budget, h->nP);
-}
-extern "C" int bbx_launch_gather_lite(const char* recs, uint32_t rec_bytes, int B, void* out, hipStream_t stream) {
-  hipLaunchKernelGGL(bbx_gather_lite_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, recs, rec_bytes, B, (int4*)out);
-  return (int)hipGetLastError();
-}
-extern "C" int bbx_launch_gather_hdr(const char* recs, uint32_t rec_bytes, int B, BbxHdr* out, hipStream_t stream) {
-  hipLaunchKernelGGL(bbx_gather_hdr_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, recs, rec_bytes, B, out);
-  return (int)hipGetLastError();
-}
-
-extern "C" int bbx_launch_pmlp_prepare(const float* w1, const float* b1, const float* w2, float b2, int cols, int hidden, float* out, hipStream_t stream) {
-  hipLaunchKernelGGL(bbx_pmlp_prepare_kernel, dim3(16), dim3(256), 0, stream, w1, b1, w2, b2, cols, hidden, out);
-  return (int)hipGetLastError();
-}
-extern "C" int bbx_launch_pmlp_act(const int32_t* obs, const int32_t* rows, int B, int obs_rows, int cols, const float* wp, int hidden, const float* u,
-                                   int32_t* actions, float* logprobs, hipStream_t stream) {
-  const int waves = 4, nb = pmlp_nb_for(hidden), ks = pmlp_ks_for(cols);
-  const size_t ml = pmlp_lds_bytes(waves);
-#define BBX_PMLP_MFMA(N, K) hipLaunchKernelGGL((bbx_pmlp_act_mfma_kernel<N, K>), dim3((B + waves - 1) / waves), dim3(waves * WAVE), ml, stream, obs, rows, B, \
-                                                obs_rows, cols, wp, u, actions, logprobs)
-#define BBX_PMLP_MFMA_K(N) do { if (ks == 3) BBX_PMLP_MFMA(N, 3); else if (ks == 6) BBX_PMLP_MFMA(N, 6); else if (ks == 10) BBX_PMLP_MFMA(N, 10); \
-                                else if (ks == 16) BBX_PMLP_MFMA(N, 16); else BBX_PMLP_MFMA(N, 32); } while (0)
-  if (nb == 1) BBX_PMLP_MFMA_K(1); else if (nb == 2) BBX_PMLP_MFMA_K(2); else if (nb == 4) BBX_PMLP_MFMA_K(4); else BBX_PMLP_MFMA_K(8);
-#undef BBX_PMLP_MFMA_K
-#undef BBX_PMLP_MFMA
-  return (int)hipGetLastError();
-}
-
-#ifdef BBX_PROF_BUILD
-extern "C" int bbx_bin_prof_read(unsigned long long* out, int reset) {   // diagnostic build only
-  hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(bbx_bin_prof_acc), 32 * sizeof(unsigned long long));
-  if (e == hipSuccess && reset) { unsigned long long z[32] = {0}; e = hipMemcpyToSymbol(HIP_SYMBOL(bbx_bin_prof_acc), z, sizeof z); }
-  return (int)e;
-}
-extern "C" int bbx_wide_prof_read(unsigned long long* out, int reset) {   // diagnostic build only
-  hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(bbx_wide_prof_acc), 32 * sizeof(unsigned long long));
-  if (e == hipSuccess && reset) { unsigned long long z[32] = {0}; e = hipMemcpyToSymbol(HIP_SYMBOL(bbx_wide_prof_acc), z, sizeof z); }
-  return (int)e;
-}
-#endif
-
-// ------------------------------------------------------------------ host-callable launcher
-// kind: 0 = HBM-resident step kernel, 1 = LDS-staged step kernel, 2 = aux (reset / observation only)
-#define BBX_LAUNCH(KERN) hipLaunchKernelGGL((KERN), dim3(blocks), dim3(threads), lds, stream, *p)
-template <int W>
-static int launch_w(const BbxParams* p, int kind, int blocks, int threads, size_t lds, hipStream_t stream) {
-  const bool trace = p->trace != nullptr;
-  const bool binom = p->L.kind == 1;
-  if (kind == 2) {
-    if (binom) BBX_LAUNCH(bbx_binom_aux_kernel<W>); else BBX_LAUNCH(bbx_aux_kernel<W>);
-    return 0;
-  }
-  if (kind == 1) {
-    const void* fn = binom ? (trace ? (const void*)bbx_binom_kernel<W, true, true> : (const void*)bbx_binom_kernel<W, true, false>)
-                           : (trace ? (const void*)bbx_step_kernel<W, true, true> : (const void*)bbx_step_kernel<W, true, false>);
-    hipError_t err = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (err != hipSuccess) return (int)err;
-    if (binom) { if (trace) BBX_LAUNCH((bbx_binom_kernel<W, true, true>)); else BBX_LAUNCH((bbx_binom_kernel<W, true, false>)); }
-    else { if (trace) BBX_LAUNCH((bbx_step_kernel<W, true, true>)); else BBX_LAUNCH((bbx_step_kernel<W, true, false>)); }
-    return 0;
-  }
-#ifdef BBX_PROF_BUILD   // diagnostic build only (-DBBX_PROF_BUILD): per-phase s_memtime sums, never in the product library
-  if (!binom && !trace && getenv("BBX_PROF")) {
-    static unsigned long long* d_prof = nullptr;
-    if (!d_prof) (void)hipMalloc((void**)&d_prof, (size_t)p->B * 10 * sizeof(unsigned long long));
-    lds = (size_t)(threads / WAVE) * merge_lds_bytes<W>();
-    (void)hipFuncSetAttribute((const void*)bbx_step_prof_kernel<W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((bbx_step_prof_kernel<W>), dim3(blocks), dim3(threads), lds, stream, *p, d_prof);
-    (void)hipStreamSynchronize(stream);
-    std::vector<unsigned long long> h((size_t)p->B * 10);
-    (void)hipMemcpy(h.data(), d_prof, h.size() * 8, hipMemcpyDeviceToHost);
-    double s[10] = {0}, tot = 0;
-    for (int e = 0; e < p->B; e++) for (int i = 0; i < 10; i++) s[i] += (double)h[(size_t)e * 10 + i];
-    for (int i = 0; i < 6; i++) tot += s[i];
-    fprintf(stderr, "[bbx prof general] nsteps=%d kcycles/env:", p->nsteps);
-    for (int i = 0; i < 10; i++) fprintf(stderr, " p%d=%.0f(%.0f%%)", i, s[i] / p->B / 1e3, 100.0 * s[i] / tot);
-    fprintf(stderr, "\n");
-    return 0;
-  }
-#endif
-  if (binom) {
-    lds = (size_t)(threads / WAVE) * update_lds_bytes<W>();           // Gebauer-Moeller peel scratch, one per wave
-    if constexpr (W == 2 || W == 4) {
-      if (p->policy && p->policy->rollout) {               // a policy rollout: its continuation pass, or the whole of it
-        BbxParams q = *p; q.policy = nullptr; q.actions = nullptr; q.rewards = nullptr; q.dones = nullptr; q.rows = nullptr; q.obs_every_step = 0;
-        const int nb = pmlp_nb_for(p->policy->hidden), ks = pmlp_ks_for(2 * p->nvars * p->k);
-#define BBX_BPOL(NBV, KSV) hipLaunchKernelGGL((bbx_binom_policy_kernel<W, NBV, KSV>), dim3(blocks), dim3(threads), lds, stream, q, *p->policy)
-        if (ks == 6) { if (nb == 2) BBX_BPOL(2, 6); else BBX_BPOL(4, 6); }
-        else if (W == 4 && ks == 10) { if (nb == 2) BBX_BPOL(2, 10); else BBX_BPOL(4, 10); }
-        else return (int)hipErrorInvalidValue;             // (bbx_api.cpp admits only the built-in shapes)
-#undef BBX_BPOL
-        return 0;
-      }
-    }
-    if (trace) BBX_LAUNCH((bbx_binom_kernel<W, false, true>)); else BBX_LAUNCH((bbx_binom_kernel<W, false, false>));
-  } else {
-    lds = (size_t)(threads / WAVE) * merge_lds_bytes<W>();          // merge-path tile scratch, one per wave
-    const void* fn = trace ? (const void*)bbx_step_kernel<W, false, true> : (const void*)bbx_step_kernel<W, false, false>;
-    hipError_t err = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (err != hipSuccess) return (int)err;
-    if (trace) BBX_LAUNCH((bbx_step_kernel<W, false, true>)); else BBX_LAUNCH((bbx_step_kernel<W, false, false>));
-  }
-  return 0;
-}
-// kind 3: the hand-tuned LDS/register-resident kernel (bbx_fast.h) for W == 2 binomial, GM, sorted reducers
-static int launch_fast(const BbxParams* p, int blocks, int threads, int envs_per_block, hipStream_t stream) {
-  BbxFastParams f{};
-  f.recs = p->recs; f.qwords = p->q.words; f.qtail = p->q.tail; f.inv_table = p->inv_table;
-  f.actions = p->actions; f.rewards = p->rewards; f.dones = p->dones; f.rows = p->rows; f.obs = p->obs; f.trace = p->trace;
-  f.rec_bytes = p->L.rec_bytes; f.hbmG = p->L.maxG;
-  f.q_env_stride = p->q.env_stride; f.q_slot_words = p->q.slot_words; f.q_nslots = p->q.nslots; f.q_fixed = p->q.fixed;
-  f.B = p->B; f.nsteps = p->nsteps; f.obs_rows = p->obs_rows; f.trace_stride = p->trace_stride; f.k = p->k; f.nvars = p->nvars;
-  f.lim_G = (int)p->LL.maxG; f.lim_P = (int)p->LL.maxP;
-  f.agent = p->agent; f.auto_reset = p->auto_reset; f.set_budget = p->set_budget; f.pass = p->pass;
-  f.obs_every_step = p->obs_every_step; f.obs_fill = p->obs_fill; f.rewards_mode = p->rewards_mode;
-  f.lite = p->lite; f.done_seq = p->done_seq;
-  f.gen = p->gen;
-  f.sort_input = p->sort_input;
-  const size_t lds = (size_t)envs_per_block * FLDS_BYTES;
-#ifdef BBX_PROF_BUILD
-  static unsigned long long* d_prof = nullptr;
-  if (getenv("BBX_PROF") && !p->trace) {          // diagnostic: per-phase cycle sums, printed by bbx_prof_dump()
-    if (!d_prof) (void)hipMalloc((void**)&d_prof, (size_t)p->B * 8 * sizeof(unsigned long long));
-    f.prof = d_prof;
-    hipLaunchKernelGGL(bbx_fast_prof_kernel, dim3(blocks), dim3(threads), lds, stream, f);
-    (void)hipStreamSynchronize(stream);
-    std::vector<unsigned long long> h((size_t)p->B * 8);
-    (void)hipMemcpy(h.data(), d_prof, h.size() * 8, hipMemcpyDeviceToHost);
-    double s[8] = {0}; for (int e = 0; e < p->B; e++) for (int i = 0; i < 8; i++) s[i] += (double)h[(size_t)e * 8 + i];
-    double tot = 0; for (int i = 0; i < 8; i++) tot += s[i];
-    fprintf(stderr, "[bbx prof] nsteps=%d ticks/step/env:", p->nsteps);
-    for (int i = 0; i < 6; i++) fprintf(stderr, " p%d=%.0f(%.0f%%)", i, s[i] / p->B / (p->nsteps ? p->nsteps : 1), 100.0 * s[i] / tot);
-    fprintf(stderr, "\n");
-    return 0;
-  }
-#endif
-  if (p->policy) {                                         // policy + step in one launch (bbx_api.cpp checked the shapes)
-    BbxFastPolicyParams q; q.f = f; q.pol = *p->policy;
-    q.f.agent = BBX_AGENT_EXTERNAL; q.f.actions = q.pol.actions;
-    if (q.pol.rollout) {                                   // nsteps steps, the policy inside the step loop (3 variables, k = 2)
-      q.f.actions = nullptr; q.f.rewards = nullptr; q.f.dones = nullptr; q.f.rows = nullptr; q.f.obs_every_step = 0; q.f.auto_reset = 1;
-      const size_t rl = (size_t)envs_per_block * (FLDS_BYTES + 4 * FP) + ((size_t)(2 * 6 + 2) * 32 * pmlp_nb_for(q.pol.hidden) + 4) * sizeof(float);
-      if (pmlp_nb_for(q.pol.hidden) == 2) hipLaunchKernelGGL((bbx_fast_policy_rollout_kernel<2>), dim3(blocks), dim3(threads), rl, stream, q);
-      else hipLaunchKernelGGL((bbx_fast_policy_rollout_kernel<4>), dim3(blocks), dim3(threads), rl, stream, q);
-      return 0;
-    }
-    const int nb = pmlp_nb_for(q.pol.hidden), ks = pmlp_ks_for(2 * f.k * f.nvars);
-    const size_t pl = pmlp_lds_bytes(envs_per_block), ll = pl > lds ? pl : lds;
-    if (ks == 3) { if (nb == 2) hipLaunchKernelGGL((bbx_fast_policy_kernel<2, 3>), dim3(blocks), dim3(threads), ll, stream, q);
-                   else hipLaunchKernelGGL((bbx_fast_policy_kernel<4, 3>), dim3(blocks), dim3(threads), ll, stream, q); }
-    else { if (nb == 2) hipLaunchKernelGGL((bbx_fast_policy_kernel<2, 6>), dim3(blocks), dim3(threads), ll, stream, q);
-           else hipLaunchKernelGGL((bbx_fast_policy_kernel<4, 6>), dim3(blocks), dim3(threads), ll, stream, q); }
-    return 0;
-  }
-  if (p->trace) hipLaunchKernelGGL((bbx_fast_kernel<true, true>), dim3(blocks), dim3(threads), lds, stream, f);
-  else if (p->accounting) hipLaunchKernelGGL((bbx_fast_kernel<false, true>), dim3(blocks), dim3(threads), lds, stream, f);
-  else if (f.agent == BBX_AGENT_HASH && f.nvars == 3 && f.k == 2 && f.obs && f.obs_every_step && !f.obs_fill && f.auto_reset)
-    hipLaunchKernelGGL(bbx_fast_headline_kernel, dim3(blocks), dim3(threads), lds, stream, f);
-  else hipLaunchKernelGGL((bbx_fast_kernel<false, false>), dim3(blocks), dim3(threads), lds, stream, f);
-  return 0;
-}
-extern "C" int bbx_launch_step(const BbxParams* p, int kind, int envs_per_block, hipStream_t stream) {
-  const int threads = envs_per_block * WAVE;
-  const int blocks = (p->B + envs_per_block - 1) / envs_per_block;
-  if (kind == 3) { launch_fast(p, blocks, threads, envs_per_block, stream); return (int)hipGetLastError(); }
-  if (kind == 4) {                                         // wide: envs_per_block is the number of waves per environment
-    if (p->L.W != 2 && p->L.W != 4) return (int)hipErrorInvalidValue;   // (8-variable rings take the general class)
-    const int nw = envs_per_block;
-    BbxParams q = *p;                                      // LDS capacities of the workgroup (terms): forced by the caller or
-    const int W_ = (int)q.L.W;                             // as large as the residency aimed at allows
-    // lean variants: random and external agents let h grow long — reducer tails collect in an LDS accumulator and h is
-    // rewritten only when it is full (LAZY); the ordering strategies keep h short — plain eager merges without the
-    // accumulator's bookkeeping.  BBX_WIDE_EAGER=1 / =0 force one or the other (experiments).
-    const bool strategy = q.agent == BBX_AGENT_DEGREE || q.agent == BBX_AGENT_FIRST || q.agent == BBX_AGENT_NORMAL || q.agent == BBX_AGENT_SUGAR ||
-                          q.agent == BBX_AGENT_LAST || q.agent == BBX_AGENT_CODEGREE || q.agent == BBX_AGENT_STRANGE || q.agent == BBX_AGENT_SPICE;
-    bool lazy = !q.accounting && !strategy;
-    if (const char* ev = getenv("BBX_WIDE_EAGER")) lazy = !q.accounting && ev[0] == '0';
-    const bool acct = q.accounting != 0;
-    bool one_per_cu = false;
-    if (q.wide_hc > 0) {                                   // forced capacities (tests, experiments): as asked, as far as 160 KB go
-      q.wide_hc = (q.wide_hc + 7) & ~7;
-      while (q.wide_hc > 8 && wide_lds_bytes(W_, q.wide_hc, q.wide_hc, q.wide_hc, lazy ? q.wide_hc : 0) > 160u * 1024u) q.wide_hc -= 8;
-      q.wide_fc = q.wide_hc; q.wide_rc = q.wide_hc; q.wide_sc = lazy ? q.wide_hc : 0;
-    }
-    else {
-      static int ncu = 0;
-      if (!ncu) { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount; if (ncu <= 0) ncu = 256; }
-      // one workgroup per CU while the batch fits that way (160 KB each), otherwise two per CU (80 KB each)
-      const bool one = q.B <= ncu;
-      one_per_cu = one;
-      const size_t budget = one ? 160u * 1024u : 80u * 1024u;
-      // (without the accumulator's two buffers the reducer table can hold twice as many reducers)
-      q.wide_fc = one ? 1024 : 512; q.wide_rc = one ? (lazy ? 1024 : 2048) : (lazy ? 704 : 1024); q.wide_sc = lazy ? (one ? 1536 : 1024) : 0;
-      const size_t fixed = wide_lds_bytes(W_, 0, q.wide_fc, q.wide_rc, q.wide_sc);
-      q.wide_hc = (int)((budget - fixed) / 20) & ~63;       // a term in LDS: 8-byte sort key + u16 coefficient, two buffers
-      while (wide_lds_bytes(W_, q.wide_hc, q.wide_fc, q.wide_rc, q.wide_sc) > budget) q.wide_hc -= 64;
-    }
-    p = &q;
-    const size_t wl = wide_lds_bytes(W_, q.wide_hc, q.wide_fc, q.wide_rc, q.wide_sc);
-    const bool tr = p->trace != nullptr;
-#define BBX_WIDE_LAUNCH(WW, TT, LL) do { \
-      hipError_t err_ = hipFuncSetAttribute((const void*)bbx_wide_kernel<WW, TT, LL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl); \
-      if (err_ != hipSuccess) return (int)err_; \
-      hipLaunchKernelGGL((bbx_wide_kernel<WW, TT, LL>), dim3(p->B), dim3(nw * WAVE), wl, stream, *p); } while (0)
-#define BBX_WIDE_LAUNCH1(WW, LL, AA) do { \
-      hipError_t err_ = hipFuncSetAttribute((const void*)bbx_wide_kernel_1cu<WW, LL, AA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl); \
-      if (err_ != hipSuccess) return (int)err_; \
-      hipLaunchKernelGGL((bbx_wide_kernel_1cu<WW, LL, AA>), dim3(p->B), dim3(nw * WAVE), wl, stream, *p); } while (0)
-#define BBX_WIDE_LAUNCHE(WW) do { \
-      hipError_t err_ = hipFuncSetAttribute((const void*)bbx_wide_eager_kernel<WW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl); \
-      if (err_ != hipSuccess) return (int)err_; \
-      hipLaunchKernelGGL((bbx_wide_eager_kernel<WW>), dim3(p->B), dim3(nw * WAVE), wl, stream, *p); } while (0)
-    if (!tr && one_per_cu && !getenv("BBX_WIDE_NO1CU")) {
-      if (W_ == 2) { if (lazy) BBX_WIDE_LAUNCH1(2, true, false); else if (acct) BBX_WIDE_LAUNCH1(2, false, true); else BBX_WIDE_LAUNCH1(2, false, false); }
-      else { if (lazy) BBX_WIDE_LAUNCH1(4, true, false); else if (acct) BBX_WIDE_LAUNCH1(4, false, true); else BBX_WIDE_LAUNCH1(4, false, false); }
-    } else if (!tr && !lazy && !acct) {
-      if (W_ == 2) BBX_WIDE_LAUNCHE(2); else BBX_WIDE_LAUNCHE(4);
-    } else
-    if (W_ == 2) { if (tr) { if (lazy) BBX_WIDE_LAUNCH(2, true, true); else BBX_WIDE_LAUNCH(2, true, false); }
-                   else { if (lazy) BBX_WIDE_LAUNCH(2, false, true); else BBX_WIDE_LAUNCH(2, false, false); } }
-    else { if (tr) { if (lazy) BBX_WIDE_LAUNCH(4, true, true); else BBX_WIDE_LAUNCH(4, true, false); }
-           else { if (lazy) BBX_WIDE_LAUNCH(4, false, true); else BBX_WIDE_LAUNCH(4, false, false); } }
-#undef BBX_WIDE_LAUNCH
-#undef BBX_WIDE_LAUNCH1
-#undef BBX_WIDE_LAUNCHE
-    return (int)hipGetLastError();
-  }
-  const size_t lds = kind == 1 ? (size_t)envs_per_block * p->LL.rec_bytes : 0;
-  int rc = p->L.W == 2 ? launch_w<2>(p, kind, blocks, threads, lds, stream)
-         : p->L.W == 4 ? launch_w<4>(p, kind, blocks, threads, lds, stream) : launch_w<8>(p, kind, blocks, threads, lds, stream);
-  if (rc) return rc;
-  return (int)hipGetLastError();
 }

@@ -1,4 +1,4 @@
-// The hand-tuned kernel for the headline class (included by bbx_kernels.hip):
+// The hand-tuned kernel for the headline class (kernels; bbx_fast.hip holds the launcher):
 //   <= 3 variables (8-byte monomials), binomial ideals, Gebauer-Moeller elimination, sorted reducers —
 //   i.e. what the reference's C++ LeadMonomialsEnv always runs (buchberger.cpp:377) on 3-20-10-weighted.
 //
@@ -16,7 +16,7 @@
 // What makes it fast: everything a wave decides about its environment is wave-uniform and is
 // kept provably so for the compiler (scalar branches, the reduction loop on scalar registers); the launch shape that
 // is benchmarked and the common |G| < 64 case have their own instantiations without the general cases' code; new
-// ideals are drawn right here at reset (gen_binomial in bbx_kernels.hip).
+// ideals are drawn right here at reset (gen_binomial in bbx_device.h).
 //
 // Gebauer-Moeller new pairs without the std::map walk (buchberger.cpp:78-91): the lcms L_i = lcm(LM G_i, LM f) that
 // survive are exactly those minimal under divisibility.  They are peeled by increasing degree: all candidates of
@@ -152,7 +152,7 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem, in
   const uint32_t agent_seed = (uint32_t)uni((int)ghdr->agent_seed);
   int budget = uni(ghdr->budget), rollout_pos = uni(ghdr->rollout_pos), done_last = uni(ghdr->done_last);
   if (status == BBX_ST_STARVED || status == BBX_ST_SPILL) status = BBX_ST_OK;
-  if (p.set_budget) { budget = p.nsteps; rollout_pos = 0; done_last = 0; }
+  if (p.set_budget) { budget = bbx_st_capacity(status) ? budget + p.nsteps : p.nsteps; rollout_pos = 0; done_last = 0; }   // (bbx_common.h: bbx_st_capacity)
   if (p.pass == 1 && !(status == BBX_ST_OK && (need_reset || (budget > 0 && nP > 0)))) return;
 
   // HBM record arrays (binomial layout: every array 16-B aligned, capacities hbmG / maxP); the addresses are only
@@ -746,7 +746,7 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem, in
   if (lane == 0) {
     BbxHdr* h = (BbxHdr*)(cz->recs + (size_t)env * cz->rec_bytes);
     // steps done = the rollout budget this launch started with minus what is left (the header still holds the old one)
-    const int steps_done = (cz->set_budget ? cz->nsteps : h->budget) - budget;
+    const int steps_done = (cz->set_budget ? (bbx_st_capacity(status) ? h->budget + cz->nsteps : cz->nsteps) : h->budget) - budget;
     rollout_pos = (cz->set_budget ? 0 : h->rollout_pos) + steps_done;
     h->nG = nG; h->nP = nP; h->arena_used = 0; h->status = status; h->need_reset = need_reset;
     h->q_head = q_head; h->t = t_agent; h->total_steps += steps_done; h->total_additions += adds;

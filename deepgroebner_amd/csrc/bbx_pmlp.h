@@ -1,5 +1,5 @@
-// PMLP policy on the observation block (included by bbx_kernels.hip before the step kernels: the fast class has a
-// policy + step launch).
+// PMLP policy on the observation block (included by the binomial / fast / aux translation units: the step kernels of
+// the binomial classes have the policy built in).
 #pragma once
 
 // ------------------------------------------------------------------ the consumer of the observation block: PMLP policy
@@ -77,20 +77,6 @@ __host__ __device__ constexpr int pmlp_nb_for(int hidden) { const int nb = (hidd
 // prepared weights (floats): W1p [2 KS][32 NB] | b1p [32 NB] | w2p [32 NB] | b2 | pad to a multiple of 4
 __host__ __device__ constexpr int pmlp_prepared_floats(int cols, int hidden) {
   return (2 * pmlp_ks_for(cols) + 2) * 32 * pmlp_nb_for(hidden) + 4;
-}
-__global__ void bbx_pmlp_prepare_kernel(const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2, float b2,
-                                        int cols, int hidden, float* __restrict__ out) {
-  const int HP = 32 * pmlp_nb_for(hidden), K2 = 2 * pmlp_ks_for(cols);
-  const int total = (K2 + 2) * HP + 4;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    const int k = i / HP, h = i - k * HP;
-    float v = 0.f;
-    if (k < K2) v = (k < cols && h < hidden) ? w1[(size_t)k * hidden + h] : 0.f;
-    else if (k == K2) v = h < hidden ? b1[h] : 0.f;
-    else if (k == K2 + 1) v = h < hidden ? w2[h] : 0.f;
-    else v = h == 0 ? b2 : 0.f;
-    out[i] = v;
-  }
 }
 // one tile: the logit (without b2) of row (lane & 31) from the lane's B operands xa[]; G unit blocks in flight together
 // (registers: 32 G + G KS)

@@ -1,4 +1,4 @@
-// Wide class of the step kernel (included by bbx_kernels.hip): ONE WORKGROUP PER ENVIRONMENT, for environments whose
+// Wide class of the step kernel (kernels; bbx_wide.hip holds the launcher): ONE WORKGROUP PER ENVIRONMENT, for environments whose
 // polynomials are long and whose number is small (fixed ideals such as cyclic-n; BASELINE config "cyclic-7, batch 512").
 //
 // Reference semantics reproduced bit for bit: buchberger.cpp:18-21 (spoly), 24-49 (reduce: first divisor in G_ order,
@@ -49,6 +49,7 @@ struct WideCold {
   double vret, vdisc, last_reward;
   int episode_steps, episodes, zero_red, steps_done, rollout_pos, done_last, obs_trunc, q_head;
   uint32_t std_rng, gen_state;
+  uint32_t rng_mark;                                      // std_rng before the step in progress (restored when the step has to be taken again)
 };
 struct __attribute__((aligned(16))) WideCtl {             // LDS control block (parity double-buffered exchange slots)
   int wfound[2][WNWMAX];                                  // per-wave first divisor of a scan chunk (absent waves: INT_MAX)
@@ -484,14 +485,14 @@ __device__ __forceinline__ void wide_body(char* smem) {
     status = uni(h->status); need_reset = uni(h->need_reset); budget = uni(h->budget); t_agent = uni(h->t);
     agent_seed = (uint32_t)uni((int)h->agent_seed);
     if (status == BBX_ST_STARVED || status == BBX_ST_SPILL) status = BBX_ST_OK;
-    if (p.set_budget) budget = p.nsteps;
+    if (p.set_budget) budget = bbx_st_capacity(status) ? budget + p.nsteps : p.nsteps;   // (bbx_common.h: bbx_st_capacity)
     if (p.pass == 1 && !(status == BBX_ST_OK && (need_reset || (budget > 0 && nP > 0)))) return;   // (whole workgroup)
     if (x.tid == 0) {
       st->total_steps = h->total_steps; st->total_adds = h->total_additions; st->alg_bytes = h->alg_bytes;
       st->vret = h->vret; st->vdisc = h->vdisc; st->last_reward = 0.0;
       st->episode_steps = h->episode_steps; st->episodes = h->episodes; st->zero_red = h->zero_reductions; st->steps_done = 0;
       st->rollout_pos = h->rollout_pos; st->done_last = h->done_last; st->obs_trunc = h->obs_trunc; st->q_head = h->q_head;
-      st->std_rng = h->std_rng; st->gen_state = h->gen_rng;
+      st->std_rng = h->std_rng; st->gen_state = h->gen_rng; st->rng_mark = h->std_rng;
       if (p.set_budget) { st->rollout_pos = 0; st->done_last = 0; st->vret = 0.0; st->vdisc = 1.0; st->obs_trunc = 0; }
     }
   }
@@ -622,6 +623,7 @@ __device__ __forceinline__ void wide_body(char* smem) {
     }
     if (budget <= 0) break;
     if (nP == 0) break;
+    if (x.tid == 0) st->rng_mark = st->std_rng;
     {
       const BbxParams& p = wide_params();
       if (nG + 1 > (int)p.L.maxG || nP - 1 + nG > (int)p.L.maxP || arena_used + maxT > (int)p.L.arena) {   // before anything is modified
@@ -666,16 +668,9 @@ __device__ __forceinline__ void wide_body(char* smem) {
       if (action < 0 || action >= nP) { status = BBX_ST_BAD_ACTION; break; }
       const uint32_t pr = (uint32_t)uni((int)e.pairs[action]);
       const int gi = pr & 0xffffu, gj = pr >> 16;
-      // P.erase(remove(action))  buchberger.cpp:319 — stable, all threads; the barrier of the first trip also orders the
-      // read of pairs[action] above before any write
-      for (int base = action; base < nP - 1; base += x.NT) {
-        const int k = base + x.tid;
-        uint32_t v = 0;
-        if (k < nP - 1) v = e.pairs[k + 1];
-        __syncthreads();
-        if (k < nP - 1) e.pairs[k] = v;
-      }
-      nP -= 1;
+      // (the pair leaves P — buchberger.cpp:319 — only once the reduction is through: until then the step works in LDS,
+      // the scratch buffers and the free end of the arena, so a capacity miss leaves the record as the step found it and
+      // the step is taken again after the host has enlarged the record: bbx_common.h, bbx_st_capacity)
 
       // S-polynomial  buchberger.cpp:18-21: h <- (gamma / LT g_i) tail(g_i); the loop below subtracts (gamma / LT g_j) tail(g_j)
       const Mono<W> lmi = e.lm[gi], lmj = e.lm[gj];
@@ -869,8 +864,24 @@ __device__ __forceinline__ void wide_body(char* smem) {
       }
     }
     if (overflow) break;
+    if (rn > 65535) { status = BBX_ST_POLY_LIMIT; break; }                    // plen[] is 16 bits
     flush_r();
     rsug = rsug > hsug ? rsug : hsug;                                         // sugar of r + h (48)
+    {
+      // P.erase(remove(action))  buchberger.cpp:319 — stable, all threads (flush_r's barrier orders every earlier read of
+      // the pair list before the first write); from here on the step cannot fail for capacity
+      const BbxParams& p = wide_params();
+      const Env<W> e = env_view<W>(WIDE_REC(p), p.L);
+      for (int base = action; base < nP - 1; base += x.NT) {
+        const int k = base + x.tid;
+        uint32_t v = 0;
+        if (k < nP - 1) v = e.pairs[k + 1];
+        __syncthreads();
+        if (k < nP - 1) e.pairs[k] = v;
+      }
+      nP -= 1;
+      __syncthreads();                                                        // the list is complete for whoever reads it next
+    }
     WSTAMP(3);
 
     // ---- basis / pair-set update  buchberger.cpp:321-327: leader, wave-level code on the HBM record ----------------
@@ -928,7 +939,7 @@ __device__ __forceinline__ void wide_body(char* smem) {
       const int obs_trunc = st->obs_trunc | ((p.obs && status == BBX_ST_OK && nP > p.obs_rows) ? 1 : 0);
       const int steps_done = st->steps_done, done_last = st->done_last, q_head = st->q_head;
       h->nG = nG; h->nP = nP; h->arena_used = arena_used; h->status = status; h->need_reset = need_reset;
-      h->q_head = q_head; h->t = t_agent; h->std_rng = st->std_rng; h->gen_rng = st->gen_state; h->episode_steps = st->episode_steps;
+      h->q_head = q_head; h->t = t_agent; h->std_rng = bbx_st_capacity(status) ? st->rng_mark : st->std_rng; h->gen_rng = st->gen_state; h->episode_steps = st->episode_steps;
       h->total_steps = st->total_steps; h->total_additions = st->total_adds; h->episodes = st->episodes; h->zero_reductions = st->zero_red;
       h->steps_done = steps_done; h->budget = budget; h->rollout_pos = st->rollout_pos; h->done_last = done_last; h->alg_bytes = st->alg_bytes;
       h->vret = st->vret; h->vdisc = st->vdisc; h->obs_trunc = obs_trunc;

@@ -42,7 +42,8 @@ enum { BBX_EXTERNAL = 0, BBX_RANDOM_HASH = 1, BBX_DEGREE = 2, BBX_FIRST = 3, BBX
           Random as the reference draws it from a seeded std::default_random_engine (see bbx_seed_strategy) */
        BBX_LAST = 6, BBX_CODEGREE = 7, BBX_STRANGE = 8, BBX_SPICE = 9, BBX_RANDOM_STD = 10 };
 
-/* Per-environment capacities; 0 picks a default suited to the distribution. */
+/* Per-environment capacities; 0 picks a default suited to the distribution.  Hard limits that remain: 65534 basis
+ * elements (pairs are two 16-bit indices), 65535 terms per BASIS element, 2^22 terms per intermediate polynomial. */
 typedef struct bbx_caps {
   int32_t max_basis;      /* |G|  (<= 65535) */
   int32_t max_pairs;      /* |P| */
@@ -58,6 +59,11 @@ typedef struct bbx_caps {
   int32_t wide_lds_terms; /* wide class (fixed ideals, one workgroup per environment): terms of the polynomial being
                              reduced kept in LDS (also sizes the reducer window and table); 0 = as much as the LDS
                              holds.  Longer polynomials continue on HBM-resident buffers, so this only affects speed */
+  int32_t no_growth;      /* 0 (default): max_basis / max_pairs / arena_terms / max_poly_terms are STARTING sizes — an
+                             environment that outgrows one stops before the step that does not fit, the library doubles
+                             that array for the whole batch (device memory permitting) and the environment continues, as
+                             the reference's heap vectors would (polynomials.h:71-94): capacity costs time, never results.
+                             Non-zero: they are hard limits and exceeding one is BBX_E_CAPACITY */
 } bbx_caps;
 
 /* One record per environment per step of a traced rollout (parity tests). */
@@ -222,6 +228,9 @@ int bbx_timing(bbx_batch* b, int enable, double* kernel_ms, int32_t* launches);
  * ideals_consumed, algorithmic_bytes (the roofline numerator), basis_size */
 int bbx_stats(bbx_batch* b, int64_t* out8);
 int bbx_env_status(bbx_batch* b, int32_t* status);
+/* the current per-environment capacities (they grow on demand, see bbx_caps.no_growth) and how often they grew:
+ * out5 = {max_basis, max_pairs, arena_terms, max_poly_terms, times enlarged} */
+int bbx_capacities(bbx_batch* b, int32_t* out5);
 int bbx_state_sizes(bbx_batch* b, int idx, int32_t* basis_size, int32_t* npairs, int32_t* nterms_total);
 /* G[0..basis_size): nterms[i], then concatenated coefs and exps (8 ints per term); pairs as (i,j);
  * order[r] = index into G of the r-th reducer */

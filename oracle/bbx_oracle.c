@@ -364,11 +364,17 @@ typedef struct { long long lm_scanned, f_terms, h_terms; } reduce_acct;
 
 /* buchberger.cpp:24-49: full (head+tail) division; first divisor in the order
  * of F wins; steps counts successful reductions only */
+/* test statistic: the longest polynomial a reduction of this thread has held (tests pick inputs that outgrow the
+ * device's starting capacities with it); bo_stat_max_terms(1) reads and clears it */
+static __thread int bo_max_terms = 0;
+int bo_stat_max_terms(int reset) { const int v = bo_max_terms; if (reset) bo_max_terms = 0; return v; }
+
 static poly reduce(const poly* g, const poly* const* F, int nF, int* steps_out, reduce_acct* acct) {
   int steps = 0;
   poly r; poly_init(&r);
   poly h = poly_clone(g);
   while (h.n != 0) {
+    if (h.n > bo_max_terms) bo_max_terms = h.n;
     int found = 0;
     for (int k = 0; k < nF; k++) {
       const poly* f = F[k];

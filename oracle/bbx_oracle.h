@@ -85,6 +85,7 @@ void   bo_env_reducer_order(void* e, int* out);
 void   bo_env_obs(void* e, int k, int n, int* out);
 /* algorithmic bytes of the last step (SURVEY.md section 8d formula) */
 long long bo_env_last_step_bytes(void* e);
+int bo_stat_max_terms(int reset);   /* longest polynomial held by a reduction of this thread (test statistic) */
 
 /* ---- batch driver used as the CPU baseline ("port") ----------------------- */
 double bo_bench_random(const char* dist, int k, int nenvs, int nsteps, int seed0, int agent_seed0,

@@ -77,6 +77,7 @@ def _sig(lib, pre):
       C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_ulonglong))
     if pre == "bo":
         f("env_last_step_bytes", C.c_longlong, _vp)
+        f("stat_max_terms", C.c_int, C.c_int)
         f("run_random", C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_longlong))
     else:
         f("lme_new", _vp, C.c_char_p, C.c_int, C.c_int, C.c_int); f("lme_free", None, _vp)

@@ -38,6 +38,10 @@ TRACES = {
     # sort_input with sorted reducers (BuchbergerEnv::reset sorts the drawn generators, buchberger.cpp:299-303)
     "w3_sortinput": ("3-20-10-weighted", {"sort_input": True}, 2, 4, 640, 6, "hash", 160, False),
     "u5_sortinput": ("5-10-5-uniform", {"sort_input": True}, 2, 2, 650, 7, "hash", 200, False),
+    # non-binomial random ideals in >= 5 variables whose intermediate polynomials outgrow the device's starting
+    # max_poly_terms = 4096 (8630 and 13029 terms: oracle statistic bo_stat_max_terms): the records grow on demand
+    "r5_long": ("5-4-4-1.0-uniform", {}, 2, 1, 1177, 177, "hash", 100, False),
+    "r8_long": ("8-4-4-0.5-uniform", {}, 2, 1, 1092, 92, "hash", 100, False),
 }
 
 GENERATORS = [

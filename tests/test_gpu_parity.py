@@ -82,6 +82,8 @@ def test_golden_trace(name, residency):
         assert len(want["action"]) == T
         compare_with_trace(env, e, want, T, name)
         assert np.array_equal(final_obs[e], want["final_obs"]), name
+    if name.endswith("_long"):                        # these runs outgrow the starting scratch: the records were enlarged
+        assert env.capacities()["max_poly_terms"] > 4096 and env.capacities()["grown"] > 0, env.capacities()
 
 
 def test_gym_surface_single_env_vs_oracle():
@@ -198,13 +200,103 @@ def test_copy_is_deep():
 
 
 def test_capacity_overflow_is_reported_not_wrapped():
+    """caps['no_growth']: the configured capacities are hard limits and exceeding one is BBX_E_CAPACITY."""
     from deepgroebner_amd import VecLeadMonomialsEnv, _ffi
-    env = VecLeadMonomialsEnv("3-20-10-weighted", batch=4, k=1, caps={"max_basis": 12, "max_pairs": 16})
+    env = VecLeadMonomialsEnv("3-20-10-weighted", batch=4, k=1, caps={"max_basis": 12, "max_pairs": 16, "no_growth": 1})
     env.seed(np.arange(4))
     env.reset()
     with pytest.raises(_ffi.BbxError) as ei:
         env.rollout("random", 200, auto_reset=True)
     assert ei.value.code == -3
+
+
+def _assert_equals_oracle_run(env, want, sample_every=1):
+    st = env.stats()
+    assert (st[:, 4] == 0).all(), st[:, 4]
+    for key, col in (("steps", 0), ("additions", 1), ("episodes", 2), ("zero_reductions", 3), ("nG", 7)):
+        w = np.array([r[key] for r in want])
+        assert np.array_equal(st[:, col], w), (key, int(np.flatnonzero(st[:, col] != w)[0]))
+    B = len(want)
+    for e in sorted(set(range(0, B, sample_every)) | {B - 1}):
+        basis, pairs, order = env.state(e)
+        assert fnv64(_state_words(basis, pairs, order)) == want[e]["state_hash"], e
+
+
+@pytest.mark.parametrize("dist,B,T,caps,cls", [
+    # binomial classes: the basis / pair arrays of the HBM record start far too small
+    ("3-20-10-weighted", 9, 200, {"max_basis": 12, "max_pairs": 16}, "fast + binomial continuation"),
+    ("3-20-10-weighted", 9, 200, {"max_basis": 12, "max_pairs": 16, "lds_max_basis": -1}, "binomial, HBM-resident"),
+    ("5-10-5-uniform", 5, 300, {"max_basis": 16, "max_pairs": 32}, "binomial, 16-byte monomials"),
+    # general class: every array starts tiny (scratch of 8 terms, arena of 64): dozens of doublings
+    ("3-20-10-weighted", 9, 120, {"general_class": 1, "lds_max_basis": -1, "max_basis": 8, "max_pairs": 8, "arena_terms": 32, "max_poly_terms": 4}, "general on binomials"),
+    ("3-5-4-0.5-uniform", 9, 100, {"max_basis": 8, "max_pairs": 8, "arena_terms": 64, "max_poly_terms": 8}, "general"),
+    ("5-4-4-1.0-uniform", 17, 60, {"max_basis": 8, "max_pairs": 16, "arena_terms": 64, "max_poly_terms": 16}, "general, long polynomials"),
+    ("8-3-4-1.5-weighted", 5, 40, {"max_basis": 8, "max_pairs": 16, "arena_terms": 64, "max_poly_terms": 16}, "general, 32-byte monomials"),
+])
+def test_capacity_is_a_cliff_not_a_failure(dist, B, T, caps, cls):
+    """Every per-environment array of the record starts far too small: the kernels stop BEFORE the step that does not fit,
+    the host doubles what was full (bbx_api.cpp grow_records) and the step is taken then — counters of every environment
+    and every final state equal the oracle's, as if the capacities had been ample (reference: heap vectors,
+    polynomials.h:71-94, buchberger.cpp:24-99)."""
+    from deepgroebner_amd import VecLeadMonomialsEnv
+    bo = ffi.load("bo")
+    want = bo.run_random_many(dist, 2, range(500, 500 + B), range(B), T, True, 0)
+    env = VecLeadMonomialsEnv(dist, batch=B, k=2, caps=caps)
+    env.seed(np.arange(B) + 500); env.seed_agent(np.arange(B)); env.reset()
+    env.rollout("random", T, auto_reset=True)
+    _assert_equals_oracle_run(env, want)
+    assert env.capacities()["grown"] > 0, cls
+
+
+def test_capacity_growth_keeps_owed_steps_across_async_launches():
+    """Three asynchronous launches queued behind each other, none synchronised: an environment that stops for room in the
+    first keeps adding the later launches' steps to what it owes and takes them all once bbx_sync has enlarged the records."""
+    import torch
+    from deepgroebner_amd import VecLeadMonomialsEnv
+    bo = ffi.load("bo")
+    dist, B, T = "3-5-4-0.5-uniform", 33, 40
+    want = bo.run_random_many(dist, 2, range(500, 500 + B), range(B), 3 * T, True, 0)
+    env = VecLeadMonomialsEnv(dist, batch=B, k=2, caps={"max_basis": 8, "max_pairs": 8, "arena_terms": 64, "max_poly_terms": 8})
+    env.seed(np.arange(B) + 500); env.seed_agent(np.arange(B)); env.reset()
+    rows = torch.zeros(B, dtype=torch.int32, device="cuda")
+    for _ in range(3):
+        env.rollout_device("random", T, True, torch.cuda.current_stream().cuda_stream, rows=rows)
+    env.sync()
+    _assert_equals_oracle_run(env, want)
+    assert np.array_equal(rows.cpu().numpy(), np.array([r["nP"] for r in want]))
+
+
+def test_capacity_growth_wide_class_and_strategies():
+    """Fixed ideals on the wide (one workgroup per environment) class with a tiny arena and scratch: cyclic-5 under the
+    seeded std::random selection — whose engine state must rewind when a step is taken again — and Degree, to completion."""
+    from deepgroebner_amd import VecLeadMonomialsEnv
+    from deepgroebner_amd.ideals import FixedIdealGenerator, cyclic
+    bo = ffi.load("bo")
+    for sel, seed in (("degree", None), ("random", 77), ("sugar", None)):
+        env = VecLeadMonomialsEnv(FixedIdealGenerator(cyclic(5)), batch=3, k=1, caps={"max_basis": 8, "max_pairs": 16, "arena_terms": 64, "max_poly_terms": 16})
+        if seed is not None:
+            env.seed_strategy(seed)
+        env.reset()
+        env.rollout("random_std" if seed is not None else sel, 1 << 30, auto_reset=False)
+        st = env.stats()
+        _, w = bo.buchberger(bo.cyclic(5), selection=sel, want_basis=False, seed=seed)
+        for e in range(3):
+            assert (st[e, 3], st[e, 0] - st[e, 3], st[e, 1]) == (w["zero_reductions"], w["nonzero_reductions"], w["polynomial_additions"]), (sel, e)
+        assert env.capacities()["grown"] > 0
+
+
+def test_full_size_non_binomial_8_variables_vs_oracle():
+    """8-4-4-0.5-uniform at B=4096 x T=25 on the general class at DEFAULT capacities (round 2: BBX_E_CAPACITY in environment
+    3245): counters of all environments, the complete final state of every 16th."""
+    from deepgroebner_amd import VecLeadMonomialsEnv
+    bo = ffi.load("bo")
+    dist, B, T = "8-4-4-0.5-uniform", 4096, 25
+    want = bo.run_random_many(dist, 2, range(1000, 1000 + B), range(B), T, True, 0)
+    env = VecLeadMonomialsEnv(dist, batch=B, k=2)
+    env.seed(np.arange(B) + 1000); env.seed_agent(np.arange(B)); env.reset()
+    env.accounting(False)
+    env.rollout("random", T, auto_reset=True)
+    _assert_equals_oracle_run(env, want, 16)
 
 
 def test_algorithmic_byte_counter_matches_oracle():
