@@ -15,9 +15,14 @@ Measurement protocol (so that the line means the same at --steps 20 and at --ste
     state (a mix of episode phases) rather than all environments in their first episode;
   * W warm-up steps (one launch), then eight chained calibration launches of K steps (untimed);
   * timed region: R back-to-back launches of K steps each (`repeats`; R is chosen so that the region lasts >= 60 ms),
-    enqueued asynchronously on one stream, bracketed by barrier + synchronize on both sides; `ms_per_step` is the
-    region's wall time / (R*K), `value` = batch * R * K / wall time (max over ranks);
-  * `roofline.kernel_ms_per_launch` = HIP-event time of the region on the launch stream / R.
+    enqueued asynchronously, bracketed by barrier + synchronize on both sides; `ms_per_step` is the region's wall time /
+    (R*K), `value` = batch * R * K / wall time (max over ranks).  The launches go through a persistent session
+    (bbx_persistent, include/bbx.h): the first starts the step kernel, the others raise a device-visible step counter
+    its waves look at, so environments never wait for each other between launches (`config.launch_path`;
+    --no-persistent issues one kernel per launch, the round-2 path);
+  * `roofline.kernel_ms_per_launch` = HIP-event time of the region / R: the events are recorded on the caller's stream,
+    the first before the first launch, the second behind bbx_join (which makes that stream wait, on the device, for the
+    session's kernels).
 
 Prints ONE JSON line on rank 0 with `roofline` and `cpu_baseline` objects (the only thing that reaches stdout: everything
 else, native libraries' chatter included, is sent to stderr).  With --gpus N > 1 and no launcher
@@ -57,9 +62,12 @@ def parse_args():
                     help="diagnostic: pad the observation with -1 (obs_fill), which selects bbx_fast_kernel<false,false> "
                          "instead of the compile-time specialised headline variant")
     ap.add_argument("--cpu-sample-envs", type=int, default=0)
-    ap.add_argument("--long-launch", action="store_true",
-                    help="context figure after the timed region: the same kernel in 8 launches of 1024 steps (not with rocprofv3: "
-                         "it would mix two launch lengths into the kernel's average)")
+    ap.add_argument("--no-long-launch", action="store_true",
+                    help="skip the context figure after the timed region (the same workload in 8 launches of 1024 steps; skip it under "
+                         "rocprofv3: it would mix two launch lengths into the kernel's average)")
+    ap.add_argument("--no-persistent", action="store_true", help="one kernel per launch instead of a persistent session")
+    ap.add_argument("--allow-oversubscribe", action="store_true",
+                    help="rehearsal only: accept more ranks than visible GPUs (the line then says \"oversubscribed\": true)")
     return ap.parse_args()
 
 
@@ -106,8 +114,18 @@ def main():
     ndev = torch.cuda.device_count()
     if ndev < 1:
         raise SystemExit("no GPU visible: libbbx has no CPU fallback")
-    device = local_rank % ndev                       # (more ranks than GPUs only when rehearsing the launch on a smaller box)
+    # one rank per distinct GPU, or the line must say otherwise: a scaling figure from ranks that share a device is not one
+    oversubscribed = world > ndev
+    if oversubscribed and not args.allow_oversubscribe:
+        raise SystemExit("--gpus %d but only %d GPU(s) visible: refusing to oversubscribe (rehearsals: --allow-oversubscribe)" % (world, ndev))
+    device = local_rank % ndev
     torch.cuda.set_device(device)
+    uuid = str(torch.cuda.get_device_properties(device).uuid) if hasattr(torch.cuda.get_device_properties(device), "uuid") else "dev%d" % device
+    if world > 1:
+        uuids = [None] * world
+        dist.all_gather_object(uuids, uuid)
+        if not oversubscribed and len(set(uuids)) != world:
+            raise SystemExit("ranks share a GPU (device ids %s) although %d are visible" % (uuids, ndev))
     from deepgroebner_amd import VecLeadMonomialsEnv
     from deepgroebner_amd.shard import plan
 
@@ -134,12 +152,14 @@ def main():
             env.sync()
 
     env.accounting(False)                             # lean kernel (no per-step byte counting) from here on
+    persistent = chain and not args.no_persistent and not args.generic_kernel
+    env.persistent(persistent)
     launch(max(args.preroll, 0) or 1); env.sync()     # steady state
     if Wm > 0:
         launch(Wm); env.sync()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    ncal = 8 if chain else 1                         # calibration (also the untimed warm-up of this launch shape): chained
+    ncal = (64 if persistent else 8) if chain else 1 # calibration (also the untimed warm-up of this launch shape): chained
     for _ in range(ncal):                             # launches, so that the synchronisation is not mistaken for launch time
         launch(K)
     env.sync(); torch.cuda.synchronize()
@@ -150,6 +170,7 @@ def main():
         dist.all_gather_object(r_all, R)
         R = max(r_all)
     st0 = env.stats()
+    sess0 = env.session_stats()
     twin = env.copy()                               # same state, same generator state: replayed after the timed region
 
     torch.cuda.synchronize()
@@ -160,6 +181,7 @@ def main():
     ev0.record(stream)
     for _ in range(R):
         launch(K)
+    env.join(stream.cuda_stream)                    # (persistent session: the caller's stream waits for its kernels, on the device)
     ev1.record(stream)
     env.sync()
     torch.cuda.synchronize()
@@ -172,7 +194,8 @@ def main():
     # context, outside the timed region: the same kernel in launches of 1024 steps (how a rollout would normally be
     # issued; launches of few steps end with the waves that met an episode reset)
     long_launch = None
-    if args.long_launch and world == 1:
+    sess = env.session_stats()
+    if not args.no_long_launch and world == 1:
         torch.cuda.synchronize()
         tl0 = time.perf_counter()
         for _ in range(8):
@@ -195,7 +218,10 @@ def main():
     alg_bytes = int(dt[:, 6].sum())
     del twin
 
+    per_rank = [steps_done / elapsed]
     if world > 1:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, steps_done / elapsed)
         t = torch.tensor([elapsed, region_ms], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, region_ms = float(t[0]), float(t[1])
@@ -209,7 +235,7 @@ def main():
 
     if rank == 0:
         value = steps_done / elapsed
-        kernel = "bbx_fast_headline_kernel" if not args.generic_kernel else "bbx_fast_kernel<false,false>"
+        kernel = ("bbx_fast_headline_persistent_kernel" if persistent else "bbx_fast_headline_kernel") if not args.generic_kernel else "bbx_fast_kernel<false,false>"
         # the dominant (only) kernel: per launch, algorithmic bytes of ONE GPU / its HIP-event duration
         per_launch_bytes = alg_bytes / world / R
         per_launch_s = region_ms * 1e-3 / R
@@ -220,7 +246,10 @@ def main():
                         "register/LDS resident, the measured HBM traffic (`traffic`) is a fraction of a percent of it, and "
                         "the kernel is bound by per-wave instruction issue (see `issue_bound`)",
                 "alg_bytes_per_launch": per_launch_bytes, "alg_bytes_per_env_step": alg_bytes / steps_done,
-                "kernel": kernel, "kernel_ms_per_launch": region_ms / R, "launches": R, "timed_region_ms": region_ms}
+                "kernel": kernel, "kernel_ms_per_launch": region_ms / R, "launches": R, "timed_region_ms": region_ms,
+                "kernels_in_timed_region": (sess["kernels"] - sess0["kernels"]) if persistent else R,
+                "launch_note": ("the R launches of the timed region are served by the kernels of one persistent session (time slices of 10 ms); "
+                                "kernel_ms_per_launch = HIP-event time of the region / R") if persistent else "one kernel per launch"}
         pf = os.path.join(ROOT, PMC_PROFILE)
         if os.path.exists(pf) and args.dist == DIST and B == BATCH and not args.generic_kernel:
             prof = json.load(open(pf))
@@ -240,7 +269,8 @@ def main():
             "repeats": R, "preroll_steps": max(args.preroll, 0) or 1, "timed_steps": R * K, "elapsed_s": elapsed,
             "config": {"workload": "%s k=%d batch=%d/GPU random-hash agent auto-reset, observation written every step" % (args.dist, K_LEADS, B),
                        "global_batch": B * world, "steps_per_launch": K, "parallelism": "env-sharded x%d, no collectives" % world,
-                       "devices_visible": ndev},
+                       "devices_visible": ndev, "launch_path": "persistent session (bbx_persistent)" if persistent else "one kernel per launch"},
+            "oversubscribed": bool(oversubscribed), "per_rank_value": per_rank,
             "additions": additions,
             "additions_per_s": additions / elapsed,
             "long_launch": long_launch,

@@ -80,6 +80,9 @@ SIGNATURES = {
     "bbx_stats": (C.c_int, [_vp, _vp]),
     "bbx_env_status": (C.c_int, [_vp, _vp]),
     "bbx_capacities": (C.c_int, [_vp, _vp]),
+    "bbx_persistent": (C.c_int, [_vp, C.c_int]),
+    "bbx_join": (C.c_int, [_vp, _vp]),
+    "bbx_session_stats": (C.c_int, [_vp, _vp]),
     "bbx_state_sizes": (C.c_int, [_vp, C.c_int, _i32p, _i32p, _i32p]),
     "bbx_state_get": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     "bbx_reduced_basis": (C.c_int, [_vp, C.c_int, _i32p, _i32p, _vp, _vp, _vp]),

@@ -291,6 +291,21 @@ class VecLeadMonomialsEnv:
     def sync(self):
         _ffi.check(_ffi.lib().bbx_sync(self._h))
 
+    def persistent(self, enable=True):
+        """Persistent sessions (bbx_persistent): asynchronous rollout_device calls queued behind each other feed ONE running
+        kernel through a device-visible step counter instead of becoming a kernel each; environments never wait for each
+        other between calls.  Outputs are ready for the caller's stream after join(stream) or sync()."""
+        _ffi.check(_ffi.lib().bbx_persistent(self._h, int(enable)))
+
+    def session_stats(self):
+        out = np.zeros(4, dtype=np.int64)
+        _ffi.check(_ffi.lib().bbx_session_stats(self._h, _ffi.ptr(out)))
+        return dict(zip(("sessions", "joined", "later_kernel_steps", "kernels"), (int(v) for v in out)))
+
+    def join(self, stream=0):
+        """Device-side end of the persistent session in flight: `stream` waits for it (the host does not)."""
+        _ffi.check(_ffi.lib().bbx_join(self._h, C.c_void_p(int(stream))))
+
     def accounting(self, enable):
         """Toggle per-step algorithmic-byte accounting (stats()[:, 6]); off selects the leanest kernel."""
         _ffi.check(_ffi.lib().bbx_accounting(self._h, int(enable)))

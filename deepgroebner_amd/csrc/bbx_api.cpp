@@ -23,6 +23,7 @@ extern "C" int bbx_launch_step(const BbxParams* p, int kind, int envs_per_block,
 extern "C" int bbx_launch_clone(const char* src_recs, char* dst_recs, const BbxLayout* L, const int32_t* src, const int32_t* dst, int n,
                                 const uint32_t* seeds, int keep_counters, hipStream_t stream);
 extern "C" int bbx_launch_relayout(const char* src_recs, char* dst_recs, const BbxLayout* Ls, const BbxLayout* Ld, int B, hipStream_t stream);
+extern "C" int bbx_launch_ctl(unsigned long long* ctl, unsigned long long value, hipStream_t stream);
 extern "C" int bbx_launch_gather_lite(const char* recs, uint32_t rec_bytes, int B, void* out, hipStream_t stream);
 extern "C" int bbx_launch_gather_hdr(const char* recs, uint32_t rec_bytes, int B, BbxHdr* out, hipStream_t stream);
 extern "C" int bbx_launch_scatter_queue(const uint32_t* stage, int n, uint32_t ring_words, uint32_t* q, int32_t* tail, hipStream_t stream);
@@ -147,6 +148,14 @@ struct bbx_batch {
   bool device_async = false;          // the launch in flight came through a *_device entry point (no host poll per step)
   bool obs_external = false;          // the launch in flight writes observations into a caller-owned block: rows cut for
                                       // lack of space are an error the caller must hear about (bbx_sync)
+  // persistent sessions (bbx_persistent): see BbxParams::ctl
+  bool ps_enabled = false, ps_active = false;
+  unsigned long long* d_ctl = nullptr;
+  hipStream_t ps_stream = nullptr, ps_ctl_stream = nullptr;   // the session's kernel / the writes to its control word
+  hipEvent_t ps_ev = nullptr;
+  long long ps_target = 0;            // steps issued since the session began
+  BbxParams ps_p{};                   // the parameters of the call that began it (later calls must match to join)
+  int ps_sessions = 0, ps_joined = 0, ps_kernels = 0; // statistics: sessions begun, calls that joined a running one, kernels
   bool no_growth = false;             // bbx_caps.no_growth: the configured capacities are hard limits (BBX_E_CAPACITY)
   int grow_events = 0;                // times the records were enlarged (bbx_capacities)
   bbx_batch() = default;
@@ -160,6 +169,10 @@ bbx_batch::~bbx_batch() {
   (void)hipSetDevice(device);
   (void)hipDeviceSynchronize();
   for (auto& ev : ev_open) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+  if (d_ctl) (void)hipFree(d_ctl);
+  if (ps_ev) (void)hipEventDestroy(ps_ev);
+  if (ps_stream) (void)hipStreamDestroy(ps_stream);
+  if (ps_ctl_stream) (void)hipStreamDestroy(ps_ctl_stream);
   void* dev[] = {d_recs, d_q, d_tail, d_out, d_actions, d_mask, d_seeds, d_obs, d_trace, d_hdr, d_inv,
                  d_vrecs, d_vhdr, d_vsrc, d_vseeds, d_vvals, d_stage, d_gen, d_obs_off, d_obs_packed};
   for (void* q : dev) if (q) (void)hipFree(q);
@@ -316,6 +329,7 @@ void fill_params(bbx_batch* b, BbxParams* p) {
   p->lite = b->d_lite;
   p->gen = b->device_gen ? b->d_gen : nullptr;
   p->wide_hc = b->wide_terms;
+  p->ctl_stats = b->d_ctl ? b->d_ctl + 8 : nullptr;
 }
 
 // enqueue the kernels of one logical launch: the LDS-staged pass (when the class allows) followed by the
@@ -324,6 +338,8 @@ int enqueue(bbx_batch* b, const BbxParams& p0, bool resume, hipStream_t stream) 
   BbxParams p = p0;
   int kinds[2]; int nk = 0;
   if (p.nsteps == 0 && !resume) kinds[nk++] = 2;
+  else if (p.ctl) { kinds[nk++] = 3; kinds[nk++] = 0; }   // a kernel of a persistent session, and behind it the HBM-resident
+                                                      // class for the environments that outgrew the register/LDS class
   else if (b->wide) kinds[nk++] = 4;
   else {   // the hand-tuned kernel knows the external / random / degree / first agents; the others take the class kernel
     const bool pol_hbm_only = p.policy && p.policy->rollout == 2;     // a policy rollout outside the register/LDS class
@@ -345,8 +361,9 @@ int enqueue(bbx_batch* b, const BbxParams& p0, bool resume, hipStream_t stream) 
     std::atomic_thread_fence(std::memory_order_release);
   } else p.done_seq = 0;
   for (int i = 0; i < nk; i++) {
-    if (resume) { p.set_budget = 0; p.pass = 1; }
-    else if (i > 0) { p.set_budget = 0; p.pass = 1; }
+    if (resume || i > 0) { p.set_budget = 0; p.pass = 1; }
+    if (i > 0 && p0.ctl) { p.ctl = nullptr; p.sess_target = p0.nsteps; }   // (what is owed of the session's total when it runs; slice_ticks
+                                                                           // != 0 tells it that the host looks after environments it hands back)
     // a per-step policy call: only the first pass of the fast class evaluates the policy (the follow-up reads its actions);
     // a policy rollout: the HBM-resident continuation pass has the policy too
     if (p.policy && !(p.policy->rollout ? (!resume && (kinds[i] == 3 || kinds[i] == 0)) : (!resume && i == 0 && kinds[i] == 3))) p.policy = nullptr;
@@ -498,9 +515,26 @@ int grow_records(bbx_batch* b, unsigned need, int env, hipStream_t stream) {
 // errors.  Whatever happens, the handle is left with nothing in flight: an error is reported once, not re-raised by
 // every later call, and environments that only needed service (STARVED / SPILL) have been served before the first
 // error of another environment is returned.
+int session_close(bbx_batch* b, bool wait, hipStream_t then, bool sliced);
+int session_kernel(bbx_batch* b, bool first, hipStream_t after, bool sliced);
+
 int finish(bbx_batch* b, hipStream_t stream) {
   int err = BBX_OK;
   auto note = [&err](int code) { if (err == BBX_OK) err = code; };
+  if (b->ps_active) {                                // a persistent session: stop it; its kernels run in slices until nothing is owed
+    int rc = session_close(b, false, nullptr, true);
+    if (rc) { b->in_flight = false; return rc; }
+    stream = b->ps_stream;
+    for (int guard = 0; guard < 100000; guard++) {
+      rc = read_lite(b, stream);
+      if (rc) { b->in_flight = false; return rc; }
+      bool owed = false;
+      for (int e = 0; e < b->B && !owed; e++) owed = (b->h_lite[(size_t)e * 4] & 0xffff) == BBX_ST_TIMESLICE;
+      if (!owed) break;
+      rc = session_kernel(b, false, nullptr, true);
+      if (rc) { b->in_flight = false; return rc; }
+    }
+  }
   for (int round = 0;; round++) {
     int rc = read_lite(b, stream);
     if (rc) { b->in_flight = false; return rc; }
@@ -561,10 +595,96 @@ int finish(bbx_batch* b, hipStream_t stream) {
   return err;
 }
 
+// ---- persistent sessions (bbx_persistent; see BbxParams::ctl) --------------------------------------------------------
+// A kernel that runs for more than ~100 ms is clocked down to about half speed (measured: scripts/exp_overlap.py,
+// DESIGN.md), so a session runs as a sequence of kernels of at most PS_SLICE_TICKS each: a kernel whose slice is over
+// leaves with what its environments still owe (BBX_ST_TIMESLICE) and the next call on the handle starts the next one.
+constexpr uint32_t PS_SLICE_TICKS = 1000000u;            // 10 ms of the 100 MHz clock
+
+int ps_write_ctl(bbx_batch* b, bool stop) {              // all writes to the control word travel on one stream, in order
+  int lrc = bbx_launch_ctl(b->d_ctl, (unsigned long long)b->ps_target | (stop ? (1ull << 32) : 0ull), b->ps_ctl_stream);
+  if (lrc) return fail(BBX_E_DEVICE, "control launch failed: %s", hipGetErrorString((hipError_t)lrc));
+  return BBX_OK;
+}
+
+// Queue a kernel of the session on its stream: the first one (every environment starts with the steps issued so far) or a
+// later one (every environment takes what it still owes of the total), behind the last write to the control word and
+// behind what the caller queued on `after` (or null).  `sliced`: it leaves when its time slice is over.
+int session_kernel(bbx_batch* b, bool first, hipStream_t after, bool sliced) {
+  HIPCHK(hipEventRecord(b->ps_ev, b->ps_ctl_stream));
+  HIPCHK(hipStreamWaitEvent(b->ps_stream, b->ps_ev, 0));
+  if (after) {
+    HIPCHK(hipEventRecord(b->ps_ev, after));
+    HIPCHK(hipStreamWaitEvent(b->ps_stream, b->ps_ev, 0));
+  }
+  BbxParams q = b->ps_p;
+  q.recs = b->d_recs; q.L = b->L; q.ctl = b->d_ctl; q.ctl_stats = b->d_ctl + 8;
+  q.nsteps = (int32_t)b->ps_target; q.slice_ticks = sliced ? PS_SLICE_TICKS : 0u;
+  q.set_budget = first ? 1 : 0; q.sess_target = first ? 0 : (int32_t)b->ps_target; q.pass = 0;
+  b->ps_kernels++;
+  return enqueue(b, q, false, b->ps_stream);
+}
+
+// End the session (asynchronously): the waves are told to stop once they have taken every step issued, and one more kernel
+// of the session is queued behind the running one for whatever environments still owe — those whose wave had left before
+// the last steps were issued (slice over, 20 ms without news) or had handed its environment to the HBM-resident class.
+// `wait`: the stream `then` is made to wait for all of it.  `sliced`: the caller (finish) looks after kernels that
+// leave at the end of their slice; otherwise the closing kernel runs to completion whatever it takes.
+int session_close(bbx_batch* b, bool wait, hipStream_t then, bool sliced) {
+  if (!b->ps_active) return BBX_OK;
+  b->ps_active = false;
+  int rc = ps_write_ctl(b, true);
+  if (rc) return rc;
+  rc = session_kernel(b, false, nullptr, sliced);
+  if (rc) return rc;
+  b->last = b->ps_p; b->last.recs = b->d_recs; b->last.L = b->L;   // (a resumed pass continues from the budgets left in the headers)
+  b->last.ctl = nullptr; b->last.sess_target = 0; b->last.set_budget = 0; b->last.policy = nullptr;
+  b->last_stream = b->ps_stream;
+  if (wait) {                                              // (`then` may be the null stream)
+    HIPCHK(hipEventRecord(b->ps_ev, b->ps_stream));
+    HIPCHK(hipStreamWaitEvent(then, b->ps_ev, 0));
+  }
+  return BBX_OK;
+}
+
+bool session_same_call(const BbxParams& a, const BbxParams& c) {
+  return a.agent == c.agent && a.auto_reset == c.auto_reset && a.rewards == c.rewards && a.dones == c.dones && a.rows == c.rows &&
+         a.obs == c.obs && a.obs_rows == c.obs_rows && a.obs_fill == c.obs_fill && a.obs_every_step == c.obs_every_step &&
+         a.actions == c.actions && a.recs == c.recs;
+}
+
 int launch(bbx_batch* b, BbxParams& p, hipStream_t stream, bool obs_external = false, bool device_async = false) {
   int rc = fill_queues(b, 1, stream);
   if (rc) return rc;
-  b->last = p;
+  // persistent sessions: asynchronous rollouts with a built-in agent on the register/LDS-resident class, lean and untraced,
+  // ideals drawn on the device (nothing for the host to do between launches), every wave of the batch resident at once
+  const bool ps = b->ps_enabled && device_async && b->fast && b->staged && b->device_gen && !b->accounting && !p.policy && p.nsteps >= 1 &&
+                  p.auto_reset && p.obs_fill == 0 && (p.agent == BBX_AGENT_HASH || p.agent == BBX_AGENT_DEGREE || p.agent == BBX_AGENT_FIRST) &&
+                  !(b->d_trace && b->trace_cap >= 1) && !b->timing && b->B <= 4096 && p.set_budget == 1;
+  if (b->ps_active) {
+    if (ps && session_same_call(b->ps_p, p) && b->ps_target + p.nsteps < (1ll << 30)) {
+      b->ps_target += p.nsteps;                        // the waves see the new total the next time they look
+      rc = ps_write_ctl(b, false);
+      if (rc) return rc;
+      // the session's kernel may have left meanwhile (its slice was over, or no news for 20 ms): the next one
+      if (hipStreamQuery(b->ps_stream) == hipSuccess) { rc = session_kernel(b, false, stream, true); if (rc) return rc; }
+      b->ps_joined++;
+      b->in_flight = true; b->obs_external = obs_external; b->device_async = true;
+      return BBX_OK;
+    }
+    rc = session_close(b, !ps, stream, false);   // something else: the session ends; what follows is ordered behind it
+    if (rc) return rc;
+  }
+  if (ps) {
+    b->ps_p = p; b->ps_p.ctl = nullptr;
+    b->ps_target = p.nsteps; b->ps_active = true; b->ps_sessions++;
+    rc = ps_write_ctl(b, false);
+    if (rc) return rc;
+    b->last = p; b->last.ctl = nullptr; b->last.policy = nullptr;
+    b->policy_rollout = false; b->last_stream = b->ps_stream; b->in_flight = true; b->obs_external = obs_external; b->device_async = true;
+    return session_kernel(b, true, stream, true);
+  }
+  b->last = p; b->last.ctl = nullptr;
   b->policy_rollout = p.policy && p.policy->rollout;
   b->last.policy = nullptr;                 // (a host pointer of the caller's frame: never kept)
   b->last_stream = stream;
@@ -799,6 +919,7 @@ void bbx_destroy(bbx_batch* b) { delete b; }
 int bbx_copy(const bbx_batch* s, bbx_batch** out) {
   if (!s || !out) return fail(BBX_E_ARG, "null argument");
   HIPCHK(hipSetDevice(s->device));
+  if (s->ps_active) { int rc_ = session_close(const_cast<bbx_batch*>(s), false, nullptr, false); if (rc_) return rc_; }
   HIPCHK(hipDeviceSynchronize());
   auto b = std::make_unique<bbx_batch>();
   b->B = s->B; b->device = s->device; b->k = s->k; b->nvars = s->nvars; b->W = s->W;
@@ -1192,6 +1313,42 @@ int bbx_sync(bbx_batch* b) {
   return finish(b, b->last_stream);
 }
 
+int bbx_persistent(bbx_batch* b, int enable) {
+  if (!b) return fail(BBX_E_ARG, "null argument");
+  HIPCHK(hipSetDevice(b->device));
+  if (b->in_flight) { int rc = finish(b, b->last_stream); if (rc) return rc; }
+  if (enable && !b->d_ctl) {
+    HIPCHK(hipMalloc((void**)&b->d_ctl, 65536));          // (word 0: control, word 8: statistics; the rest: scripts/patches)
+    HIPCHK(hipMemset(b->d_ctl, 0, 65536));
+    HIPCHK(hipStreamCreateWithFlags(&b->ps_stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&b->ps_ctl_stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&b->ps_ev, hipEventDisableTiming));
+    HIPCHK(hipDeviceSynchronize());
+  }
+  b->ps_enabled = enable != 0;
+  return BBX_OK;
+}
+
+int bbx_session_stats(bbx_batch* b, int64_t* out3) {   // out: 4 values
+  if (!b || !out3) return fail(BBX_E_ARG, "null argument");
+  HIPCHK(hipSetDevice(b->device));
+  out3[0] = b->ps_sessions; out3[1] = b->ps_joined; out3[2] = 0; out3[3] = b->ps_kernels;
+  if (b->d_ctl) {
+    if (b->in_flight) { int rc = finish(b, b->last_stream); if (rc) return rc; }
+    unsigned long long v = 0;
+    HIPCHK(hipMemcpy(&v, b->d_ctl + 8, sizeof v, hipMemcpyDeviceToHost));
+    out3[2] = (int64_t)v;
+  }
+  return BBX_OK;
+}
+
+int bbx_join(bbx_batch* b, void* stream) {
+  if (!b) return fail(BBX_E_ARG, "null argument");
+  HIPCHK(hipSetDevice(b->device));
+  if (!b->ps_active) return BBX_OK;
+  return session_close(b, true, (hipStream_t)stream, false);
+}
+
 int bbx_accounting(bbx_batch* b, int enable) {
   if (!b) return fail(BBX_E_ARG, "null argument");
   b->accounting = enable != 0;
@@ -1394,6 +1551,7 @@ int bbx_stats(bbx_batch* b, int64_t* out8) {
   int64_t* out6 = out8;
   if (!b || !out6) return fail(BBX_E_ARG, "null argument");
   HIPCHK(hipSetDevice(b->device));
+  if (b->ps_active) { int rc_ = session_close(b, false, nullptr, false); if (rc_) return rc_; }
   HIPCHK(hipDeviceSynchronize());
   int rc = read_headers(b);
   if (rc) return rc;
@@ -1415,6 +1573,7 @@ int bbx_capacities(bbx_batch* b, int32_t* out5) {
 int bbx_env_status(bbx_batch* b, int32_t* status) {
   if (!b || !status) return fail(BBX_E_ARG, "null argument");
   HIPCHK(hipSetDevice(b->device));
+  if (b->ps_active) { int rc_ = session_close(b, false, nullptr, false); if (rc_) return rc_; }
   HIPCHK(hipDeviceSynchronize());
   int rc = read_headers(b);
   if (rc) return rc;
@@ -1425,6 +1584,7 @@ int bbx_env_status(bbx_batch* b, int32_t* status) {
 int bbx_state_sizes(bbx_batch* b, int idx, int32_t* basis_size, int32_t* npairs, int32_t* nterms_total) {
   if (!b || idx < 0 || idx >= b->B) return fail(BBX_E_ARG, "bad environment index");
   HIPCHK(hipSetDevice(b->device));
+  if (b->ps_active) { int rc_ = session_close(b, false, nullptr, false); if (rc_) return rc_; }
   HIPCHK(hipDeviceSynchronize());
   BbxHdr h;
   HIPCHK(hipMemcpy(&h, b->d_recs + (size_t)idx * b->L.rec_bytes, sizeof h, hipMemcpyDeviceToHost));
@@ -1437,6 +1597,7 @@ int bbx_state_sizes(bbx_batch* b, int idx, int32_t* basis_size, int32_t* npairs,
 int bbx_state_get(bbx_batch* b, int idx, int32_t* nterms, int32_t* coefs, int32_t* exps, int32_t* pairs, int32_t* order) {
   if (!b || idx < 0 || idx >= b->B) return fail(BBX_E_ARG, "bad environment index");
   HIPCHK(hipSetDevice(b->device));
+  if (b->ps_active) { int rc_ = session_close(b, false, nullptr, false); if (rc_) return rc_; }
   HIPCHK(hipDeviceSynchronize());
   const char* rec = b->d_recs + (size_t)idx * b->L.rec_bytes;
   BbxHdr h;

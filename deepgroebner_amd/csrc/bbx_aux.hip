@@ -139,6 +139,15 @@ extern "C" int bbx_launch_relayout(const char* src_recs, char* dst_recs, const B
   return (int)hipGetLastError();
 }
 
+// persistent sessions: the host's hand on the control word (one relaxed agent-scope atomic store: what the waves' polls observe)
+__global__ void bbx_ctl_kernel(unsigned long long* ctl, unsigned long long value) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) __hip_atomic_store(ctl, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+extern "C" int bbx_launch_ctl(unsigned long long* ctl, unsigned long long value, hipStream_t stream) {
+  hipLaunchKernelGGL(bbx_ctl_kernel, dim3(1), dim3(64), 0, stream, ctl, value);
+  return (int)hipGetLastError();
+}
+
 // compact copy of every header so the host reads them with one contiguous transfer
 __global__ void bbx_gather_hdr_kernel(const char* recs, uint32_t rec_bytes, int B, BbxHdr* out) {
   int env = blockIdx.x * blockDim.x + threadIdx.x;

@@ -310,11 +310,25 @@ __device__ __forceinline__ void binom_body(const BbxParams& p, char* smem, const
   uint32_t gen_state = ghdr->gen_rng;
   int budget = uni(ghdr->budget), rollout_pos = uni(ghdr->rollout_pos);
   int done_last = uni(ghdr->done_last);
-  if (status == BBX_ST_STARVED || status == BBX_ST_SPILL) status = BBX_ST_OK;
+  // behind a kernel of a persistent session this class only serves what that kernel handed over (an environment whose
+  // slice was over waits for the session's next kernel)
+  if (p.sess_target && status != BBX_ST_SPILL) return;
+  const bool was_transient = status == BBX_ST_STARVED || status == BBX_ST_SPILL || status == BBX_ST_TIMESLICE;
+  if (was_transient) status = BBX_ST_OK;
   double vret = ghdr->vret, vdisc = ghdr->vdisc;
   int obs_trunc = uni(ghdr->obs_trunc);
   if (p.set_budget) { budget = bbx_st_capacity(status) ? budget + p.nsteps : p.nsteps; rollout_pos = 0; done_last = 0; vret = 0.0; vdisc = 1.0; obs_trunc = 0; }   // (bbx_common.h: bbx_st_capacity)
-  if (p.pass == 1 && !(status == BBX_ST_OK && (need_reset || (budget > 0 && nP > 0)))) return;
+  if (p.sess_target) budget = p.sess_target - uni(ghdr->sess_done);   // closing launch of a persistent session: what is still owed
+  if (p.pass == 1 && !(status == BBX_ST_OK && (need_reset || (budget > 0 && nP > 0)))) {
+    // nothing to do here.  If the kernel in front could not hold the environment (it is too large for the register/LDS
+    // class) although there was nothing to take either, its hand-over mark must not outlive the launch: the host would
+    // keep resuming an environment that has no step left
+    if (was_transient && status == BBX_ST_OK && lane == 0) {
+      ghdr->status = BBX_ST_OK;
+      if (p.lite) p.lite[4 * (size_t)env] &= ~0xffff;
+    }
+    return;
+  }
 
   BEnv<W> ge = benv_view<W>(grec, p.L);
   BEnv<W> e = STAGED ? benv_view<W>(smem + (size_t)wave_in_block * L.rec_bytes, L) : ge;
@@ -552,6 +566,10 @@ __device__ __forceinline__ void binom_body(const BbxParams& p, char* smem, const
     if (done) {
       episodes++;
       if (p.auto_reset) need_reset = 1;
+      // behind a kernel of a persistent session: the episode that outgrew the register/LDS class is over — the next one
+      // starts small, so the environment goes back to the session's next kernel with what it still owes
+      // (only where the host looks after it: slice_ticks != 0)
+      if (p.sess_target && p.slice_ticks && p.auto_reset && budget > 0) { status = BBX_ST_TIMESLICE; break; }
     }
   }
 
@@ -572,6 +590,7 @@ __device__ __forceinline__ void binom_body(const BbxParams& p, char* smem, const
     h->total_additions = total_adds; h->episodes = episodes; h->zero_reductions = zero_red; h->steps_done = steps_done;
     h->budget = budget; h->rollout_pos = rollout_pos; h->done_last = done_last; h->alg_bytes = alg_bytes;
     h->vret = vret; h->vdisc = vdisc; h->obs_trunc = obs_trunc;
+    if (p.sess_target) h->sess_done = p.sess_target - budget;
     if (p.lite) *(int4*)(p.lite + 4 * (size_t)env) = make_int4(status | (obs_trunc ? BBX_LITE_OBS_TRUNC : 0), q_head, budget, nP);
     if (p.value_mode && p.values) p.values[env] = vret;
     if (!handoff) {

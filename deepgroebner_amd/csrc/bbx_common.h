@@ -45,6 +45,8 @@ enum {
   BBX_ST_GEN_FAIL = 10,     // the ideal generator failed (no two distinct monomials after 1000 trials: the reference throws)
   BBX_ST_GEN_ZERO = 11,     // a random polynomial cancelled to zero (undefined in the reference)
   BBX_ST_POLY_LIMIT = 12,   // a basis element would have more than 65535 terms (plen[] is 16 bits): a hard limit
+  BBX_ST_TIMESLICE = 14,    // transient: a kernel of a persistent session ended its time slice with steps still owed (a kernel
+                            // that runs longer than ~100 ms is clocked down to half speed; sessions run in slices of 40 ms)
   BBX_ST_SPILL = 8,         // transient: the state outgrew the LDS-resident class; the HBM-resident pass of the
                             // same launch sequence continues this environment
 };
@@ -80,7 +82,8 @@ struct BbxHdr {             // 128 bytes
                             // on the device (BbxParams.gen != null); the host-side generators then stay unused
   int32_t obs_trunc;        // != 0: during the current rollout an observation had more rows than the caller's block holds
                             // (rows beyond obs_rows were not written); reported by bbx_sync as BBX_E_CAPACITY
-  int32_t reserved[4];
+  int32_t sess_done;        // persistent sessions (bbx_persistent): steps of the session's total this environment has taken
+  int32_t reserved[3];
 };
 
 struct BbxLayout {
@@ -167,6 +170,14 @@ struct BbxParams {
                             // number in bits 17.., written behind a system-scope fence after every other output
   BbxTraceRec* trace;       // [B, trace_stride] or null
   int32_t trace_stride;
+  // persistent sessions (bbx_persistent; register/LDS-resident class): asynchronous rollouts queued behind each other do not
+  // become one kernel each — the first starts a kernel whose waves keep their environments, and every further call only
+  // raises the step total in a device-visible control word the waves look at when they have taken all steps issued so far
+  const unsigned long long* ctl;   // control word {bits 0..31: steps issued since the session began, bit 32: stop} or null
+  unsigned long long* ctl_stats;   // statistics: steps the closing launches had to take (null: not counted)
+  int32_t sess_target;      // != 0: every environment owes sess_target - BbxHdr.sess_done steps (later slices of a session, and
+                            // the launch of the HBM-resident class behind them)
+  uint32_t slice_ticks;     // persistent kernels: leave after this many ticks of the 100 MHz clock (0: no limit)
   int32_t wide_hc, wide_fc, wide_rc, wide_sc;   // wide class: LDS capacities (terms) of the polynomial being reduced, the
                                        // reducer-tail window, the reducer table and the accumulator; wide_hc == 0: chosen by the launcher
 };

@@ -42,6 +42,8 @@ struct BbxFastParams {
   const uint32_t* gen;                                // device-side ideal generator table or null (ideals come from the queue)
   int32_t sort_input;                                 // device-drawn ideals enter in ascending lead-monomial order
   unsigned long long* prof;                           // diagnostic build only: [B][8] cycle sums per phase
+  const unsigned long long* ctl; int32_t sess_target; uint32_t slice_ticks;   // persistent sessions: see BbxParams
+  unsigned long long* ctl_stats;                      // statistics word: steps taken by closing launches
 };
 
 __device__ __forceinline__ uint32_t f_readlane(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
@@ -122,7 +124,14 @@ struct FastState {                 // reducer-order arrays, lane l <-> reducers 
 // observation, evaluates the PMLP policy (POL unit blocks of 32, 3 variables and k = 2: 12 columns) on the rows — taken
 // straight from the pair list and the monomial arrays in LDS, exactly the values the observation holds — and samples
 // its action; per-step outputs go to [nsteps][B] arrays (BbxPolicy).  Waves never wait for each other between steps.
-template <bool TRACE, bool ACCT, bool PROF = false, bool HL = false, int POL = 0>
+// PERSIST: a kernel of a persistent session (bbx_persistent): the session's first kernel starts with the p.nsteps steps
+// issued so far (set_budget), later ones with what the environment still owes of the total (sess_target).  A wave that has
+// taken every step issued reads the control word (one relaxed agent-scope atomic load: coherent by the memory model, no
+// fences — the environment never changes hands, so nothing else has to become visible to anybody before the kernel ends)
+// and carries on if the host has issued more meanwhile.  It leaves when told to stop, after 20 ms without news, or when
+// the kernel's time slice is over (steps still owed then: BBX_ST_TIMESLICE) — exits every wave reaches (s_memrealtime
+// counts at 100 MHz whatever the shader clock does).  What is owed when it leaves is taken by the session's next kernel.
+template <bool TRACE, bool ACCT, bool PROF = false, bool HL = false, int POL = 0, bool PERSIST = false>
 __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem, int ext_action = -1) {
   unsigned long long prof_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long prof_last = PROF ? __builtin_amdgcn_s_memtime() : 0;
@@ -151,8 +160,10 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem, in
   uint32_t gen_state = ghdr->gen_rng;                  // (a vector register: only the reset touches it)
   const uint32_t agent_seed = (uint32_t)uni((int)ghdr->agent_seed);
   int budget = uni(ghdr->budget), rollout_pos = uni(ghdr->rollout_pos), done_last = uni(ghdr->done_last);
-  if (status == BBX_ST_STARVED || status == BBX_ST_SPILL) status = BBX_ST_OK;
+  if (status == BBX_ST_STARVED || status == BBX_ST_SPILL || status == BBX_ST_TIMESLICE) status = BBX_ST_OK;
   if (p.set_budget) { budget = bbx_st_capacity(status) ? budget + p.nsteps : p.nsteps; rollout_pos = 0; done_last = 0; }   // (bbx_common.h: bbx_st_capacity)
+  if (p.sess_target) budget = p.sess_target - uni(ghdr->sess_done);   // later kernels of a persistent session: what is still owed
+  const uint32_t t_begin = PERSIST ? (uint32_t)__builtin_amdgcn_s_memrealtime() : 0u;
   if (p.pass == 1 && !(status == BBX_ST_OK && (need_reset || (budget > 0 && nP > 0)))) return;
 
   // HBM record arrays (binomial layout: every array 16-B aligned, capacities hbmG / maxP); the addresses are only
@@ -494,7 +505,35 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem, in
       need_reset = 0;
     }
     FSTAMP(0);                                             // 0: loop top / reset
-    if (budget <= 0 || nP == 0) break;
+    if (budget <= 0) {
+      if constexpr (PERSIST) {
+        // every step issued so far is taken: have more been issued meanwhile?  (Nothing about the session is kept live
+        // across the step loop: the steps taken are the agent's step counter minus what the record's header — untouched
+        // until this wave leaves — says it was when the session began.)
+        const FColdParams cq = f_cold_params();
+        const unsigned long long* ctl = cq->ctl;
+        const BbxHdr* hh = (const BbxHdr*)(cq->recs + (size_t)env * cq->rec_bytes);
+        const int taken = (cq->set_budget ? 0 : uni(hh->sess_done)) + t_agent - uni(hh->t);   // of the session's total
+        const uint32_t t0 = (uint32_t)__builtin_amdgcn_s_memrealtime();
+        bool more = false;
+        for (;;) {
+          const unsigned long long w = __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const int tgt = uni((int)(uint32_t)w), stop = uni((int)(uint32_t)(w >> 32));
+          if (tgt > taken) { budget = tgt - taken; more = true; break; }
+          if (stop & 1) break;
+          const uint32_t now = (uint32_t)__builtin_amdgcn_s_memrealtime();
+          if (now - t0 > 2000000u) break;                                // 20 ms without news
+          if (cq->slice_ticks && now - t_begin > cq->slice_ticks) break; // the slice is over anyway
+          __builtin_amdgcn_s_sleep(32);
+        }
+        if (!more) break;
+      } else break;
+    }
+    if (nP == 0) break;
+    if constexpr (PERSIST) {                               // the time slice (see BBX_ST_TIMESLICE): steps are still owed
+      const uint32_t lim = f_cold_params()->slice_ticks;
+      if (lim && (uint32_t)__builtin_amdgcn_s_memrealtime() - t_begin > lim) { status = BBX_ST_TIMESLICE; break; }
+    }
     if (nG + 1 > limG || nP - 1 + nG > limP) { status = BBX_ST_SPILL; break; }   // before anything is modified
 
     // ---- choose the pair -----------------------------------------------------------------------------------------
@@ -687,6 +726,24 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem, in
     last_nred = vzero + nred;
     adds += 1 + nred; t_agent++;
     if ((t_agent & 63) == 0) hv = bbx_agent_hash32(agent_seed, (uint32_t)(t_agent + lane));
+#ifndef BBX_PRIO_SHIFT
+#define BBX_PRIO_SHIFT 6
+#endif
+    if ((t_agent & ((1 << BBX_PRIO_SHIFT) - 1)) == 0) {
+#ifndef BBX_NO_PRIO_ROTATION
+      // The instruction arbiter serves the OLDEST wave first, and this kernel is bound by the one scalar unit its waves share:
+      // left alone, the waves of the workgroups dispatched first run at 2.1 us per step and those dispatched last at 3.8,
+      // so every launch ends with a phase in which only the starved quarter is left, too few waves to fill the unit.
+      // Rotating the user priority (which ranks above age) every 2^BBX_PRIO_SHIFT steps, offset by the workgroup's quarter of
+      // the grid, gives every wave of a SIMD the same share over time: all finish together.  (s_setprio takes an immediate.)
+      switch (((t_agent >> BBX_PRIO_SHIFT) + (env >> 10)) & 3) {
+        case 0: __builtin_amdgcn_s_setprio(0); break;
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        default: __builtin_amdgcn_s_setprio(3); break;
+      }
+#endif
+    }
     const bool done = nP == 0;
 
     if (obs_step) { if (obs32) write_obs32(); else write_obs(true, false); obs_trunc |= nP > p.obs_rows ? 1 : 0; }
@@ -746,7 +803,13 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem, in
   if (lane == 0) {
     BbxHdr* h = (BbxHdr*)(cz->recs + (size_t)env * cz->rec_bytes);
     // steps done = the rollout budget this launch started with minus what is left (the header still holds the old one)
-    const int steps_done = (cz->set_budget ? (bbx_st_capacity(status) ? h->budget + cz->nsteps : cz->nsteps) : h->budget) - budget;
+    const int budget0 = cz->sess_target ? cz->sess_target - h->sess_done
+                                        : (cz->set_budget ? (bbx_st_capacity(status) ? h->budget + cz->nsteps : cz->nsteps) : h->budget);
+    const int steps_done = PERSIST ? t_agent - h->t : budget0 - budget;
+    if (PERSIST) {
+      h->sess_done = (cz->set_budget ? 0 : h->sess_done) + steps_done;
+      if (!cz->set_budget && steps_done > 0 && cz->ctl_stats) atomicAdd((unsigned long long*)cz->ctl_stats, (unsigned long long)steps_done);   // statistics: steps taken by later kernels of sessions
+    } else if (cz->sess_target) h->sess_done = cz->sess_target - budget;
     rollout_pos = (cz->set_budget ? 0 : h->rollout_pos) + steps_done;
     h->nG = nG; h->nP = nP; h->arena_used = 0; h->status = status; h->need_reset = need_reset;
     h->q_head = q_head; h->t = t_agent; h->total_steps += steps_done; h->total_additions += adds;
@@ -785,6 +848,15 @@ __global__ __launch_bounds__(256) void bbx_fast_kernel(BbxFastParams p) {
 __global__ __launch_bounds__(256) void bbx_fast_headline_kernel(BbxFastParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   fast_body<false, false, false, true>(p, smem);
+}
+// the kernels of persistent sessions (fast_body PERSIST): the headline shape and the general lean one
+__global__ __launch_bounds__(256) void bbx_fast_headline_persistent_kernel(BbxFastParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  fast_body<false, false, false, true, 0, true>(p, smem);
+}
+__global__ __launch_bounds__(256) void bbx_fast_persistent_kernel(BbxFastParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  fast_body<false, false, false, false, 0, true>(p, smem);
 }
 // Policy + step in one launch: every wave first evaluates the PMLP policy on its environment's rows of the
 // observation block the previous launch left (pmlp_act_wave: matrix-core hidden layer, log-softmax, inverse-CDF draw),

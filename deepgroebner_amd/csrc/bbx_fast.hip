@@ -18,6 +18,7 @@ extern "C" int bbx_launch_fast(const BbxParams* p, int blocks, int threads, int 
   f.lite = p->lite; f.done_seq = p->done_seq;
   f.gen = p->gen;
   f.sort_input = p->sort_input;
+  f.ctl = p->ctl; f.sess_target = p->sess_target; f.ctl_stats = p->ctl_stats; f.slice_ticks = p->slice_ticks;
   const size_t lds = (size_t)envs_per_block * FLDS_BYTES;
 #ifdef BBX_PROF_BUILD
   static unsigned long long* d_prof = nullptr;
@@ -52,6 +53,12 @@ extern "C" int bbx_launch_fast(const BbxParams* p, int blocks, int threads, int 
                    else hipLaunchKernelGGL((bbx_fast_policy_kernel<4, 3>), dim3(blocks), dim3(threads), ll, stream, q); }
     else { if (nb == 2) hipLaunchKernelGGL((bbx_fast_policy_kernel<2, 6>), dim3(blocks), dim3(threads), ll, stream, q);
            else hipLaunchKernelGGL((bbx_fast_policy_kernel<4, 6>), dim3(blocks), dim3(threads), ll, stream, q); }
+    return 0;
+  }
+  if (p->ctl) {                                            // the kernel of a persistent session (bbx_api.cpp admits lean, untraced launches only)
+    if (f.agent == BBX_AGENT_HASH && f.nvars == 3 && f.k == 2 && f.obs && f.obs_every_step && !f.obs_fill && f.auto_reset)
+      hipLaunchKernelGGL(bbx_fast_headline_persistent_kernel, dim3(blocks), dim3(threads), lds, stream, f);
+    else hipLaunchKernelGGL(bbx_fast_persistent_kernel, dim3(blocks), dim3(threads), lds, stream, f);
     return 0;
   }
   if (p->trace) hipLaunchKernelGGL((bbx_fast_kernel<true, true>), dim3(blocks), dim3(threads), lds, stream, f);

@@ -27,7 +27,7 @@ __device__ __forceinline__ void step_body(const BbxParams& p, char* smem, unsign
   uint32_t gen_state = ghdr->gen_rng;
   int budget = uni(ghdr->budget), rollout_pos = uni(ghdr->rollout_pos);
   int done_last = uni(ghdr->done_last);
-  if (status == BBX_ST_STARVED || status == BBX_ST_SPILL) status = BBX_ST_OK;   // transient states: try again
+  if (status == BBX_ST_STARVED || status == BBX_ST_SPILL || status == BBX_ST_TIMESLICE) status = BBX_ST_OK;   // transient states: try again
   double vret = ghdr->vret, vdisc = ghdr->vdisc;
   int obs_trunc = uni(ghdr->obs_trunc);
   // (an environment waiting for the host to enlarge its record keeps the steps it still owes: bbx_common.h)

@@ -484,7 +484,7 @@ __device__ __forceinline__ void wide_body(char* smem) {
     nG = uni(h->nG); nP = uni(h->nP); arena_used = uni(h->arena_used);
     status = uni(h->status); need_reset = uni(h->need_reset); budget = uni(h->budget); t_agent = uni(h->t);
     agent_seed = (uint32_t)uni((int)h->agent_seed);
-    if (status == BBX_ST_STARVED || status == BBX_ST_SPILL) status = BBX_ST_OK;
+    if (status == BBX_ST_STARVED || status == BBX_ST_SPILL || status == BBX_ST_TIMESLICE) status = BBX_ST_OK;
     if (p.set_budget) budget = bbx_st_capacity(status) ? budget + p.nsteps : p.nsteps;   // (bbx_common.h: bbx_st_capacity)
     if (p.pass == 1 && !(status == BBX_ST_OK && (need_reset || (budget > 0 && nP > 0)))) return;   // (whole workgroup)
     if (x.tid == 0) {

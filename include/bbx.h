@@ -210,6 +210,24 @@ int bbx_rollout_device(bbx_batch* b, int agent, int nsteps, int auto_reset, doub
  * wait for ideals; returns BBX_E_CAPACITY etc. if any environment failed */
 int bbx_sync(bbx_batch* b);
 
+/* ---- persistent sessions ---------------------------------------------------------------------------------------------
+ * A launch of K steps ends with its slowest environment (an episode reset costs as much as several steps), so K-step
+ * rollouts queued one kernel each leave most of the device idle at the end of every launch: 115 us per 20-step launch for
+ * 68 us of work.  With bbx_persistent(b, 1), the first asynchronous bbx_rollout_device call on the register/LDS-resident
+ * class (3-variable binomial distributions drawn on the device, Gebauer-Moeller, sorted reducers; built-in agent,
+ * auto-reset, lean, untraced, batch <= 4096) starts ONE kernel whose waves keep their environments, and every further
+ * call with the same arguments only raises the step total in a device-visible control word; a wave that has taken every
+ * step issued so far looks at the word and carries on — environments never wait for each other between calls.  The
+ * session ends (its kernel is told to stop after the steps issued, a closing launch takes whatever an environment still
+ * owes) with bbx_sync, bbx_join or any other call on the handle; results are those of the same calls as separate
+ * launches, bit for bit.  Outputs (rewards / dones / rows / observation block: those of the LAST step) are ready for the
+ * caller's stream after bbx_join(b, stream) — device-side: `stream` waits, the host does not — or after bbx_sync.
+ * A wave that sees no news for 20 ms leaves by itself (a session never outlives an idle host by more than that). */
+int bbx_persistent(bbx_batch* b, int enable);
+int bbx_join(bbx_batch* b, void* stream);
+/* out4 = {sessions begun, calls that joined a running session, env-steps taken by later kernels of sessions, kernels} */
+int bbx_session_stats(bbx_batch* b, int64_t* out4);
+
 /* Algorithmic-byte accounting (stats column 6, the roofline numerator) is on by default; the hand-tuned kernel
  * has a leaner variant without it, selected by bbx_accounting(b, 0).  The count is a property of the workload:
  * bench.py times the lean variant and takes the bytes from an accounting run over a bbx_copy of the same batch. */

@@ -39,5 +39,6 @@ def test_bench_line_fields_and_consistency():
 
 @pytest.mark.gpu
 def test_bench_spawns_its_ranks_and_prints_one_line():
-    d = _run(["--gpus", "2", "--steps", "8", "--warmup", "2", "--repeats", "4", "--no-cpu-baseline"])   # two ranks on the one device
+    d = _run(["--gpus", "2", "--steps", "8", "--warmup", "2", "--repeats", "4", "--no-cpu-baseline", "--allow-oversubscribe"])   # two ranks on the one device
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 2 * 4096 and d["value"] > 0
+    assert d["oversubscribed"] is True and len(d["per_rank_value"]) == 2 and all(v > 0 for v in d["per_rank_value"])

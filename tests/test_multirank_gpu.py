@@ -52,8 +52,9 @@ def _bench(*extra):
 def test_bench_two_ranks_via_its_own_launcher():
     """`python bench.py --gpus 2` with no launcher environment starts the ranks itself; the two ranks' environments are
     the first 2 x B global ids, so their additions over the timed region equal a 1-rank run of batch 2 x B."""
-    two = _bench("--gpus", "2", "--batch", "128")
+    two = _bench("--gpus", "2", "--batch", "128", "--allow-oversubscribe")
     one = _bench("--gpus", "1", "--batch", "256")
+    assert two["oversubscribed"] is True and one["oversubscribed"] is False and len(two["per_rank_value"]) == 2
     assert two["n_gpus"] == 2 and one["n_gpus"] == 1
     assert two["config"]["global_batch"] == one["config"]["global_batch"] == 256
     assert two["repeats"] == one["repeats"] == 3 and two["steps"] == 8 and two["warmup"] == 2
@@ -61,3 +62,17 @@ def test_bench_two_ranks_via_its_own_launcher():
     assert two["roofline"]["alg_bytes_per_env_step"] == one["roofline"]["alg_bytes_per_env_step"]
     for r in (one, two):
         assert r["value"] > 0 and r["scaling"] == "weak" and r["roofline"]["launches"] == 3
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """A scaling line can only come from one rank per distinct GPU: without --allow-oversubscribe a launch with more ranks
+    than visible devices stops before it measures anything."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a box with a single GPU")
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--repeats", "2",
+                        "--batch", "64", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert p.returncode != 0 and "refusing to oversubscribe" in p.stderr
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]

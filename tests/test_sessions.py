@@ -1,0 +1,132 @@
+"""Persistent sessions (bbx_persistent): asynchronous rollouts queued behind each other feed ONE running kernel through a
+device-visible step counter.  Results must be those of the same calls as separate launches, i.e. the oracle's, bit for bit."""
+import time
+
+import numpy as np
+import pytest
+
+from oracle import ffi
+from oracle.trace import fnv64
+from tests.test_gpu_parity import _state_words
+
+pytestmark = pytest.mark.gpu
+DIST = "3-20-10-weighted"
+
+
+def _env(B, caps=None, k=2):
+    from deepgroebner_amd import VecLeadMonomialsEnv
+    env = VecLeadMonomialsEnv(DIST, batch=B, k=k, caps=caps)
+    env.seed(np.arange(B) + 1000); env.seed_agent(np.arange(B)); env.reset(); env.accounting(False)
+    env.persistent(True)
+    return env
+
+
+def _check(env, want, rows=None, obs=None, sample_every=37):
+    st = env.stats()
+    assert (st[:, 4] == 0).all(), st[:, 4]
+    for key, col in (("steps", 0), ("additions", 1), ("episodes", 2), ("zero_reductions", 3), ("nG", 7)):
+        w = np.array([r[key] for r in want])
+        assert np.array_equal(st[:, col], w), (key, int(np.flatnonzero(st[:, col] != w)[0]), st[:, col][st[:, col] != w][:4], w[st[:, col] != w][:4])
+    B = len(want)
+    if rows is not None:
+        assert np.array_equal(rows.cpu().numpy(), np.array([r["nP"] for r in want]))
+    for e in sorted(set(range(0, B, sample_every)) | {B - 1}):
+        basis, pairs, order = env.state(e)
+        assert fnv64(_state_words(basis, pairs, order)) == want[e]["state_hash"], e
+
+
+@pytest.mark.parametrize("B,K,calls,caps", [
+    (4096, 20, 30, None),                                  # the bench's shape: 4096 environments, 20 steps per call
+    (512, 1, 300, None), (512, 7, 60, None),
+    (300, 13, 40, {"lds_max_basis": 16}),                  # a register/LDS class so small that environments keep leaving it
+    (64, 50, 12, {"lds_max_basis": 32, "max_basis": 12, "max_pairs": 16}),   # ... and the HBM records grow on top of that
+])
+def test_session_equals_separate_launches(B, K, calls, caps):
+    import torch
+    bo = ffi.load("bo")
+    want = bo.run_random_many(DIST, 2, range(1000, 1000 + B), range(B), K * calls, True, 0)
+    env = _env(B, caps)
+    R = 256
+    obs = torch.zeros((B, R, env.cols), dtype=torch.int32, device="cuda")
+    rew = torch.zeros(B, dtype=torch.float64, device="cuda"); done = torch.zeros(B, dtype=torch.uint8, device="cuda")
+    rows = torch.zeros(B, dtype=torch.int32, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    for _ in range(calls):
+        env.rollout_device("random", K, True, s, rew, done, rows, obs, R, False, True)
+    env.sync()
+    ss = env.session_stats()
+    assert ss["sessions"] >= 1 and ss["sessions"] + ss["joined"] == calls, ss
+    _check(env, want, rows)
+    for e in (0, B // 2, B - 1):                           # the block holds the observation of the last state
+        o = bo.env(DIST); o.seed(1000 + e); o.reset()
+        for t in range(K * calls):
+            o.step(ffi.agent_action(e, t, o.nP))
+            if o.nP == 0:
+                o.reset()
+        assert np.array_equal(obs[e, :o.nP].cpu().numpy(), o.obs(2)), e
+
+
+def test_session_survives_an_idle_host_and_other_calls():
+    """Waves leave after 20 ms without news and a kernel's time slice is 10 ms: steps issued after that are taken by the
+    session's next kernel; stats() / state() / copy() in the middle end the session and the next rollout begins a new one."""
+    import torch
+    bo = ffi.load("bo")
+    B, K = 256, 16
+    env = _env(B)
+    rows = torch.zeros(B, dtype=torch.int32, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    total = 0
+    for rnd in range(3):
+        for i in range(10):
+            env.rollout_device("random", K, True, s, rows=rows)
+            total += K
+            if i in (3, 7):
+                time.sleep(0.06)                           # the kernel has left by now
+        want = bo.run_random_many(DIST, 2, range(1000, 1000 + B), range(B), total, True, 0)
+        if rnd == 0:
+            st = env.stats()                               # (ends the session without bbx_sync)
+            assert np.array_equal(st[:, 0], np.full(B, total))
+        elif rnd == 1:
+            twin = env.copy()
+            _check(twin, want)
+        _check(env, want, sample_every=17)
+    assert env.session_stats()["sessions"] == 3
+
+
+def test_session_join_orders_the_callers_stream():
+    """bbx_join: the caller's stream (also the null stream) waits on the device for the session; what it then reads is final."""
+    import torch
+    bo = ffi.load("bo")
+    B, K, calls = 512, 20, 25
+    want = bo.run_random_many(DIST, 2, range(1000, 1000 + B), range(B), K * calls, True, 0)
+    env = _env(B)
+    rows = torch.zeros(B, dtype=torch.int32, device="cuda")
+    rew = torch.zeros(B, dtype=torch.float64, device="cuda")
+    s = torch.cuda.current_stream()
+    for _ in range(calls):
+        env.rollout_device("random", K, True, s.cuda_stream, rewards=rew, rows=rows)
+    env.join(s.cuda_stream)
+    snapshot = rows.clone()                                # queued on the caller's stream behind the join
+    torch.cuda.synchronize()
+    assert np.array_equal(snapshot.cpu().numpy(), np.array([r["nP"] for r in want]))
+    env.sync()
+    _check(env, want, rows)
+
+
+def test_session_only_where_admitted():
+    """Other kernel classes, traced or accounting launches, host-side calls: plain launches, same results."""
+    import torch
+    from deepgroebner_amd import VecLeadMonomialsEnv
+    bo = ffi.load("bo")
+    B, K, calls = 33, 10, 6
+    for dist, acct in (("5-10-5-uniform", False), (DIST, True)):
+        want = bo.run_random_many(dist, 2, range(1000, 1000 + B), range(B), K * calls, True, 0)
+        env = VecLeadMonomialsEnv(dist, batch=B, k=2)
+        env.seed(np.arange(B) + 1000); env.seed_agent(np.arange(B)); env.reset(); env.accounting(acct)
+        env.persistent(True)
+        rows = torch.zeros(B, dtype=torch.int32, device="cuda")
+        for _ in range(calls):
+            env.rollout_device("random", K, True, torch.cuda.current_stream().cuda_stream, rows=rows)
+        env.sync()
+        assert env.session_stats()["sessions"] == 0
+        _check(env, want, rows, sample_every=5)
