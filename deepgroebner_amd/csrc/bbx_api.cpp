@@ -590,8 +590,8 @@ int finish(bbx_batch* b, hipStream_t stream) {
   if (err == BBX_OK && b->obs_external)
     for (int e = 0; e < b->B; e++)
       if (b->h_lite[(size_t)e * 4] & BBX_LITE_OBS_TRUNC)
-        return fail(BBX_E_CAPACITY, "environment %d: an observation had more rows than the caller's block holds (obs_rows = %d); "
-                                    "the extra rows were not written", e, b->last.obs_rows);
+        return fail(BBX_E_CAPACITY, "environment %d: an observation had more rows than the caller's block holds (obs_rows = %d) or, in a policy "
+                                    "rollout, than the policy kernels score (1024); the extra rows were not written / scored", e, b->last.obs_rows);
   return err;
 }
 
@@ -1233,6 +1233,7 @@ int bbx_pmlp_act(const int32_t* d_obs, const int32_t* d_rows, int batch, int obs
                  const float* d_u, int32_t* d_actions, float* d_logprobs, void* stream) {
   if (!d_obs || !d_rows || !d_prepared || !d_u || !d_actions || !d_logprobs) return fail(BBX_E_ARG, "null argument");
   if (batch < 1 || obs_rows < 1) return fail(BBX_E_ARG, "bad policy shape");
+  if (obs_rows > 1024) return fail(BBX_E_UNSUPPORTED, "the policy kernels score at most 1024 rows per environment (obs_rows = %d)", obs_rows);
   if (bbx_pmlp_prepared_floats(cols, hidden) < 0) return BBX_E_UNSUPPORTED;
   int lrc = bbx_launch_pmlp_act(d_obs, d_rows, batch, obs_rows, cols, d_prepared, hidden, d_u, d_actions, d_logprobs, (hipStream_t)stream);
   if (lrc) return fail(BBX_E_DEVICE, "policy launch failed: %s", hipGetErrorString((hipError_t)lrc));
@@ -1243,6 +1244,8 @@ int bbx_policy_step_device(bbx_batch* b, const float* d_prepared, int hidden, co
                            double* d_rewards, uint8_t* d_dones, int32_t* d_rows, int32_t* d_obs, int obs_rows, int obs_fill, void* stream) {
   if (!b || !d_prepared || !d_u || !d_actions || !d_logprobs || !d_rows || !d_obs) return fail(BBX_E_ARG, "null argument");
   if (obs_rows < 1) return fail(BBX_E_ARG, "obs_rows must be positive");
+  if (obs_rows > 1024) return fail(BBX_E_UNSUPPORTED, "the policy kernels score at most 1024 rows per environment (obs_rows = %d)", obs_rows);
+  HIPCHK(hipSetDevice(b->device));
   const int cols = 2 * b->nvars * b->k;
   if (bbx_pmlp_prepared_floats(cols, hidden) < 0) return BBX_E_UNSUPPORTED;
   // one launch for policy + step where the step kernel has the policy built in (the register/LDS-resident class, lean
@@ -1269,6 +1272,7 @@ int bbx_policy_rollout_device(bbx_batch* b, const float* d_prepared, int hidden,
                               long long obs_step_stride, void* stream) {
   if (!b || !d_prepared || !d_u || !d_actions || !d_logprobs) return fail(BBX_E_ARG, "null argument");
   if (nsteps < 1 || (d_obs && obs_rows < 1) || obs_step_stride < 0) return fail(BBX_E_ARG, "bad rollout arguments");
+  if (d_obs && obs_rows > 1024) return fail(BBX_E_UNSUPPORTED, "the policy kernels score at most 1024 rows per environment (obs_rows = %d)", obs_rows);
   const int cols = 2 * b->nvars * b->k;
   if (bbx_pmlp_prepared_floats(cols, hidden) < 0) return BBX_E_UNSUPPORTED;
   // where the policy is built into the step kernels: binomial classes with 8- or 16-byte monomials, 33..128 hidden units,
@@ -1290,7 +1294,7 @@ int bbx_policy_rollout_device(bbx_batch* b, const float* d_prepared, int hidden,
   // the register/LDS-resident kernel has the policy for 3 variables and k = 2; every other admitted shape runs in the
   // HBM-resident binomial kernel from the start
   pol.rollout = (b->fast && b->staged && b->nvars == 3 && b->k == 2) ? 1 : 2;
-  return launch(b, p, (hipStream_t)stream, d_obs != nullptr, true);
+  return launch(b, p, (hipStream_t)stream, true, true);   // (rows the policy could not score — more than the block or the kernel holds — are an error)
 }
 
 int bbx_rollout_device(bbx_batch* b, int agent, int nsteps, int auto_reset, double* d_rewards, uint8_t* d_dones,

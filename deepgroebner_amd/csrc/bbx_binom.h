@@ -374,7 +374,8 @@ __device__ __forceinline__ void binom_body(const BbxParams& p, char* smem, const
       const float uu = pol->u[tb];
       if (p.obs) { bin_obs<W, false>(e, p, env, nP, true, false, nullptr, (size_t)pol_tt * (size_t)pol->obs_tstride); obs_trunc |= nP > p.obs_rows ? 1 : 0; }
       if (lane == 0 && pol->rows_t) pol->rows_t[tb] = nP;
-      int n = nP < PMLP_MAXROWS ? nP : PMLP_MAXROWS;
+      int n = nP < PMLP_MAXROWS ? nP : PMLP_MAXROWS;            // (rows beyond what the policy can score: reported, like rows
+      obs_trunc |= nP > PMLP_MAXROWS ? 1 : 0;                    // beyond the caller's block — bbx_sync returns BBX_E_CAPACITY)
       if (p.obs) n = n < p.obs_rows ? n : p.obs_rows;
       const float* wp = pol->wp;
       const int plr = lane & 31, plk = lane >> 5;

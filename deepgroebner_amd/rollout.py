@@ -69,7 +69,7 @@ class PMLPPolicy(torch.nn.Module):
             actions = torch.empty(B, dtype=torch.int32, device=obs.device)
         if logprobs is None:
             logprobs = torch.empty(B, dtype=torch.float32, device=obs.device)
-        if len(self.embedding) == 1 and self.fused_ok(cols, self.embedding[0].out_features):
+        if len(self.embedding) == 1 and self.fused_ok(cols, self.embedding[0].out_features) and R <= 1024:   # (the kernels score <= 1024 rows)
             w = self._fused_weights()
             s = (stream if stream is not None else torch.cuda.current_stream()).cuda_stream
             _ffi.check(_ffi.lib().bbx_pmlp_act(C.c_void_p(obs.data_ptr()), C.c_void_p(rows.data_ptr()), B, R, cols, w["prepared"], w["hidden"],
@@ -171,21 +171,44 @@ class DeviceTrajectoryBuffer:
         self.returns, self.advantages, self.complete = ret, adv, comp
         return ret, adv, comp
 
-    def get(self, normalize_advantages=True):
-        """(states or None, actions, logprobs, advantages, values-to-fit) of all complete-episode steps whose state had more
-        than one row (pg.py:184-196), advantages normalised by their mean and population std over the complete steps
-        (pg.py:176-178: before the single-row filter, like the reference)."""
+    def get(self, batch_size=None, normalize_advantages=True, sort=False, drop_remainder=False):
+        """Training data of all complete-episode steps whose state had more than one row (pg.py:162-240): (states or None,
+        actions, logprobs, advantages, values-to-fit), advantages normalised by their mean and population std over the
+        complete steps (pg.py:176-178: before the single-row filter, like the reference), steps ordered trajectory after
+        trajectory (environment-major).  batch_size=None: one tuple of whole tensors.  Otherwise the reference's
+        padded_batch: a list of such tuples of at most batch_size steps each, the state block of a batch cut to the most
+        rows any of its states has (-1 padding beyond a state's own rows, as stored); sort=True orders the steps by their
+        number of rows first (less padding); drop_remainder=True leaves a short last batch out."""
         if self.returns is None:
             self.finish()
         T = self.t
-        comp = self.complete[:T]
-        adv = self.advantages[:T][comp].to(torch.float32)
+        em = lambda x: x[:T].transpose(0, 1)                        # [B, T, ...]: trajectory after trajectory
+        comp = em(self.complete)
+        adv = em(self.advantages)[comp].to(torch.float32)
         if normalize_advantages and adv.numel():
             adv = (adv - adv.mean()) / adv.std(unbiased=False)
-        keep = self.rows[:T][comp] != 1
-        st = self.states[:T][comp][keep] if self.states is not None else None
-        return (st, self.actions[:T][comp][keep], self.logprobs[:T][comp][keep], adv[keep],
-                self.returns[:T][comp].to(torch.float32)[keep])
+        rows = em(self.rows)[comp]
+        keep = rows != 1
+        st = em(self.states)[comp][keep] if self.states is not None else None
+        out = [st, em(self.actions)[comp][keep], em(self.logprobs)[comp][keep], adv[keep], em(self.returns)[comp].to(torch.float32)[keep]]
+        rows = rows[keep]
+        if batch_size is None and not sort:
+            return tuple(out)
+        if sort:
+            order = torch.argsort(rows, stable=True)
+            out = [None if x is None else x[order] for x in out]
+            rows = rows[order]
+        if batch_size is None:
+            return tuple(out)
+        n = int(rows.numel())
+        batches = []
+        for i in range(0, n, batch_size):
+            j = min(i + batch_size, n)
+            if drop_remainder and j - i < batch_size:
+                break
+            mr = int(rows[i:j].max()) if self.states is not None else 0
+            batches.append(tuple(None if x is None else (x[i:j, :mr] if k == 0 else x[i:j]) for k, x in enumerate(out)))
+        return batches
 
 
 @torch.no_grad()
@@ -205,6 +228,12 @@ def run_rollout_fused(env, policy, nsteps, buffer=None, obs_rows=256, generator=
         act = torch.empty((chunk, B), dtype=torch.int32, device=dev); logp = torch.empty((chunk, B), dtype=torch.float32, device=dev)
     obs1 = None if keep_states else torch.empty((B, obs_rows, cols), dtype=torch.int32, device=dev)
     st0 = env.stats()
+    if buffer is not None:
+        # the kernel writes n x B elements behind raw pointers into the buffer's arrays: a short slice would be overrun
+        if buffer.t + nsteps > buffer.T:
+            raise IndexError("trajectory buffer holds %d steps, %d are stored already: no room for %d more" % (buffer.T, buffer.t, nsteps))
+        if keep_states and tuple(buffer.states.shape[2:]) != (obs_rows, cols):
+            raise ValueError("buffer.states has blocks of %s, the environment writes (%d, %d)" % (tuple(buffer.states.shape[2:]), obs_rows, cols))
     for t0 in range(0, nsteps, chunk):
         n = min(chunk, nsteps - t0)
         u = torch.rand((n, B), device=dev, generator=generator)
@@ -227,8 +256,10 @@ def run_rollout_fused(env, policy, nsteps, buffer=None, obs_rows=256, generator=
 
 
 @torch.no_grad()
-def run_rollout(env, policy, nsteps, buffer=None, obs_rows=128, generator=None, sync_every=64):
-    """nsteps vector steps of `env` (a VecLeadMonomialsEnv already reset) under `policy`, everything on the device:
+def run_rollout(env, policy, nsteps, buffer=None, obs_rows=256, generator=None, sync_every=64):
+    """nsteps vector steps of `env` (a VecLeadMonomialsEnv already reset) under `policy`, everything on the device
+    (obs_rows: rows of the observation block per environment — a pair set with more rows makes env.sync() raise
+    BBX_E_CAPACITY, it is never cut silently; 256 is what the register/LDS-resident class holds):
     observation block -> policy.act (log-softmax + inverse-CDF draw) -> bbx_step_device_autoreset -> next block.  The
     host only enqueues kernels; it waits (env.sync: errors, environments that outgrew a kernel class) every
     `sync_every` steps and at the end.  Returns (total reward per environment float64 [B] — for `additions` rewards —,

@@ -168,7 +168,10 @@ int bbx_step_device_autoreset(bbx_batch* b, const int32_t* d_actions, double* d_
  * ParallelDecidingLayer :414-460) evaluated on d_obs [batch, obs_rows, cols] over the d_rows[e] valid rows of each
  * environment (the -1 padding is masked out there, plays no part here), log-softmax over the rows and ONE action drawn
  * by inverse CDF from the uniform number d_u[e] in [0, 1) — the step of pg.py:451-503's run_episode that used to cross to
- * the host every step.  fp32, the hidden layer on the matrix cores (exact f32 MFMA); cols <= 64, hidden <= 256.
+ * the host every step.  fp32, the hidden layer on the matrix cores (exact f32 MFMA); cols <= 64, hidden <= 256, at most
+ * 1024 rows per environment (obs_rows > 1024: BBX_E_UNSUPPORTED; a policy rollout without an observation block whose pair
+ * set outgrows 1024 rows: BBX_E_CAPACITY from bbx_sync — never a silent cut).  exp / log of the softmax are the
+ * hardware's fast forms (__expf / __logf): log-probabilities agree with an IEEE evaluation to ~2e-4 (tests/test_rollout.py).
  * The weights are handed over PREPARED: bbx_pmlp_prepare copies d_w1 [cols][hidden] (the layout of
  * torch.nn.Linear(...).weight.t()), d_b1 [hidden], d_w2 [hidden], b2 into d_prepared (bbx_pmlp_prepared_floats(cols,
  * hidden) floats, 16-byte aligned) zero-padded to the kernels' tile sizes; call it again whenever the weights change.

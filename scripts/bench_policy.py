@@ -22,7 +22,7 @@ ap.add_argument("--batch", type=int, default=4096)
 ap.add_argument("--steps", type=int, default=2000)
 ap.add_argument("--k", type=int, default=2)
 ap.add_argument("--hidden", type=int, default=128)
-ap.add_argument("--obs-rows", type=int, default=128)
+ap.add_argument("--obs-rows", type=int, default=256)
 ap.add_argument("--store", action="store_true", help="also record the trajectory (actions, rewards, log-probabilities, dones) on the device")
 ap.add_argument("--per-step", action="store_true", help="one library call per vector step (bbx_policy_step_device) instead of the policy rollout "
                                                        "kernel (bbx_policy_rollout_device: --chunk steps per launch, policy inside the step loop)")

@@ -4,7 +4,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from deepgroebner_amd import VecLeadMonomialsEnv
-B, R = 4096, 128
+B, R = 4096, 256
 env = VecLeadMonomialsEnv("3-20-10-weighted", batch=B, k=2)
 env.seed(np.arange(B) + 1000); env.seed_agent(np.arange(B)); env.reset(); env.accounting(False)
 obs = torch.empty((B, R, env.cols), dtype=torch.int32, device="cuda")

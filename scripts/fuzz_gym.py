@@ -74,7 +74,7 @@ for it in range(rounds):
     except Exception as ex:
         msg = str(ex)
         if "error -3" in msg:
-            print("capacity  %s: %s" % (tag, msg[:90])); continue
+            print("CAPACITY %s: %s" % (tag, msg[:160])); sys.exit(1)   # (records grow on demand: a failure)
         if "error -4" in msg or "error -5" in msg or "bad distribution" in msg:
             print("generator %s: %s" % (dist, msg[:90])); continue
         print("ERROR %s: %s" % (tag, msg[:300])); sys.exit(1)

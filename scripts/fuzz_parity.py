@@ -1,7 +1,8 @@
 """Randomised parity sweep (test infrastructure, GPU box): random distribution strings, batch sizes, horizons, k and kernel
 capacities; every environment's counters and final state against the CPU restatement (oracle/, counter-hash agent).
     python scripts/fuzz_parity.py [ROUNDS] [SEED]          (FUZZ_LARGE=1: batches of 1024 / 4096 environments; FUZZ_LONG=1: 10x horizons)
-Prints one line per case; exits non-zero at the first mismatch."""
+Prints one line per case; exits non-zero at the first mismatch — or capacity error: records grow on demand, an environment
+the oracle could finish must finish here."""
 import os, sys, random, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
@@ -52,8 +53,9 @@ for it in range(rounds):
         env.rollout("random", T, auto_reset=True)
     except Exception as ex:
         msg = str(ex)
-        if "error -3" in msg:                              # a configured capacity was exceeded: reported, not wrong
-            print("capacity  %s k=%d B=%d T=%d: %s" % (dist, k, B, T, msg[:100])); continue
+        if "error -3" in msg:                              # capacities grow on demand (bbx_caps.no_growth = 0): the reference would
+            print("CAPACITY %s k=%d B=%d T=%d caps=%s seed0=%d: %s" % (dist, k, B, T, caps, seed0, msg[:160]))   # have continued, so this is a failure
+            sys.exit(1)
         if "error -4" in msg:                              # the generator fails where the reference throws
             print("generator %s: %s" % (dist, msg[:100])); continue
         print("ERROR %s k=%d B=%d T=%d caps=%s lean=%s seed0=%d: %s" % (dist, k, B, T, caps, lean, seed0, msg[:200]))

@@ -66,7 +66,7 @@ for it in range(rounds):
             raise
     except _ffi.BbxError as ex:
         if ex.code == -3:
-            print("capacity %s: %s" % (tag, str(ex)[:80])); continue
+            print("CAPACITY %s: %s" % (tag, str(ex)[:160])); sys.exit(1)   # (default capacities: a failure)
         print("ERROR %s: %s" % (tag, str(ex)[:200])); sys.exit(1)
     for t in range(T):
         live = torch.arange(R, device="cuda")[None, :] < N[t][:, None]

@@ -46,10 +46,47 @@ def test_batched_buffer_equals_per_episode_reference_formulas():
         assert not comp[start:, b].any()                        # the unfinished tail is left out
     _, a, lp, ad, vf = buf.get(normalize_advantages=True)
     keep = comp & (rows != 1)
-    all_adv = adv[comp]
-    want = ((all_adv - all_adv.mean()) / all_adv.std())[(rows != 1)[comp]]
+    all_adv = adv.T[comp.T]                                        # trajectory after trajectory (environment-major)
+    want = ((all_adv - all_adv.mean()) / all_adv.std())[(rows != 1).T[comp.T]]
     assert len(a) == keep.sum() and np.allclose(ad.numpy(), want.astype(np.float32), atol=1e-5)
-    assert np.allclose(vf.numpy(), ret[keep].astype(np.float32))
+    assert np.allclose(vf.numpy(), ret.T[keep.T].astype(np.float32))
+
+
+def test_buffer_get_batches_like_the_reference_padded_batch():
+    """TrajectoryBuffer.get(batch_size, sort, drop_remainder) (pg.py:162-240): batches of at most batch_size steps, the
+    state block of a batch as tall as its tallest state, -1 below every state's own rows, optional sort by rows."""
+    import torch
+    from deepgroebner_amd.rollout import DeviceTrajectoryBuffer
+    rng = np.random.default_rng(5)
+    T, B, R, cols = 40, 5, 9, 4
+    buf = DeviceTrajectoryBuffer(T, B, obs_shape=(R, cols), device="cpu")
+    rows = rng.integers(1, R + 1, size=(T, B)).astype(np.int32)
+    done = rng.random((T, B)) < 0.15
+    for t in range(T):
+        state = np.full((B, R, cols), -1, dtype=np.int32)
+        for b in range(B):
+            state[b, :rows[t, b]] = 100 * t + b
+        buf.store(torch.tensor(state), torch.tensor(rows[t]), torch.tensor(np.arange(B, dtype=np.int32) + t), torch.tensor(-np.ones(B)),
+                  torch.zeros(B), torch.zeros(B, dtype=torch.float64), torch.tensor(done[t]))
+    whole = buf.get()
+    n = len(whole[1])
+    assert n > 20
+    for sort in (False, True):
+        for drop in (False, True):
+            batches = buf.get(batch_size=8, sort=sort, drop_remainder=drop)
+            assert len(batches) == (n // 8 if drop else -(-n // 8))
+            seen = []
+            for st, a, lp, ad, vf in batches:
+                assert 1 <= len(a) <= 8 and (not drop or len(a) == 8)
+                r = (st[:, :, -1] != -1).sum(dim=1)
+                assert st.shape[1] == int(r.max()) and (r > 1).all()          # as tall as the tallest state, single rows filtered
+                for i in range(len(a)):
+                    assert (st[i, :r[i]] == st[i, 0, 0]).all() and (st[i, r[i]:] == -1).all()
+                seen += r.tolist()
+            if sort:
+                assert seen == sorted(seen)
+            elif not drop:
+                assert torch.equal(torch.cat([b[1] for b in batches]), whole[1])
 
 
 def test_pmlp_policy_masks_padding_like_the_reference():
@@ -227,3 +264,33 @@ def test_policy_rollout_rejects_what_the_kernel_class_cannot_do():
     with pytest.raises(_ffi.BbxError) as ei:
         env.policy_rollout_device(w["prepared"], w["hidden"], 4, z, z.int(), z.clone(), stream=torch.cuda.current_stream().cuda_stream)
     assert ei.value.code == -5                               # BBX_E_UNSUPPORTED (include/bbx.h)
+
+
+@pytest.mark.gpu
+def test_rollout_refuses_to_overrun_the_buffer_and_policy_row_limit():
+    """run_rollout_fused hands raw pointers into the trajectory buffer to the kernel: a rollout that does not fit raises
+    instead of writing past the arrays; observation blocks taller than the 1024 rows the policy kernels score are refused."""
+    import torch
+    from deepgroebner_amd import VecLeadMonomialsEnv, _ffi
+    from deepgroebner_amd.rollout import DeviceTrajectoryBuffer, PMLPPolicy, run_rollout_fused
+    B = 32
+    env = VecLeadMonomialsEnv("3-20-10-weighted", batch=B, k=2)
+    env.seed(np.arange(B) + 7); env.reset(); env.accounting(False)
+    policy = PMLPPolicy(env.cols, [64]).cuda()
+    buf = DeviceTrajectoryBuffer(40, B)
+    run_rollout_fused(env, policy, 30, buffer=buf, chunk=16)
+    assert buf.t == 30
+    with pytest.raises(IndexError):
+        run_rollout_fused(env, policy, 11, buffer=buf, chunk=16)
+    run_rollout_fused(env, policy, 10, buffer=buf, chunk=16)
+    assert buf.t == 40
+    obs = torch.zeros((B, 1100, env.cols), dtype=torch.int32, device="cuda")
+    w = policy._fused_weights()
+    u = torch.rand((4, B), device="cuda"); act = torch.zeros((4, B), dtype=torch.int32, device="cuda"); lp = torch.zeros((4, B), device="cuda")
+    with pytest.raises(_ffi.BbxError) as ei:
+        env.policy_rollout_device(w["prepared"], w["hidden"], 4, u, act, lp, obs=obs, obs_rows=1100)
+    assert ei.value.code == -5
+    rows = torch.full((B,), 3, dtype=torch.int32, device="cuda")
+    a2, l2 = policy.act(obs, rows, u[0])                            # (taller than the kernels score: the torch path serves it)
+    a3, l3 = policy.act_torch(obs, rows, u[0])
+    assert torch.equal(a2, a3) and torch.allclose(l2, l3)
