@@ -80,6 +80,7 @@ SIGNATURES = {
     "bbx_stats": (C.c_int, [_vp, _vp]),
     "bbx_env_status": (C.c_int, [_vp, _vp]),
     "bbx_capacities": (C.c_int, [_vp, _vp]),
+    "bbx_values_seeded": (C.c_int, [_vp, C.c_char_p, C.c_double, _vp, _vp]),
     "bbx_persistent": (C.c_int, [_vp, C.c_int]),
     "bbx_join": (C.c_int, [_vp, _vp]),
     "bbx_session_stats": (C.c_int, [_vp, _vp]),

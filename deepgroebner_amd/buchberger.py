@@ -202,10 +202,16 @@ class VecLeadMonomialsEnv:
         _ffi.check(_ffi.lib().bbx_value(self._h, int(idx), strategy.encode(), float(gamma), C.byref(v)))
         return v.value
 
-    def values(self, strategy="degree", gamma=0.99):
-        """value() of every environment at once (float64 [batch])."""
+    def values(self, strategy="degree", gamma=0.99, seeds=None):
+        """value() of every environment at once (float64 [batch]).  seeds: the seeds of the Random rollouts behind "random"
+        ([batch]) / "sample" ([batch, 100]) — buchberger(..., Random, seed) of the reference; None: the handle draws them."""
         out = np.zeros(self.batch, dtype=np.float64)
-        _ffi.check(_ffi.lib().bbx_values(self._h, strategy.encode(), float(gamma), _ffi.ptr(out)))
+        if seeds is None:
+            _ffi.check(_ffi.lib().bbx_values(self._h, strategy.encode(), float(gamma), _ffi.ptr(out)))
+        else:
+            s = np.ascontiguousarray(seeds, dtype=np.int64)
+            assert s.size == self.batch * (100 if strategy == "sample" else 1)
+            _ffi.check(_ffi.lib().bbx_values_seeded(self._h, strategy.encode(), float(gamma), _ffi.ptr(s), _ffi.ptr(out)))
         return out
 
     def copy(self):

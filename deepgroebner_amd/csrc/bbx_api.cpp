@@ -21,7 +21,9 @@
 
 extern "C" int bbx_launch_step(const BbxParams* p, int kind, int envs_per_block, hipStream_t stream);
 extern "C" int bbx_launch_clone(const char* src_recs, char* dst_recs, const BbxLayout* L, const int32_t* src, const int32_t* dst, int n,
-                                const uint32_t* seeds, int keep_counters, hipStream_t stream);
+                                const uint32_t* seeds, int keep_counters, int seed_std, int ngen, uint8_t* flags, hipStream_t stream);
+extern "C" int bbx_launch_value_resort(char* recs, const BbxLayout* L, int n, const uint8_t* flags, hipStream_t stream);
+extern "C" int bbx_launch_value_collect(const char* recs, uint32_t rec_bytes, int n, double* out2, hipStream_t stream);
 extern "C" int bbx_launch_relayout(const char* src_recs, char* dst_recs, const BbxLayout* Ls, const BbxLayout* Ld, int B, hipStream_t stream);
 extern "C" int bbx_launch_ctl(unsigned long long* ctl, unsigned long long value, hipStream_t stream);
 extern "C" int bbx_launch_gather_lite(const char* recs, uint32_t rec_bytes, int B, void* out, hipStream_t stream);
@@ -156,6 +158,7 @@ struct bbx_batch {
   long long ps_target = 0;            // steps issued since the session began
   BbxParams ps_p{};                   // the parameters of the call that began it (later calls must match to join)
   int ps_sessions = 0, ps_joined = 0, ps_kernels = 0; // statistics: sessions begun, calls that joined a running one, kernels
+  std::mt19937_64 value_rng;          // seeds of value("random") / value("sample") rollouts when the caller gives none
   bool no_growth = false;             // bbx_caps.no_growth: the configured capacities are hard limits (BBX_E_CAPACITY)
   int grow_events = 0;                // times the records were enlarged (bbx_capacities)
   bbx_batch() = default;
@@ -801,6 +804,7 @@ int create_common(std::unique_ptr<bbx::IdealGen> proto, int nvars_obs, int elimi
   long long seed_base;
   if (const char* sb = getenv("BBX_DEFAULT_SEED")) seed_base = atoll(sb);
   else { std::random_device rd; seed_base = (long long)(rd() & 0x3fffffffu); }
+  b->value_rng.seed((uint64_t)seed_base * 0x9E3779B97F4A7C15ull + 0x5851F42D4C957F2Dull);
   if (b->fixed) b->gens.push_back(std::move(proto));
   else {
     for (int e = 0; e < batch; e++) {
@@ -926,7 +930,7 @@ int bbx_copy(const bbx_batch* s, bbx_batch** out) {
   b->elim = s->elim; b->rewards = s->rewards; b->sort_input = s->sort_input; b->sort_reducers = s->sort_reducers;
   b->fixed = s->fixed; b->listed = s->listed; b->binom = s->binom; b->L = s->L; b->LL = s->LL; b->slot_words = s->slot_words; b->nslots = s->nslots;
   b->h_q = s->h_q; b->h_tail = s->h_tail; b->h_head = s->h_head; b->q_dirty = true;
-  b->no_growth = s->no_growth;
+  b->no_growth = s->no_growth; b->value_rng = s->value_rng;
   b->wide = s->wide; b->wide_terms = s->wide_terms; b->accounting = s->accounting; b->staged = s->staged; b->fast = s->fast; b->envs_per_block = s->envs_per_block;
   if (s->device_gen) {
     HIPCHK(hipMalloc((void**)&b->d_gen, s->gen_words * sizeof(uint32_t)));
@@ -971,7 +975,7 @@ int bbx_clone_envs(bbx_batch* b, int n, const int32_t* src, const int32_t* dst) 
   HIPCHK(hipMalloc((void**)&d_s, (size_t)n * 4)); HIPCHK(hipMalloc((void**)&d_d, (size_t)n * 4));
   HIPCHK(hipMemcpy(d_s, src, (size_t)n * 4, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(d_d, dst, (size_t)n * 4, hipMemcpyHostToDevice));
-  int lrc = bbx_launch_clone(b->d_recs, b->d_recs, &b->L, d_s, d_d, n, nullptr, 1, 0);
+  int lrc = bbx_launch_clone(b->d_recs, b->d_recs, &b->L, d_s, d_d, n, nullptr, 1, 0, 0, nullptr, 0);
   HIPCHK(hipDeviceSynchronize());
   (void)hipFree(d_s); (void)hipFree(d_d);
   if (lrc) return fail(BBX_E_DEVICE, "clone launch failed: %s", hipGetErrorString((hipError_t)lrc));
@@ -1407,128 +1411,107 @@ int bbx_batch_size(const bbx_batch* b) { return b ? b->B : 0; }
 // ---- value(): discounted return of full Buchberger rollouts from clones of the current states ---------------------
 namespace {
 
-bool packed_less(int W, const uint32_t* a, const uint32_t* b) {   // grevlex a < b on packed monomials (device m_gt)
-  for (int i = W - 1; i >= 0; i--) {              // most significant word first; exponent slots complemented, degree not
-    const uint32_t mk = i == W - 1 ? 0x0000FFFFu : 0xFFFFFFFFu;
-    const uint32_t ka = a[i] ^ mk, kb = b[i] ^ mk;
-    if (ka != kb) return ka < kb;
-  }
-  return false;
-}
-
-// buchberger() re-sorts its reducers with std::sort (buchberger.cpp:157-158).  That only differs from the
-// environment's own upper_bound order when lead monomials tie, which can only happen among the generators.  For a
-// clone with such a tie the reducer-order arrays are rebuilt on the host with the same std::sort call.
-int resort_reducers_if_tied(bbx_batch* b, char* vrec, const BbxHdr& h) {
-  const int W = b->W, nG = h.nG;
-  if (!b->sort_reducers || nG < 2) return BBX_OK;
-  const int ngen = std::min(nG, b->gens[0]->npolys());
-  std::vector<uint32_t> lm((size_t)nG * W);
-  HIPCHK(hipMemcpy(lm.data(), vrec + b->L.off_lm, (size_t)ngen * W * 4, hipMemcpyDeviceToHost));
-  bool tie = false;
-  for (int i = 0; i < ngen && !tie; i++)
-    for (int j = i + 1; j < ngen; j++)
-      if (!memcmp(&lm[(size_t)i * W], &lm[(size_t)j * W], (size_t)W * 4)) { tie = true; break; }
-  if (!tie) return BBX_OK;
-  HIPCHK(hipMemcpy(lm.data(), vrec + b->L.off_lm, (size_t)nG * W * 4, hipMemcpyDeviceToHost));
-  std::vector<int> ord(nG);
-  for (int i = 0; i < nG; i++) ord[i] = i;
-  std::sort(ord.begin(), ord.end(), [&](int x, int y) { return packed_less(W, &lm[(size_t)x * W], &lm[(size_t)y * W]); });
-  std::vector<uint32_t> slm((size_t)nG * W);
-  for (int r = 0; r < nG; r++) memcpy(&slm[(size_t)r * W], &lm[(size_t)ord[r] * W], (size_t)W * 4);
-  HIPCHK(hipMemcpy(vrec + b->L.off_slm, slm.data(), slm.size() * 4, hipMemcpyHostToDevice));
-  if (b->binom) {
-    std::vector<uint32_t> tm((size_t)nG * W), stm((size_t)nG * W), gi((size_t)nG * 2), si((size_t)nG * 2);
-    HIPCHK(hipMemcpy(tm.data(), vrec + b->L.off_tm, tm.size() * 4, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(gi.data(), vrec + b->L.off_ginfo, gi.size() * 4, hipMemcpyDeviceToHost));
-    for (int r = 0; r < nG; r++) {
-      const int g = ord[r];
-      memcpy(&stm[(size_t)r * W], &tm[(size_t)g * W], (size_t)W * 4);
-      const uint32_t tc = gi[2 * g] >> 16, inv = gi[2 * g + 1] & 0xffffu, sug = gi[2 * g + 1] >> 16;
-      const uint32_t kq = (32003u - (tc * inv) % 32003u) % 32003u;                    // -tc / lc mod p (bbx_binom.h: bin_add_poly)
-      si[2 * r] = tc | (kq << 16); si[2 * r + 1] = sug | ((uint32_t)g << 16);
-    }
-    HIPCHK(hipMemcpy(vrec + b->L.off_stm, stm.data(), stm.size() * 4, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(vrec + b->L.off_sinfo, si.data(), si.size() * 4, hipMemcpyHostToDevice));
-  } else {
-    std::vector<uint16_t> sidx(nG);
-    for (int r = 0; r < nG; r++) sidx[r] = (uint16_t)ord[r];
-    HIPCHK(hipMemcpy(vrec + b->L.off_sidx, sidx.data(), sidx.size() * 2, hipMemcpyHostToDevice));
-  }
-  return BBX_OK;
-}
-
 int agent_of_strategy(const char* s) {   // unknown keys select First: std::map::operator[] default (buchberger.cpp:342-349)
   if (!strcmp(s, "degree")) return BBX_AGENT_DEGREE;
   if (!strcmp(s, "normal")) return BBX_AGENT_NORMAL;
   if (!strcmp(s, "sugar")) return BBX_AGENT_SUGAR;
-  if (!strcmp(s, "random")) return BBX_AGENT_HASH;
+  if (!strcmp(s, "random")) return BBX_AGENT_STDRANDOM;   // choice(P, rng) of a seeded std::default_random_engine (buchberger.cpp:200-203, 244)
   return BBX_AGENT_FIRST;
 }
 
-// one rollout to completion per entry of src (indices into b); seeds != null re-seeds the clones' random agent
+// std::default_random_engine::seed(s) (linear_congruential_engine<uint_fast32_t, 16807, 0, 2^31-1>, libstdc++ bits/random.tcc):
+// the int seed converts to the unsigned result type first; x = s mod m, and 0 becomes 1
+uint32_t minstd_state_of_seed(long long seed) {
+  const uint32_t x = (uint32_t)((uint64_t)seed % 2147483647ull);
+  return x ? x : 1u;
+}
+
+// One rollout to completion per entry of src (indices into b), from clones of the current states; seeds != null: the
+// engine states of the clones' seeded Random selection.  Everything runs on the default stream without a copy in between
+// and with one wait: values + completion marks come back in one transfer at the end (clones whose generator lead monomials
+// tie get the reducer order buchberger()'s std::sort would give them from a kernel: bbx_value_resort_kernel).  3-variable binomial batches run on the register/LDS-resident class (bbx_fast_value_kernel),
+// environments that outgrow it and every other batch on the HBM-resident class of the batch, long-polynomial
+// environments one workgroup per clone.  A clone that runs out of room enlarges the records of the whole batch
+// (grow_records) and the rollouts start again.
 int value_rollouts(bbx_batch* b, const std::vector<int32_t>& src, int agent, const std::vector<uint32_t>* seeds, double gamma, double* out) {
   const int n = (int)src.size();
   if (b->in_flight) { int rc = finish(b, b->last_stream); if (rc) return rc; }
-  if (n > b->vcap) {
-    void* old[] = {b->d_vrecs, b->d_vhdr, b->d_vsrc, b->d_vseeds, b->d_vvals};
-    for (void* q : old) (void)hipFree(q);
-    b->d_vrecs = nullptr; b->d_vhdr = nullptr; b->d_vsrc = nullptr; b->d_vseeds = nullptr; b->d_vvals = nullptr; b->vcap = 0;
-    HIPCHK(hipMalloc((void**)&b->d_vrecs, (size_t)n * b->L.rec_bytes));
-    HIPCHK(hipMalloc((void**)&b->d_vhdr, (size_t)n * sizeof(BbxHdr)));
-    HIPCHK(hipMalloc((void**)&b->d_vsrc, (size_t)n * sizeof(int32_t)));
-    HIPCHK(hipMalloc((void**)&b->d_vseeds, (size_t)n * sizeof(uint32_t)));
-    HIPCHK(hipMalloc((void**)&b->d_vvals, (size_t)n * sizeof(double)));
-    b->vcap = n;
-  }
-  HIPCHK(hipMemcpy(b->d_vsrc, src.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice));
-  if (seeds) HIPCHK(hipMemcpy(b->d_vseeds, seeds->data(), (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice));
-  int lrc = bbx_launch_clone(b->d_recs, b->d_vrecs, &b->L, b->d_vsrc, nullptr, n, seeds ? b->d_vseeds : nullptr, 0, 0);
-  if (lrc) return fail(BBX_E_DEVICE, "clone launch failed: %s", hipGetErrorString((hipError_t)lrc));
-  std::vector<BbxHdr> vh(n);
-  lrc = bbx_launch_gather_hdr(b->d_vrecs, b->L.rec_bytes, n, b->d_vhdr, 0);
-  if (lrc) return fail(BBX_E_DEVICE, "gather launch failed: %s", hipGetErrorString((hipError_t)lrc));
-  HIPCHK(hipMemcpy(vh.data(), b->d_vhdr, (size_t)n * sizeof(BbxHdr), hipMemcpyDeviceToHost));
-  for (int k = 0; k < n; k++) {
-    if (vh[k].status != BBX_ST_OK) return fail(BBX_E_CAPACITY, "environment %d is in an error state", src[k]);
-    int rc = resort_reducers_if_tied(b, b->d_vrecs + (size_t)k * b->L.rec_bytes, vh[k]);
+  for (int attempt = 0; attempt < 40; attempt++) {
+    if (n > b->vcap) {
+      void* old[] = {b->d_vrecs, b->d_vhdr, b->d_vsrc, b->d_vseeds, b->d_vvals};
+      for (void* q : old) (void)hipFree(q);
+      b->d_vrecs = nullptr; b->d_vhdr = nullptr; b->d_vsrc = nullptr; b->d_vseeds = nullptr; b->d_vvals = nullptr; b->vcap = 0;
+      HIPCHK(hipMalloc((void**)&b->d_vrecs, (size_t)n * b->L.rec_bytes));
+      HIPCHK(hipMalloc((void**)&b->d_vhdr, (size_t)n));                        // clone flags (u8)
+      HIPCHK(hipMalloc((void**)&b->d_vsrc, (size_t)n * sizeof(int32_t)));
+      HIPCHK(hipMalloc((void**)&b->d_vseeds, (size_t)n * sizeof(uint32_t)));
+      HIPCHK(hipMalloc((void**)&b->d_vvals, (size_t)n * 2 * sizeof(double)));  // {value, completion mark} per clone
+      b->vcap = n;
+    }
+    HIPCHK(hipMemcpyAsync(b->d_vsrc, src.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, 0));
+    if (seeds) HIPCHK(hipMemcpyAsync(b->d_vseeds, seeds->data(), (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, 0));
+    const int ngen = b->sort_reducers ? b->gens[0]->npolys() : 0;
+    uint8_t* d_flags = (uint8_t*)b->d_vhdr;
+    int lrc = bbx_launch_clone(b->d_recs, b->d_vrecs, &b->L, b->d_vsrc, nullptr, n, seeds ? b->d_vseeds : nullptr, 0, 1, ngen, d_flags, 0);
+    if (lrc) return fail(BBX_E_DEVICE, "clone launch failed: %s", hipGetErrorString((hipError_t)lrc));
+    lrc = bbx_launch_value_resort(b->d_vrecs, &b->L, n, d_flags, 0);   // (clones whose generators tie: std::sort's order)
+    if (lrc) return fail(BBX_E_DEVICE, "resort launch failed: %s", hipGetErrorString((hipError_t)lrc));
+    BbxParams p; fill_params(b, &p);
+    p.recs = b->d_vrecs; p.B = n; p.nsteps = 1 << 30; p.set_budget = 1; p.agent = agent; p.auto_reset = 0;
+    p.value_mode = 1; p.gamma = gamma; p.values = nullptr; p.trace = nullptr; p.accounting = 0;
+    p.lite = nullptr;                                           // the clones are not the batch's environments
+    if (b->wide) lrc = bbx_launch_step(&p, 4, b->wide, 0);
+    else {
+      const bool vfast = b->fast && b->staged && (agent == BBX_AGENT_DEGREE || agent == BBX_AGENT_FIRST || agent == BBX_AGENT_STDRANDOM || agent == BBX_AGENT_HASH);
+      lrc = 0;
+      if (vfast) lrc = bbx_launch_step(&p, 3, b->envs_per_block, 0);
+      if (!lrc) { if (vfast) { p.set_budget = 0; p.pass = 1; } lrc = bbx_launch_step(&p, 0, b->envs_per_block, 0); }
+    }
+    if (lrc) return fail(BBX_E_DEVICE, "kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
+    lrc = bbx_launch_value_collect(b->d_vrecs, b->L.rec_bytes, n, b->d_vvals, 0);
+    if (lrc) return fail(BBX_E_DEVICE, "collect launch failed: %s", hipGetErrorString((hipError_t)lrc));
+    std::vector<double> v2((size_t)n * 2);
+    HIPCHK(hipMemcpy(v2.data(), b->d_vvals, v2.size() * sizeof(double), hipMemcpyDeviceToHost));   // the only wait of the call
+    unsigned grow = 0; int grow_k = -1;
+    for (int k = 0; k < n; k++) {
+      const int st = (int)v2[2 * (size_t)k + 1];
+      if (st == 0) continue;
+      if (st > 0 && bbx_st_capacity(st) && !b->no_growth) { grow |= 1u << st; if (grow_k < 0) grow_k = k; continue; }
+      return fail(BBX_E_CAPACITY, "value rollout of environment %d did not finish: %s", src[k], st > 0 ? status_name(st) : "pairs left");
+    }
+    if (!grow) {
+      for (int k = 0; k < n; k++) out[k] = v2[2 * (size_t)k];
+      return BBX_OK;
+    }
+    int rc = grow_records(b, grow, src[grow_k], 0);             // (frees the clones: sized by the old layout)
     if (rc) return rc;
   }
-  BbxParams p; fill_params(b, &p);
-  p.recs = b->d_vrecs; p.B = n; p.nsteps = 1 << 30; p.set_budget = 1; p.agent = agent; p.auto_reset = 0;
-  p.value_mode = 1; p.gamma = gamma; p.values = b->d_vvals; p.trace = nullptr; p.accounting = 0;
-  p.lite = nullptr;                                           // the clones are not the batch's environments
-  // HBM-resident class kernel (no resets, no staging); long-polynomial environments: one workgroup per clone
-  lrc = b->wide ? bbx_launch_step(&p, 4, b->wide, 0) : bbx_launch_step(&p, 0, b->envs_per_block, 0);
-  if (lrc) return fail(BBX_E_DEVICE, "kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
-  lrc = bbx_launch_gather_hdr(b->d_vrecs, b->L.rec_bytes, n, b->d_vhdr, 0);
-  if (lrc) return fail(BBX_E_DEVICE, "gather launch failed: %s", hipGetErrorString((hipError_t)lrc));
-  HIPCHK(hipMemcpy(vh.data(), b->d_vhdr, (size_t)n * sizeof(BbxHdr), hipMemcpyDeviceToHost));
-  for (int k = 0; k < n; k++)
-    if (vh[k].status != BBX_ST_OK || vh[k].nP != 0)
-      return fail(BBX_E_CAPACITY, "value rollout of environment %d did not finish: %s", src[k], status_name(vh[k].status));
-  HIPCHK(hipMemcpy(out, b->d_vvals, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
-  return BBX_OK;
+  return fail(BBX_E_CAPACITY, "value rollouts kept outgrowing the records");
 }
 
-int values_for(bbx_batch* b, const std::vector<int32_t>& envs, const char* strategy, double gamma, double* out) {
+// `seeds`: explicit seeds of the Random rollouts — [n] for "random", [n][100] for "sample" — or null: drawn from the
+// handle's own stream (the reference seeds from std::random_device: ours starts from the handle's seed base, so a run is
+// reproducible under BBX_DEFAULT_SEED)
+int values_for(bbx_batch* b, const std::vector<int32_t>& envs, const char* strategy, double gamma, const int64_t* seeds, double* out) {
   const int n = (int)envs.size();
+  auto draw = [b]() { return (long long)(b->value_rng() & 0x7fffffffull); };
   if (!strcmp(strategy, "sample")) {          // best of one Degree and 100 Random rollouts (buchberger.cpp:333-341)
     int rc = value_rollouts(b, envs, BBX_AGENT_DEGREE, nullptr, gamma, out);
     if (rc) return rc;
-    std::vector<int32_t> src; std::vector<uint32_t> seeds;
-    for (int e : envs) for (int i = 0; i < 100; i++) { src.push_back(e); seeds.push_back((uint32_t)rand() * 2654435761u + (uint32_t)i); }
+    std::vector<int32_t> src; std::vector<uint32_t> st;
+    src.reserve((size_t)n * 100); st.reserve((size_t)n * 100);
+    for (int k = 0; k < n; k++) for (int i = 0; i < 100; i++) { src.push_back(envs[k]); st.push_back(minstd_state_of_seed(seeds ? seeds[(size_t)k * 100 + i] : draw())); }
     std::vector<double> r(src.size());
-    rc = value_rollouts(b, src, BBX_AGENT_HASH, &seeds, gamma, r.data());
+    rc = value_rollouts(b, src, BBX_AGENT_STDRANDOM, &st, gamma, r.data());
     if (rc) return rc;
     for (int k = 0; k < n; k++) for (int i = 0; i < 100; i++) out[k] = std::max(out[k], r[(size_t)k * 100 + i]);
     return BBX_OK;
   }
   const int agent = agent_of_strategy(strategy);
-  if (agent == BBX_AGENT_HASH) {              // unseeded in the reference (std::random_device): not reproducible there either
-    std::vector<uint32_t> seeds(n);
-    for (auto& s : seeds) s = (uint32_t)rand() * 2654435761u;
-    return value_rollouts(b, envs, agent, &seeds, gamma, out);
+  if (agent == BBX_AGENT_STDRANDOM) {
+    std::vector<uint32_t> st(n);
+    for (int k = 0; k < n; k++) st[k] = minstd_state_of_seed(seeds ? seeds[k] : draw());
+    return value_rollouts(b, envs, agent, &st, gamma, out);
   }
   return value_rollouts(b, envs, agent, nullptr, gamma, out);
 }
@@ -1538,7 +1521,15 @@ int values_for(bbx_batch* b, const std::vector<int32_t>& envs, const char* strat
 extern "C" int bbx_value(bbx_batch* b, int idx, const char* strategy, double gamma, double* out) {
   if (!b || !strategy || !out || idx < 0 || idx >= b->B) return fail(BBX_E_ARG, "bad arguments");
   HIPCHK(hipSetDevice(b->device));
-  return values_for(b, std::vector<int32_t>{idx}, strategy, gamma, out);
+  return values_for(b, std::vector<int32_t>{idx}, strategy, gamma, nullptr, out);
+}
+
+extern "C" int bbx_values_seeded(bbx_batch* b, const char* strategy, double gamma, const int64_t* seeds, double* out) {
+  if (!b || !strategy || !out) return fail(BBX_E_ARG, "bad arguments");
+  HIPCHK(hipSetDevice(b->device));
+  std::vector<int32_t> envs(b->B);
+  for (int e = 0; e < b->B; e++) envs[e] = e;
+  return values_for(b, envs, strategy, gamma, seeds, out);
 }
 
 extern "C" int bbx_values(bbx_batch* b, const char* strategy, double gamma, double* out) {
@@ -1546,7 +1537,7 @@ extern "C" int bbx_values(bbx_batch* b, const char* strategy, double gamma, doub
   HIPCHK(hipSetDevice(b->device));
   std::vector<int32_t> envs(b->B);
   for (int e = 0; e < b->B; e++) envs[e] = e;
-  return values_for(b, envs, strategy, gamma, out);
+  return values_for(b, envs, strategy, gamma, nullptr, out);
 }
 
 extern "C" {

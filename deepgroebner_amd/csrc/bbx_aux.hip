@@ -90,9 +90,13 @@ extern "C" int bbx_launch_mark_reset(char* recs, uint32_t rec_bytes, int B, cons
 
 // value(): clone environment src[k] of one record array into slot k of another (live prefixes only), optionally
 // re-seeding the built-in random agent of the clone
+// seed_std != 0: the seeds are states of the std::default_random_engine behind the seeded Random selection (BbxHdr.std_rng)
+// instead of seeds of the counter-hash agent.  flags (or null): per clone, bit 0 = the source is in an error state, bit 1 =
+// two of its first ngen basis elements (the ideal's generators) have the same lead monomial (value(): buchberger() sorts
+// its reducers with std::sort, whose order of equal elements the host reproduces — bbx_api.cpp).
 template <int W>
 __global__ void bbx_clone_kernel(const char* src_recs, char* dst_recs, BbxLayout L, const int32_t* src, const int32_t* dst, int n,
-                                 const uint32_t* seeds, int keep_counters) {
+                                 const uint32_t* seeds, int keep_counters, int seed_std, int ngen, uint8_t* flags) {
   const int k = blockIdx.x * (blockDim.x / WAVE) + (int)(threadIdx.x / WAVE);
   if (k >= n) return;
   char* s = const_cast<char*>(src_recs) + (size_t)src[k] * L.rec_bytes;
@@ -100,18 +104,183 @@ __global__ void bbx_clone_kernel(const char* src_recs, char* dst_recs, BbxLayout
   BbxHdr h = *(const BbxHdr*)s;
   if (L.kind == 1) bstage_copy<W>(benv_view<W>(d, L), benv_view<W>(s, L), h.nG, h.nP);
   else stage_copy<W>(env_view<W>(d, L), env_view<W>(s, L), h.nG, h.nP, h.arena_used);
+  if (flags) {
+    const Mono<W>* lm = (const Mono<W>*)(s + L.off_lm);
+    const int ng = h.nG < ngen ? h.nG : ngen;
+    bool tie = false;
+    for (int i = lane_id(); i < ng; i += WAVE) {
+      const Mono<W> mi = lm[i];
+      for (int j = i + 1; j < ng; j++) tie = tie || m_eq(mi, lm[j]);
+    }
+    const bool any = ballot64(tie) != 0;
+    if (lane_id() == 0) flags[k] = (uint8_t)((h.status != BBX_ST_OK ? 1 : 0) | (any ? 2 : 0));
+  }
   if (lane_id() == 0) {
     if (!keep_counters) { h.need_reset = 0; h.budget = 0; h.rollout_pos = 0; h.t = 0; }
-    if (seeds) h.agent_seed = seeds[k];
+    if (seeds) { if (seed_std) h.std_rng = seeds[k]; else h.agent_seed = seeds[k]; }
     *(BbxHdr*)d = h;
   }
 }
 extern "C" int bbx_launch_clone(const char* src_recs, char* dst_recs, const BbxLayout* L, const int32_t* src, const int32_t* dst, int n,
-                                const uint32_t* seeds, int keep_counters, hipStream_t stream) {
+                                const uint32_t* seeds, int keep_counters, int seed_std, int ngen, uint8_t* flags, hipStream_t stream) {
   const int blocks = (n + 3) / 4;
-  if (L->W == 2) hipLaunchKernelGGL((bbx_clone_kernel<2>), dim3(blocks), dim3(256), 0, stream, src_recs, dst_recs, *L, src, dst, n, seeds, keep_counters);
-  else if (L->W == 4) hipLaunchKernelGGL((bbx_clone_kernel<4>), dim3(blocks), dim3(256), 0, stream, src_recs, dst_recs, *L, src, dst, n, seeds, keep_counters);
-  else hipLaunchKernelGGL((bbx_clone_kernel<8>), dim3(blocks), dim3(256), 0, stream, src_recs, dst_recs, *L, src, dst, n, seeds, keep_counters);
+  if (L->W == 2) hipLaunchKernelGGL((bbx_clone_kernel<2>), dim3(blocks), dim3(256), 0, stream, src_recs, dst_recs, *L, src, dst, n, seeds, keep_counters, seed_std, ngen, flags);
+  else if (L->W == 4) hipLaunchKernelGGL((bbx_clone_kernel<4>), dim3(blocks), dim3(256), 0, stream, src_recs, dst_recs, *L, src, dst, n, seeds, keep_counters, seed_std, ngen, flags);
+  else hipLaunchKernelGGL((bbx_clone_kernel<8>), dim3(blocks), dim3(256), 0, stream, src_recs, dst_recs, *L, src, dst, n, seeds, keep_counters, seed_std, ngen, flags);
+  return (int)hipGetLastError();
+}
+// ---- value(): the reducer order buchberger() starts from ---------------------------------------------------------------
+// buchberger() re-sorts its reducers with std::sort (buchberger.cpp:157-158: G_ = F in basis order, sorted by lead
+// monomial).  The environment keeps its own reducer order by upper_bound insertion, which is the STABLE order; the two
+// differ only when lead monomials tie — possible among the ideal's generators only — AND the basis has more than 16
+// elements, where libstdc++'s std::sort stops being an insertion sort: introsort (median-of-three quicksort with a depth
+// limit of 2 log2 n and a heapsort fallback, segments of <= 16 left to a final insertion sort; bits/stl_algo.h
+// __introsort_loop / __final_insertion_sort, GCC 11).  For the clones that need it one lane reproduces that sort on an
+// index array, the wave then rebuilds the reducer-order arrays.  less(a, b) = LM(G[a]) < LM(G[b]).
+template <int W> struct SortCtx {
+  const Mono<W>* lm; uint16_t* v;
+  __device__ __forceinline__ bool less(int a, int b) const { return m_gt(lm[b], lm[a]); }
+};
+template <int W> __device__ void ss_unguarded_linear_insert(const SortCtx<W>& c, int last) {
+  const int val = c.v[last];
+  int next = last - 1;
+  while (c.less(val, c.v[next])) { c.v[last] = c.v[next]; last = next; next--; }
+  c.v[last] = (uint16_t)val;
+}
+template <int W> __device__ void ss_insertion_sort(const SortCtx<W>& c, int first, int last) {
+  if (first == last) return;
+  for (int i = first + 1; i != last; i++) {
+    if (c.less(c.v[i], c.v[first])) {
+      const int val = c.v[i];
+      for (int j = i; j > first; j--) c.v[j] = c.v[j - 1];               // move_backward(first, i, i + 1)
+      c.v[first] = (uint16_t)val;
+    } else ss_unguarded_linear_insert<W>(c, i);
+  }
+}
+template <int W> __device__ void ss_adjust_heap(const SortCtx<W>& c, int first, int hole, int len, int value) {
+  const int top = hole;
+  int child = hole;
+  while (child < (len - 1) / 2) {
+    child = 2 * (child + 1);
+    if (c.less(c.v[first + child], c.v[first + child - 1])) child--;
+    c.v[first + hole] = c.v[first + child];
+    hole = child;
+  }
+  if ((len & 1) == 0 && child == (len - 2) / 2) {
+    child = 2 * (child + 1);
+    c.v[first + hole] = c.v[first + child - 1];
+    hole = child - 1;
+  }
+  int parent = (hole - 1) / 2;                                            // __push_heap
+  while (hole > top && c.less(c.v[first + parent], value)) {
+    c.v[first + hole] = c.v[first + parent];
+    hole = parent;
+    parent = (hole - 1) / 2;
+  }
+  c.v[first + hole] = (uint16_t)value;
+}
+template <int W> __device__ void ss_heapsort(const SortCtx<W>& c, int first, int last) {   // __partial_sort(first, last, last)
+  const int len = last - first;
+  if (len >= 2)
+    for (int parent = (len - 2) / 2;; parent--) { ss_adjust_heap<W>(c, first, parent, len, c.v[first + parent]); if (parent == 0) break; }
+  while (last - first > 1) {
+    --last;
+    const int value = c.v[last];
+    c.v[last] = c.v[first];
+    ss_adjust_heap<W>(c, first, 0, last - first, value);
+  }
+}
+template <int W> __device__ void ss_std_sort(const SortCtx<W>& c, int n) {
+  if (n <= 0) return;
+  int lg = 0;
+  for (int t = n; t > 1; t >>= 1) lg++;
+  // __introsort_loop: recursion on the right part, iteration on the left — the segments are independent, so an explicit
+  // stack serves (at most one entry per level: the depth limit bounds it)
+  int sf[48], sl[48], sd[48], sp = 0;
+  sf[0] = 0; sl[0] = n; sd[0] = 2 * lg; sp = 1;
+  while (sp > 0) {
+    sp--;
+    int first = sf[sp], last = sl[sp], depth = sd[sp];
+    while (last - first > 16) {
+      if (depth == 0) { ss_heapsort<W>(c, first, last); break; }
+      --depth;
+      const int mid = first + (last - first) / 2, a = first + 1, b = mid, cc = last - 1;
+      auto swp = [&](int x, int y) { const uint16_t t = c.v[x]; c.v[x] = c.v[y]; c.v[y] = t; };
+      if (c.less(c.v[a], c.v[b])) {                                       // __move_median_to_first(first, first + 1, mid, last - 1)
+        if (c.less(c.v[b], c.v[cc])) swp(first, b); else if (c.less(c.v[a], c.v[cc])) swp(first, cc); else swp(first, a);
+      } else if (c.less(c.v[a], c.v[cc])) swp(first, a);
+      else if (c.less(c.v[b], c.v[cc])) swp(first, cc);
+      else swp(first, b);
+      int lo = first + 1, hi = last;                                      // __unguarded_partition(first + 1, last, pivot = first)
+      for (;;) {
+        while (c.less(c.v[lo], c.v[first])) lo++;
+        --hi;
+        while (c.less(c.v[first], c.v[hi])) --hi;
+        if (!(lo < hi)) break;
+        swp(lo, hi);
+        lo++;
+      }
+      if (sp < 48) { sf[sp] = lo; sl[sp] = last; sd[sp] = depth; sp++; }
+      last = lo;
+    }
+  }
+  if (n > 16) {                                                            // __final_insertion_sort
+    ss_insertion_sort<W>(c, 0, 16);
+    for (int i = 16; i != n; i++) ss_unguarded_linear_insert<W>(c, i);
+  } else ss_insertion_sort<W>(c, 0, n);
+}
+template <int W>
+__global__ void bbx_value_resort_kernel(char* recs, BbxLayout L, int n, const uint8_t* flags) {
+  const int k = blockIdx.x * (blockDim.x / WAVE) + (int)(threadIdx.x / WAVE);
+  if (k >= n || !(flags[k] & 2)) return;
+  char* rec = recs + (size_t)k * L.rec_bytes;
+  const BbxHdr* h = (const BbxHdr*)rec;
+  const int nG = h->nG, lane = lane_id();
+  if (nG <= 16) return;                                    // std::sort is its (stable) insertion sort there: the environment's order
+  const Mono<W>* lm = (const Mono<W>*)(rec + L.off_lm);
+  uint16_t* ord = (uint16_t*)(rec + L.off_lcm);            // (the update's scratch: idle between steps)
+  if (lane == 0) {
+    for (int i = 0; i < nG; i++) ord[i] = (uint16_t)i;
+    SortCtx<W> c{lm, ord};
+    ss_std_sort<W>(c, nG);
+  }
+  wave_sync();
+  Mono<W>* slm = (Mono<W>*)(rec + L.off_slm);
+  if (L.kind == 1) {
+    const Mono<W>* tm = (const Mono<W>*)(rec + L.off_tm);
+    Mono<W>* stm = (Mono<W>*)(rec + L.off_stm);
+    const uint2* gi = (const uint2*)(rec + L.off_ginfo);
+    uint2* si = (uint2*)(rec + L.off_sinfo);
+    for (int r = lane; r < nG; r += WAVE) {
+      const int g = ord[r];
+      const uint2 gg = gi[g];
+      const uint32_t tc = gg.x >> 16, inv = gg.y & 0xffffu, sug = gg.y >> 16;
+      slm[r] = lm[g]; stm[r] = tm[g];
+      si[r] = make_uint2(tc | (negmod(mulmod(tc, inv)) << 16), sug | ((uint32_t)g << 16));   // .x = tc | (-tc / lc) << 16 (bin_add_poly)
+    }
+  } else {
+    uint16_t* sidx = (uint16_t*)(rec + L.off_sidx);
+    for (int r = lane; r < nG; r += WAVE) { const int g = ord[r]; slm[r] = lm[g]; sidx[r] = (uint16_t)g; }
+  }
+}
+extern "C" int bbx_launch_value_resort(char* recs, const BbxLayout* L, int n, const uint8_t* flags, hipStream_t stream) {
+  const int blocks = (n + 3) / 4;
+  if (L->W == 2) hipLaunchKernelGGL((bbx_value_resort_kernel<2>), dim3(blocks), dim3(256), 0, stream, recs, *L, n, flags);
+  else if (L->W == 4) hipLaunchKernelGGL((bbx_value_resort_kernel<4>), dim3(blocks), dim3(256), 0, stream, recs, *L, n, flags);
+  else hipLaunchKernelGGL((bbx_value_resort_kernel<8>), dim3(blocks), dim3(256), 0, stream, recs, *L, n, flags);
+  return (int)hipGetLastError();
+}
+
+// value(): per clone {discounted return, 0 when the rollout ran to the end without an error} after the rollouts
+__global__ void bbx_value_collect_kernel(const char* recs, uint32_t rec_bytes, int n, double* out2) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const BbxHdr* h = (const BbxHdr*)(recs + (size_t)k * rec_bytes);
+  out2[2 * (size_t)k] = h->vret;
+  out2[2 * (size_t)k + 1] = (h->status != BBX_ST_OK || h->nP != 0) ? (double)(h->status ? h->status : -1) : 0.0;
+}
+extern "C" int bbx_launch_value_collect(const char* recs, uint32_t rec_bytes, int n, double* out2, hipStream_t stream) {
+  hipLaunchKernelGGL(bbx_value_collect_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, recs, rec_bytes, n, out2);
   return (int)hipGetLastError();
 }
 

@@ -43,6 +43,7 @@ struct BbxFastParams {
   int32_t sort_input;                                 // device-drawn ideals enter in ascending lead-monomial order
   unsigned long long* prof;                           // diagnostic build only: [B][8] cycle sums per phase
   const unsigned long long* ctl; int32_t sess_target; uint32_t slice_ticks;   // persistent sessions: see BbxParams
+  double gamma; double* values;                       // VAL instantiation (value(), buchberger.cpp:332-351): discount, [B] returns
   unsigned long long* ctl_stats;                      // statistics word: steps taken by closing launches
 };
 
@@ -131,7 +132,9 @@ struct FastState {                 // reducer-order arrays, lane l <-> reducers 
 // and carries on if the host has issued more meanwhile.  It leaves when told to stop, after 20 ms without news, or when
 // the kernel's time slice is over (steps still owed then: BBX_ST_TIMESLICE) — exits every wave reaches (s_memrealtime
 // counts at 100 MHz whatever the shader clock does).  What is owed when it leaves is taken by the session's next kernel.
-template <bool TRACE, bool ACCT, bool PROF = false, bool HL = false, int POL = 0, bool PERSIST = false>
+// VAL: value() rollouts (buchberger.cpp:248-252, 332-351): the discounted return of the steps taken is accumulated in
+// double, without fusing multiply and add, and written to values[] when the wave leaves.
+template <bool TRACE, bool ACCT, bool PROF = false, bool HL = false, int POL = 0, bool PERSIST = false, bool VAL = false>
 __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem, int ext_action = -1) {
   unsigned long long prof_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long prof_last = PROF ? __builtin_amdgcn_s_memtime() : 0;
@@ -158,6 +161,9 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem, in
   int status = uni(ghdr->status), need_reset = uni(ghdr->need_reset), q_head = uni(ghdr->q_head);
   int t_agent = uni(ghdr->t);
   uint32_t gen_state = ghdr->gen_rng;                  // (a vector register: only the reset touches it)
+  uint32_t std_rng = HL ? 0u : ghdr->std_rng;          // (likewise: only the seeded std::default_random_engine selection touches it)
+  double vret = 0.0, vdisc = 1.0;                      // VAL
+  if (VAL && !p.set_budget) { vret = ghdr->vret; vdisc = ghdr->vdisc; }
   const uint32_t agent_seed = (uint32_t)uni((int)ghdr->agent_seed);
   int budget = uni(ghdr->budget), rollout_pos = uni(ghdr->rollout_pos), done_last = uni(ghdr->done_last);
   if (status == BBX_ST_STARVED || status == BBX_ST_SPILL || status == BBX_ST_TIMESLICE) status = BBX_ST_OK;
@@ -571,6 +577,11 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem, in
     if (agent == BBX_AGENT_HASH) action = (int)(((uint64_t)f_readlane(hv, t_agent & 63) * (uint32_t)nP) >> 32);   // bbx_agent_action32
     else if (agent == BBX_AGENT_EXTERNAL) action = ext_action >= 0 ? ext_action : uni(f_cold_params()->actions[env]);
     else if (agent == BBX_AGENT_FIRST) action = 0;
+    else if (!HL && agent == BBX_AGENT_STDRANDOM) {        // choice(P.begin(), P.end(), rng) of the seeded engine (buchberger.cpp:200-203, 244)
+      uint32_t x = (uint32_t)uni((int)std_rng);
+      action = std_choice(x, nP);
+      std_rng = x;
+    }
     else {                                                 // degree: first row of minimal deg lcm (buchberger.cpp:171-176)
       uint32_t best = 0xFFFFFFFFu;
       for (int r = lane; r < nP; r += WAVE) {
@@ -724,6 +735,7 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem, in
     FSTAMP(4);                                             // 4: add_poly (pair update, insert)
     if (ACCT) { bytes += nP * obs_row_bytes; bytes_total += bytes; }
     last_nred = vzero + nred;
+    if (VAL) value_accumulate(vret, vdisc, p.rewards_mode == BBX_REW_ADDITIONS ? (-1.0 - (double)nred) : -1.0, p.gamma);
     adds += 1 + nred; t_agent++;
     if ((t_agent & 63) == 0) hv = bbx_agent_hash32(agent_seed, (uint32_t)(t_agent + lane));
 #ifndef BBX_PRIO_SHIFT
@@ -814,6 +826,8 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem, in
     h->nG = nG; h->nP = nP; h->arena_used = 0; h->status = status; h->need_reset = need_reset;
     h->q_head = q_head; h->t = t_agent; h->total_steps += steps_done; h->total_additions += adds;
     h->gen_rng = gen_state;
+    if (!HL) h->std_rng = std_rng;
+    if (VAL) { h->vret = vret; h->vdisc = vdisc; if (cz->values) cz->values[env] = vret; }
     h->episodes += episodes; h->zero_reductions += zero_red; h->steps_done = steps_done;
     h->budget = budget; h->rollout_pos = rollout_pos; h->done_last = done_last; h->alg_bytes += bytes_total;
     const int trunc_all = (cz->set_budget ? 0 : h->obs_trunc) | obs_trunc;
@@ -848,6 +862,11 @@ __global__ __launch_bounds__(256) void bbx_fast_kernel(BbxFastParams p) {
 __global__ __launch_bounds__(256) void bbx_fast_headline_kernel(BbxFastParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   fast_body<false, false, false, true>(p, smem);
+}
+// value() rollouts of the register/LDS-resident class
+__global__ __launch_bounds__(256) void bbx_fast_value_kernel(BbxFastParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  fast_body<false, false, false, false, 0, false, true>(p, smem);
 }
 // the kernels of persistent sessions (fast_body PERSIST): the headline shape and the general lean one
 __global__ __launch_bounds__(256) void bbx_fast_headline_persistent_kernel(BbxFastParams p) {

@@ -19,6 +19,7 @@ extern "C" int bbx_launch_fast(const BbxParams* p, int blocks, int threads, int 
   f.gen = p->gen;
   f.sort_input = p->sort_input;
   f.ctl = p->ctl; f.sess_target = p->sess_target; f.ctl_stats = p->ctl_stats; f.slice_ticks = p->slice_ticks;
+  f.gamma = p->gamma; f.values = p->values;
   const size_t lds = (size_t)envs_per_block * FLDS_BYTES;
 #ifdef BBX_PROF_BUILD
   static unsigned long long* d_prof = nullptr;
@@ -55,6 +56,7 @@ extern "C" int bbx_launch_fast(const BbxParams* p, int blocks, int threads, int 
            else hipLaunchKernelGGL((bbx_fast_policy_kernel<4, 6>), dim3(blocks), dim3(threads), ll, stream, q); }
     return 0;
   }
+  if (p->value_mode) { hipLaunchKernelGGL(bbx_fast_value_kernel, dim3(blocks), dim3(threads), lds, stream, f); return 0; }   // (lean, untraced: bbx_api.cpp)
   if (p->ctl) {                                            // the kernel of a persistent session (bbx_api.cpp admits lean, untraced launches only)
     if (f.agent == BBX_AGENT_HASH && f.nvars == 3 && f.k == 2 && f.obs && f.obs_every_step && !f.obs_fill && f.auto_reset)
       hipLaunchKernelGGL(bbx_fast_headline_persistent_kernel, dim3(blocks), dim3(threads), lds, stream, f);

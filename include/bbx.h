@@ -150,8 +150,15 @@ int bbx_batch_size(const bbx_batch* b);
  * discounted return of a full Buchberger rollout from environment idx's current state.
  * Unknown strategies select First, as the reference's std::map lookup does. */
 int bbx_value(bbx_batch* b, int idx, const char* strategy, double gamma, double* out);
-/* the same for every environment of the batch at once: out[batch] */
+/* the same for every environment of the batch at once: out[batch].  "random" and "sample" roll out under
+ * buchberger(..., SelectionType::Random, ..., seed) (buchberger.cpp:200-203, 244: a std::default_random_engine seeded per
+ * rollout, every pick choice(P.begin(), P.end(), rng)); the reference seeds each rollout from std::random_device, here the
+ * seeds come from a stream of the handle's own (started from its seed base: reproducible under BBX_DEFAULT_SEED). */
 int bbx_values(bbx_batch* b, const char* strategy, double gamma, double* out);
+/* ... with the seeds of the Random rollouts given: seeds[batch] for "random", seeds[batch][100] for "sample" (the 100
+ * Random rollouts of environment e; its Degree rollout needs none); other strategies ignore them.  Equal to the
+ * reference's buchberger(G, P, Random, ..., seed).discounted_return per rollout, bit for bit. */
+int bbx_values_seeded(bbx_batch* b, const char* strategy, double gamma, const int64_t* seeds, double* out);
 
 /* ---- same calls on caller-owned DEVICE buffers (e.g. torch tensors), asynchronous on `stream` ----
  * (hipStream_t passed as void*; NULL = the default stream).  obs may be NULL.

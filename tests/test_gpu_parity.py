@@ -398,6 +398,45 @@ def test_values_batch_and_state_untouched():
     assert v >= want[2][0]                                             # best of degree + 100 random rollouts
 
 
+@pytest.mark.parametrize("dist,caps", [("3-20-10-weighted", None), ("3-20-10-weighted", {"lds_max_basis": 16}), ("3-20-10-weighted", {"lds_max_basis": -1}),
+                                       ("5-10-5-uniform", None), ("3-5-4-0.5-uniform", None)])
+def test_value_random_and_sample_with_explicit_seeds(dist, caps):
+    """value('random') / value('sample') roll out under buchberger(G, P, SelectionType::Random, ..., seed) (buchberger.cpp:
+    200-203, 244, 332-351).  With the seeds given, every value equals the oracle's seeded rollout from the same state, ==
+    on doubles; 'sample' is the best of the Degree rollout and the 100 seeded Random ones.  Register/LDS-resident class,
+    its HBM-resident continuation, the HBM-resident binomial class and the general class."""
+    from deepgroebner_amd import VecLeadMonomialsEnv
+    bo = ffi.load("bo")
+    B, T0 = 12, 5
+    env = VecLeadMonomialsEnv(dist, batch=B, k=2, caps=caps)
+    env.seed(np.arange(B) + 70); env.seed_agent(np.arange(B)); env.reset()
+    env.rollout("random", T0, auto_reset=True)                      # somewhere inside an episode
+    states = []
+    for e in range(B):
+        o = bo.env(dist); o.seed(70 + e); o.reset()
+        for t in range(T0):
+            o.step(ffi.agent_action(e, t, o.nP))
+            if o.nP == 0:
+                o.reset()
+        G = [[(int(c), tuple(int(x) for x in ex)) for c, ex in zip(cs, es)] for cs, es in o.basis()]
+        states.append((G, [tuple(int(x) for x in p) for p in o.pairs()]))
+    rng = np.random.default_rng(11)
+    seeds = rng.integers(-2 ** 31, 2 ** 31 - 1, size=B)
+    seeds[:3] = (0, 2147483647, -1)                                 # x = seed mod (2^31 - 1), 0 becomes 1
+    def ret(e, selection, seed=None):
+        G, P = states[e]
+        if not P:
+            return 0.0
+        return bo.buchberger(G, P, selection=selection, seed=None if seed is None else int(seed), want_basis=False)[1]["discounted_return"]
+    got = env.values("random", 0.99, seeds=seeds)
+    assert got.tolist() == [ret(e, "random", seeds[e]) for e in range(B)]
+    seeds2 = rng.integers(0, 2 ** 31 - 1, size=(B, 100))
+    got = env.values("sample", 0.99, seeds=seeds2)
+    want = [max([ret(e, "degree")] + [ret(e, "random", s) for s in seeds2[e]]) for e in range(B)]
+    assert got.tolist() == want
+    assert (env.values("sample", 0.99) >= env.values("degree", 0.99)).all()      # (seeds drawn by the handle)
+
+
 def test_bad_action_is_an_error_not_ub():
     from deepgroebner_amd import CLeadMonomialsEnv, _ffi
     env = CLeadMonomialsEnv("3-20-10-weighted", k=1)
