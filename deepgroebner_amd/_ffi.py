@@ -80,6 +80,16 @@ SIGNATURES = {
     "bbx_stats": (C.c_int, [_vp, _vp]),
     "bbx_env_status": (C.c_int, [_vp, _vp]),
     "bbx_capacities": (C.c_int, [_vp, _vp]),
+    "bbx_alg_create": (C.c_int, [C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.POINTER(_vp)]),
+    "bbx_alg_destroy": (None, [_vp]),
+    "bbx_alg_from_envs": (C.c_int, [_vp, C.c_int, _vp, C.POINTER(_vp)]),
+    "bbx_alg_binop": (C.c_int, [_vp, C.c_int, _vp]),
+    "bbx_alg_reduce": (C.c_int, [_vp, _vp, _vp]),
+    "bbx_alg_update": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, C.c_int]),
+    "bbx_alg_minimalize": (C.c_int, [_vp]),
+    "bbx_alg_interreduce": (C.c_int, [_vp]),
+    "bbx_alg_sizes": (C.c_int, [_vp, _vp, _vp]),
+    "bbx_alg_get": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp]),
     "bbx_values_seeded": (C.c_int, [_vp, C.c_char_p, C.c_double, _vp, _vp]),
     "bbx_persistent": (C.c_int, [_vp, C.c_int]),
     "bbx_join": (C.c_int, [_vp, _vp]),

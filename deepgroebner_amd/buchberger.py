@@ -460,6 +460,185 @@ class BuchbergerEnv:
         return other
 
 
+# ---- the reference's free functions (buchberger.py:11-240; buchberger.cpp:18-122), on the device ----------------------------
+# Polynomials are term lists [(coefficient, exponent tuple), ...] in descending grevlex order over GF(32003), the form
+# BuchbergerEnv hands out.  Every call marshals its operands into device-resident lists (bbx_alg_*, include/bbx.h) and runs
+# the kernels of csrc/bbx_algebra.hip; the *_many forms take a batch of independent problems per launch.
+
+class PolyLists:
+    """A batch of independent polynomial lists (std::vector<Polynomial>) on the device."""
+
+    def __init__(self, lists, device=0):
+        self.n = len(lists)
+        self._h = C.c_void_p()
+        npolys = np.array([len(L) for L in lists], dtype=np.int32)
+        nterms = np.array([len(f) for L in lists for f in L], dtype=np.int32)
+        coefs = np.array([int(c) for L in lists for f in L for c, _ in f], dtype=np.int32)
+        exps = np.zeros((max(len(coefs), 1), NV), dtype=np.int32)
+        r = 0
+        for L in lists:
+            for f in L:
+                for _, e in f:
+                    exps[r, :len(e)] = e
+                    r += 1
+        _ffi.check(_ffi.lib().bbx_alg_create(int(device), self.n, _ffi.ptr(npolys), _ffi.ptr(nterms), _ffi.ptr(coefs), _ffi.ptr(exps), C.byref(self._h)))
+
+    @classmethod
+    def from_envs(cls, vec_env, envs=None):
+        """The bases of environments of a VecLeadMonomialsEnv (None: all) as device-resident lists, copied on the device."""
+        self = cls.__new__(cls)
+        idx = np.arange(vec_env.batch, dtype=np.int32) if envs is None else np.ascontiguousarray(envs, dtype=np.int32)
+        self.n = len(idx)
+        self._h = C.c_void_p()
+        _ffi.check(_ffi.lib().bbx_alg_from_envs(vec_env._h, self.n, _ffi.ptr(idx), C.byref(self._h)))
+        return self
+
+    def __del__(self):
+        try:
+            if self._h:
+                _ffi.lib().bbx_alg_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def _ij(self, pairs):
+        return np.ascontiguousarray(np.broadcast_to(np.asarray(pairs, dtype=np.int32), (self.n, 2)))
+
+    def binop(self, op, ij):
+        """op in {'add', 'sub', 'mul', 'spoly'} of elements ij = (i, j) (one pair for all lists or one per list): appended."""
+        _ffi.check(_ffi.lib().bbx_alg_binop(self._h, {"add": 0, "sub": 1, "mul": 2, "spoly": 3}[op], _ffi.ptr(self._ij(ij))))
+
+    def reduce(self, g_and_nF):
+        steps = np.zeros(self.n, dtype=np.int32)
+        _ffi.check(_ffi.lib().bbx_alg_reduce(self._h, _ffi.ptr(self._ij(g_and_nF)), _ffi.ptr(steps)))
+        return steps
+
+    def update(self, pairs, elimination="gebauermoeller"):
+        """pairs: one list of (i, j) per polynomial list -> the new pair lists."""
+        npairs = np.array([len(P) for P in pairs], dtype=np.int32)
+        flat = np.array([x for P in pairs for p in P for x in p], dtype=np.int32).reshape(-1, 2)
+        sizes = np.zeros(self.n, dtype=np.int32); tot = np.zeros(self.n, dtype=np.int32)
+        _ffi.check(_ffi.lib().bbx_alg_sizes(self._h, _ffi.ptr(sizes), _ffi.ptr(tot)))
+        cap = int(npairs.sum() + sizes.sum()) + 1
+        nout = np.zeros(self.n, dtype=np.int32); out = np.zeros((cap, 2), dtype=np.int32)
+        _ffi.check(_ffi.lib().bbx_alg_update(self._h, _ffi.ELIMINATION[elimination], _ffi.ptr(npairs), _ffi.ptr(flat) if len(flat) else None,
+                                             _ffi.ptr(nout), _ffi.ptr(out), cap))
+        res, at = [], 0
+        for k in range(self.n):
+            res.append([(int(i), int(j)) for i, j in out[at:at + nout[k]]]); at += int(nout[k])
+        return res
+
+    def minimalize(self):
+        _ffi.check(_ffi.lib().bbx_alg_minimalize(self._h))
+
+    def interreduce(self):
+        _ffi.check(_ffi.lib().bbx_alg_interreduce(self._h))
+
+    def get(self, k):
+        """List k as term lists (exponent tuples of all 8 slots)."""
+        sizes = np.zeros(self.n, dtype=np.int32); tot = np.zeros(self.n, dtype=np.int32)
+        _ffi.check(_ffi.lib().bbx_alg_sizes(self._h, _ffi.ptr(sizes), _ffi.ptr(tot)))
+        nterms = np.zeros(max(int(sizes[k]), 1), dtype=np.int32)
+        coefs = np.zeros(max(int(tot[k]), 1), dtype=np.int32); exps = np.zeros((max(int(tot[k]), 1), NV), dtype=np.int32)
+        _ffi.check(_ffi.lib().bbx_alg_get(self._h, int(k), _ffi.ptr(nterms), _ffi.ptr(coefs), _ffi.ptr(exps), None))
+        out, at = [], 0
+        for g in range(int(sizes[k])):
+            out.append([(int(coefs[at + t]), tuple(int(x) for x in exps[at + t])) for t in range(int(nterms[g]))])
+            at += int(nterms[g])
+        return out
+
+
+def _nv(*polys):
+    return max([len(e) for f in polys for _, e in f] + [1])
+
+
+def _cut(f, n):
+    return [(c, e[:n]) for c, e in f]
+
+
+def spoly_many(pairs, device=0):
+    """[(f, g), ...] -> [spoly(f, g), ...], one launch."""
+    L = PolyLists([[f, g] for f, g in pairs], device)
+    L.binop("spoly", (0, 1))
+    return [_cut(L.get(k)[2], _nv(*pairs[k])) for k in range(len(pairs))]
+
+
+def spoly(f, g, lmf=None, lmg=None):
+    """The s-polynomial of f and g (buchberger.py:11-19; buchberger.cpp:18-21: both are divided by their lead coefficients)."""
+    return spoly_many([(f, g)])[0]
+
+
+def reduce_many(problems, device=0):
+    """[(g, F), ...] -> [(remainder, {'steps': s}), ...], one launch."""
+    L = PolyLists([list(F) + [g] for g, F in problems], device)
+    steps = L.reduce([(len(F), len(F)) for _, F in problems])
+    return [(_cut(L.get(k)[-1], _nv(g, *F)), {"steps": int(steps[k])}) for k, (g, F) in enumerate(problems)]
+
+
+def reduce(g, F, lmF=None):
+    """Remainder and stats when g is divided by the polynomials F, first divisor in list order (buchberger.py:22-67;
+    buchberger.cpp:24-49) -> (r, {'steps': successful reductions})."""
+    return reduce_many([(g, F)])[0]
+
+
+def update(G, P, f, strategy="gebauermoeller", lmG=None):
+    """The updated lists of polynomials and pairs when f is added to the basis G; G and P are modified, like the reference's
+    (buchberger.py:70-147; buchberger.cpp:52-99)."""
+    if strategy not in _ffi.ELIMINATION:
+        raise ValueError("unknown elimination strategy")
+    L = PolyLists([list(G) + [f]])
+    P[:] = L.update([list(P)], strategy)[0]
+    G.append(f)
+    return G, P
+
+
+def minimalize(G):
+    """A minimal Groebner basis from the Groebner basis G (buchberger.py:150-157; buchberger.cpp:102-111)."""
+    if not G:
+        return []
+    L = PolyLists([list(G)])
+    L.minimalize()
+    return [_cut(f, _nv(*G)) for f in L.get(0)]
+
+
+def interreduce(G):
+    """The reduced Groebner basis from the minimal Groebner basis G (buchberger.py:160-166; buchberger.cpp:114-122)."""
+    if not G:
+        return []
+    L = PolyLists([list(G)])
+    L.interreduce()
+    return [_cut(f, _nv(*G)) for f in L.get(0)]
+
+
+def buchberger(F, S=None, elimination="gebauermoeller", rewards="additions", sort_reducers=True, gamma=0.99, selection="degree",
+               sort_input=False, device=0):
+    """The reduced Groebner basis of the ideal generated by F by Buchberger's algorithm and its statistics
+    (buchberger.py:169-240 — Degree selection there; buchberger.cpp:125-266 for the others): the run is a device rollout
+    to completion, minimalize / interreduce of the final basis run on the device too.  S (a partially processed pair set)
+    is not supported: the environments start from the generators."""
+    if S is not None:
+        raise NotImplementedError("buchberger(F, S): start from the generators (S=None)")
+    if selection not in ("first", "degree", "normal", "sugar"):
+        raise ValueError("buchberger(): selection must be first, degree, normal or sugar (strategy_stats covers the others)")
+    F = [list(f) for f in F]
+    if not F:
+        return [], {"zero_reductions": 0, "nonzero_reductions": 0, "polynomial_additions": 0, "total_reward": 0.0, "discounted_return": 0.0}
+    env = VecLeadMonomialsEnv([F], batch=1, elimination=elimination, rewards=rewards, sort_input=sort_input, sort_reducers=sort_reducers,
+                              k=1, device=device)
+    env.reset()
+    ret = env.value(0, selection, gamma) if int(env.rows[0]) > 0 else 0.0     # (a rollout from a clone: the discounted return)
+    if int(env.rows[0]) > 0:
+        env.rollout(selection if selection != "random" else "random", 1 << 30, auto_reset=False)
+    st = env.stats()[0]
+    n = _nv(*F)
+    zero, steps, adds = int(st[3]), int(st[0]), int(st[1])
+    stats = {"zero_reductions": zero, "nonzero_reductions": steps - zero, "polynomial_additions": adds,
+             "total_reward": float(-adds if rewards == "additions" else -steps), "discounted_return": float(ret)}
+    L = PolyLists.from_envs(env, [0])                       # minimalize / interreduce of the final basis, device to device
+    L.minimalize(); L.interreduce()
+    return [_cut(f, n) for f in L.get(0)], stats
+
+
 def _grevlex_key(m):
     """sympy's grevlex monomial key (what R.order(m) returns in buchberger.py:428)."""
     return (sum(m), tuple(-x for x in reversed(m)))

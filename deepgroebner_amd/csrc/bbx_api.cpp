@@ -18,6 +18,7 @@
 #include "../../include/bbx.h"
 #include "bbx_common.h"
 #include "bbx_ideals.h"
+#include "bbx_host.h"
 
 extern "C" int bbx_launch_step(const BbxParams* p, int kind, int envs_per_block, hipStream_t stream);
 extern "C" int bbx_launch_clone(const char* src_recs, char* dst_recs, const BbxLayout* L, const int32_t* src, const int32_t* dst, int n,
@@ -39,44 +40,15 @@ extern "C" int bbx_launch_pmlp_act(const int32_t* obs, const int32_t* rows, int 
 namespace {
 
 thread_local std::string g_err;
-int fail(int code, const char* fmt, ...) {
+}  // namespace
+int bbx_host::fail(int code, const char* fmt, ...) {
   char buf[512];
   va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
   g_err = buf;
   return code;
 }
-#define HIPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(BBX_E_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); } while (0)
-
-uint32_t align16(uint32_t x) { return (x + 15u) & ~15u; }
-
-BbxLayout make_layout(int W, int maxG, int maxP, int arena, int maxT) {
-  BbxLayout L{};
-  L.W = W; L.maxG = maxG; L.maxP = maxP; L.arena = arena; L.maxT = maxT;
-  const uint32_t MW = 4u * W;
-  uint32_t o = sizeof(BbxHdr);
-  auto take = [&o](uint32_t bytes) { uint32_t at = o; o = align16(o + bytes); return at; };
-  L.off_lm = take(MW * maxG); L.off_slm = take(MW * maxG); L.off_lcm = take(MW * maxG);
-  L.off_am = take(MW * arena); L.off_hm = take(MW * 5u * maxT);
-  L.off_poff = take(4u * maxG); L.off_pairs = take(4u * maxP);
-  L.off_sidx = take(2u * maxG); L.off_plen = take(2u * maxG); L.off_psug = take(2u * maxG); L.off_pinv = take(2u * maxG);
-  L.off_ac = take(2u * arena); L.off_hc = take(2u * 5u * maxT); L.off_cp = take(maxG);
-  L.rec_bytes = (o + 255u) & ~255u;
-  return L;
-}
-
-// binomial class: no arena, fixed two-term polynomials (bbx_common.h)
-BbxLayout make_layout_binom(int W, int maxG, int maxP) {
-  BbxLayout L{};
-  L.W = W; L.maxG = maxG; L.maxP = maxP; L.arena = 0; L.maxT = 2; L.kind = 1;
-  const uint32_t MW = 4u * W;
-  uint32_t o = sizeof(BbxHdr);
-  auto take = [&o](uint32_t bytes) { uint32_t at = o; o = align16(o + bytes); return at; };
-  L.off_lm = take(MW * maxG); L.off_tm = take(MW * maxG); L.off_slm = take(MW * maxG); L.off_stm = take(MW * maxG);
-  L.off_lcm = take(MW * maxG); L.off_ginfo = take(8u * maxG); L.off_sinfo = take(8u * maxG);
-  L.off_pairs = take(4u * maxP); L.off_cp = take(maxG);
-  L.rec_bytes = (o + 255u) & ~255u;
-  return L;
-}
+namespace {
+using bbx_host::fail; using bbx_host::make_layout; using bbx_host::make_layout_binom;
 
 struct OutBuf {            // one contiguous device block so a step needs a single D2H copy
   double* rewards; int32_t* rows; uint8_t* dones;
@@ -1559,6 +1531,16 @@ int bbx_stats(bbx_batch* b, int64_t* out8) {
   return BBX_OK;
 }
 
+// (bbx_alg.cpp) where the records of a quiet batch live
+int bbx_internal_records(bbx_batch* b, const char** recs, BbxLayout* L, int* device, int* W, int* batch) {
+  if (!b) return fail(BBX_E_ARG, "null argument");
+  HIPCHK(hipSetDevice(b->device));
+  if (b->in_flight) { int rc = finish(b, b->last_stream); if (rc) return rc; }
+  HIPCHK(hipDeviceSynchronize());
+  *recs = b->d_recs; *L = b->L; *device = b->device; *W = b->W; *batch = b->B;
+  return BBX_OK;
+}
+
 int bbx_capacities(bbx_batch* b, int32_t* out5) {
   if (!b || !out5) return fail(BBX_E_ARG, "null argument");
   out5[0] = (int32_t)b->L.maxG; out5[1] = (int32_t)b->L.maxP; out5[2] = (int32_t)b->L.arena; out5[3] = (int32_t)b->L.maxT; out5[4] = b->grow_events;
@@ -1662,45 +1644,25 @@ int bbx_state_get(bbx_batch* b, int idx, int32_t* nterms, int32_t* coefs, int32_
   return BBX_OK;
 }
 
-// interreduce(minimalize(G)) of environment idx's current basis (what buchberger() returns, buchberger.cpp:265).
-// Two-call protocol like bbx_state_get: sizes first (nterms == NULL), then the data.
+// interreduce(minimalize(G)) of environment idx's current basis (what buchberger() returns, buchberger.cpp:265), computed on
+// the device (bbx_alg_from_envs + bbx_alg_minimalize + bbx_alg_interreduce).  Two-call protocol like bbx_state_get: sizes
+// first (nterms == NULL), then the data.
 int bbx_reduced_basis(bbx_batch* b, int idx, int32_t* basis_size, int32_t* nterms_total, int32_t* nterms, int32_t* coefs, int32_t* exps) {
   if (!b || idx < 0 || idx >= b->B) return fail(BBX_E_ARG, "bad environment index");
-  int32_t nG = 0, nP = 0, nT = 0;
-  int rc = bbx_state_sizes(b, idx, &nG, &nP, &nT);
-  if (rc) return rc;
-  std::vector<int32_t> nt(std::max(nG, 1)), cf(std::max(nT, 1)), ex((size_t)std::max(nT, 1) * bbx::kN);
-  rc = bbx_state_get(b, idx, nt.data(), cf.data(), ex.data(), nullptr, nullptr);
-  if (rc) return rc;
-  std::vector<bbx::HPoly> G;
-  size_t at = 0;
-  for (int g = 0; g < nG; g++) {
-    bbx::HPoly f;
-    for (int t = 0; t < nt[g]; t++, at++) {
-      bbx::HTerm h; h.c = cf[at]; h.deg = 0;
-      for (int v = 0; v < bbx::kN; v++) { h.e[v] = ex[at * bbx::kN + v]; h.deg += h.e[v]; }
-      f.t.push_back(h);
-    }
-    f.sugar = f.t.empty() ? 0 : f.t[0].deg;
-    G.push_back(f);
+  bbx_alg* a = nullptr;
+  const int32_t e = idx;
+  int rc = bbx_alg_from_envs(b, 1, &e, &a);                 // the basis as a device-resident list, then the two kernels
+  if (!rc) rc = bbx_alg_minimalize(a);
+  if (!rc) rc = bbx_alg_interreduce(a);
+  int32_t n = 0, tot = 0;
+  if (!rc) rc = bbx_alg_sizes(a, &n, &tot);
+  if (!rc) {
+    if (basis_size) *basis_size = n;
+    if (nterms_total) *nterms_total = tot;
+    if (nterms) rc = bbx_alg_get(a, 0, nterms, coefs, exps, nullptr);
   }
-  std::vector<bbx::HPoly> R = bbx::interreduce(bbx::minimalize(G));
-  int tot = 0;
-  for (auto& f : R) tot += (int)f.t.size();
-  if (basis_size) *basis_size = (int)R.size();
-  if (nterms_total) *nterms_total = tot;
-  if (nterms) {
-    at = 0;
-    for (size_t g = 0; g < R.size(); g++) {
-      nterms[g] = (int)R[g].t.size();
-      for (auto& t : R[g].t) {
-        if (coefs) coefs[at] = t.c;
-        if (exps) for (int v = 0; v < bbx::kN; v++) exps[at * bbx::kN + v] = t.e[v];
-        at++;
-      }
-    }
-  }
-  return BBX_OK;
+  bbx_alg_destroy(a);
+  return rc;
 }
 
 int bbx_trace_enable(bbx_batch* b, int capacity_steps) {

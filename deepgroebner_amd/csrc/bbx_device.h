@@ -543,6 +543,104 @@ __device__ __forceinline__ int gen_poisson(uint32_t& x, double lm_thr) {
   return k - 1;
 }
 
+// ------------------------------------------------------------------ std::sort of basis indices by lead monomial
+// libstdc++ 11's std::sort (bits/stl_algo.h: introsort = median-of-three quicksort with a depth limit of 2 log2 n and a
+// heapsort fallback, segments of <= 16 elements left to a final insertion sort), restated on an index array and run by ONE
+// lane: where the reference sorts polynomials by lead monomial (buchberger.cpp:102-104 minimalize, :157-158 buchberger)
+// the order of elements with EQUAL lead monomials is whatever that algorithm leaves, and results depend on it.
+// less(a, b) = LM(G[a]) < LM(G[b]).
+template <int W> struct SortCtx {
+  const Mono<W>* lm; uint16_t* v;
+  __device__ __forceinline__ bool less(int a, int b) const { return m_gt(lm[b], lm[a]); }
+};
+template <int W> __device__ void ss_unguarded_linear_insert(const SortCtx<W>& c, int last) {
+  const int val = c.v[last];
+  int next = last - 1;
+  while (c.less(val, c.v[next])) { c.v[last] = c.v[next]; last = next; next--; }
+  c.v[last] = (uint16_t)val;
+}
+template <int W> __device__ void ss_insertion_sort(const SortCtx<W>& c, int first, int last) {
+  if (first == last) return;
+  for (int i = first + 1; i != last; i++) {
+    if (c.less(c.v[i], c.v[first])) {
+      const int val = c.v[i];
+      for (int j = i; j > first; j--) c.v[j] = c.v[j - 1];               // move_backward(first, i, i + 1)
+      c.v[first] = (uint16_t)val;
+    } else ss_unguarded_linear_insert<W>(c, i);
+  }
+}
+template <int W> __device__ void ss_adjust_heap(const SortCtx<W>& c, int first, int hole, int len, int value) {
+  const int top = hole;
+  int child = hole;
+  while (child < (len - 1) / 2) {
+    child = 2 * (child + 1);
+    if (c.less(c.v[first + child], c.v[first + child - 1])) child--;
+    c.v[first + hole] = c.v[first + child];
+    hole = child;
+  }
+  if ((len & 1) == 0 && child == (len - 2) / 2) {
+    child = 2 * (child + 1);
+    c.v[first + hole] = c.v[first + child - 1];
+    hole = child - 1;
+  }
+  int parent = (hole - 1) / 2;                                            // __push_heap
+  while (hole > top && c.less(c.v[first + parent], value)) {
+    c.v[first + hole] = c.v[first + parent];
+    hole = parent;
+    parent = (hole - 1) / 2;
+  }
+  c.v[first + hole] = (uint16_t)value;
+}
+template <int W> __device__ void ss_heapsort(const SortCtx<W>& c, int first, int last) {   // __partial_sort(first, last, last)
+  const int len = last - first;
+  if (len >= 2)
+    for (int parent = (len - 2) / 2;; parent--) { ss_adjust_heap<W>(c, first, parent, len, c.v[first + parent]); if (parent == 0) break; }
+  while (last - first > 1) {
+    --last;
+    const int value = c.v[last];
+    c.v[last] = c.v[first];
+    ss_adjust_heap<W>(c, first, 0, last - first, value);
+  }
+}
+template <int W> __device__ void ss_std_sort(const SortCtx<W>& c, int n) {
+  if (n <= 0) return;
+  int lg = 0;
+  for (int t = n; t > 1; t >>= 1) lg++;
+  // __introsort_loop: recursion on the right part, iteration on the left — the segments are independent, so an explicit
+  // stack serves (at most one entry per level: the depth limit bounds it)
+  int sf[48], sl[48], sd[48], sp = 0;
+  sf[0] = 0; sl[0] = n; sd[0] = 2 * lg; sp = 1;
+  while (sp > 0) {
+    sp--;
+    int first = sf[sp], last = sl[sp], depth = sd[sp];
+    while (last - first > 16) {
+      if (depth == 0) { ss_heapsort<W>(c, first, last); break; }
+      --depth;
+      const int mid = first + (last - first) / 2, a = first + 1, b = mid, cc = last - 1;
+      auto swp = [&](int x, int y) { const uint16_t t = c.v[x]; c.v[x] = c.v[y]; c.v[y] = t; };
+      if (c.less(c.v[a], c.v[b])) {                                       // __move_median_to_first(first, first + 1, mid, last - 1)
+        if (c.less(c.v[b], c.v[cc])) swp(first, b); else if (c.less(c.v[a], c.v[cc])) swp(first, cc); else swp(first, a);
+      } else if (c.less(c.v[a], c.v[cc])) swp(first, a);
+      else if (c.less(c.v[b], c.v[cc])) swp(first, cc);
+      else swp(first, b);
+      int lo = first + 1, hi = last;                                      // __unguarded_partition(first + 1, last, pivot = first)
+      for (;;) {
+        while (c.less(c.v[lo], c.v[first])) lo++;
+        --hi;
+        while (c.less(c.v[first], c.v[hi])) --hi;
+        if (!(lo < hi)) break;
+        swp(lo, hi);
+        lo++;
+      }
+      if (sp < 48) { sf[sp] = lo; sl[sp] = last; sd[sp] = depth; sp++; }
+      last = lo;
+    }
+  }
+  if (n > 16) {                                                            // __final_insertion_sort
+    ss_insertion_sort<W>(c, 0, 16);
+    for (int i = 16; i != n; i++) ss_unguarded_linear_insert<W>(c, i);
+  } else ss_insertion_sort<W>(c, 0, n);
+}
 // ------------------------------------------------------------------ update()   buchberger.cpp:52-99
 // Adds the polynomial whose lead monomial is lmf as G[m] (the caller has already stored its terms and
 // metadata) and updates the pair set.  Returns false on capacity overflow.

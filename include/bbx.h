@@ -264,7 +264,7 @@ int bbx_state_sizes(bbx_batch* b, int idx, int32_t* basis_size, int32_t* npairs,
  * order[r] = index into G of the r-th reducer */
 int bbx_state_get(bbx_batch* b, int idx, int32_t* nterms, int32_t* coefs, int32_t* exps, int32_t* pairs, int32_t* order);
 /* interreduce(minimalize(G)) of environment idx's basis — the reduced Groebner basis buchberger() returns
- * (buchberger.cpp:102-122, 265) once the environment's pair set is empty; computed on the host.  Call with
+ * (buchberger.cpp:102-122, 265) once the environment's pair set is empty; computed on the device (bbx_alg_*).  Call with
  * nterms == NULL for the sizes, then with buffers (nterms[basis_size], coefs/exps[nterms_total(*8)]). */
 int bbx_reduced_basis(bbx_batch* b, int idx, int32_t* basis_size, int32_t* nterms_total, int32_t* nterms, int32_t* coefs, int32_t* exps);
 int bbx_trace_enable(bbx_batch* b, int capacity_steps);  /* 0 disables */
@@ -291,6 +291,35 @@ int bbx_gen_get(const bbx_gen* g, int32_t* nterms, int32_t* coefs, int32_t* exps
 int bbx_parse_ideal(const char* text, int32_t cap_polys, int32_t cap_terms, int32_t* npolys, int32_t* nterms_total,
                     int32_t* nterms, int32_t* coefs, int32_t* exps);
 int bbx_format_ideal(int npolys, const int32_t* nterms, const int32_t* coefs, const int32_t* exps, char* out, int cap);
+
+/* ---- the reference's free functions on device-resident lists of polynomials -----------------------------------------
+ * spoly / reduce / update (buchberger.cpp:18-99; buchberger.py:11-147), minimalize / interreduce (buchberger.cpp:102-122;
+ * buchberger.py:150-166) and Polynomial +, -, * (polynomials.cpp:148-210), batched: a bbx_alg holds `nlists` independent
+ * std::vector<Polynomial>s in HBM (flat input like bbx_create_ideals: npolys[nlists], nterms per polynomial, coefs, exps
+ * with 8 ints per term; a polynomial may have 0 terms), every call runs one kernel over all lists (one wavefront each) and
+ *   - binop / reduce APPEND their result to every list (G.push_back): read it back with bbx_alg_sizes + bbx_alg_get;
+ *   - update treats the LAST element of every list as f and the elements before it as G, and rewrites the pair sets;
+ *   - minimalize / interreduce REPLACE every list by the result.
+ * Records grow on demand.  GF(32003), grevlex, up to 8 variables, polynomials of at most 65535 terms. */
+typedef struct bbx_alg bbx_alg;
+int bbx_alg_create(int device, int nlists, const int32_t* npolys, const int32_t* nterms, const int32_t* coefs, const int32_t* exps, bbx_alg** out);
+void bbx_alg_destroy(bbx_alg* a);
+/* the bases of n environments of a batch (envs == NULL: environments 0..n-1) as n polynomial lists, copied on the device:
+ * with bbx_alg_minimalize + bbx_alg_interreduce the reduced Groebner bases of a whole batch of finished runs
+ * (scripts/make_strat.cpp of the reference prints their sizes) without the polynomials visiting the host */
+int bbx_alg_from_envs(bbx_batch* b, int n, const int32_t* envs, bbx_alg** out);
+/* op: 0 = f + g, 1 = f - g, 2 = f * g, 3 = spoly(f, g); ij[nlists][2] = the elements f, g of every list */
+int bbx_alg_binop(bbx_alg* a, int op, const int32_t* ij);
+/* reduce(g, F) (buchberger.cpp:24-49): dividend_and_ndivisors[nlists][2] = {index of g, n: F = the list's elements 0..n-1 in list
+ * order}; the remainder is appended, steps[nlists] (may be NULL) = successful reductions */
+int bbx_alg_reduce(bbx_alg* a, const int32_t* dividend_and_ndivisors, int32_t* steps);
+/* update(G, P, f, elimination) (buchberger.cpp:52-99): npairs[nlists] + concatenated pairs (i, j) in; npairs_out[nlists] +
+ * pairs_out (room for pairs_cap pairs; may be NULL) = the new pair sets in the reference's order */
+int bbx_alg_update(bbx_alg* a, int elimination, const int32_t* npairs, const int32_t* pairs, int32_t* npairs_out, int32_t* pairs_out, int pairs_cap);
+int bbx_alg_minimalize(bbx_alg* a);
+int bbx_alg_interreduce(bbx_alg* a);
+int bbx_alg_sizes(bbx_alg* a, int32_t* npolys, int32_t* nterms_total);          /* per list */
+int bbx_alg_get(bbx_alg* a, int list, int32_t* nterms, int32_t* coefs, int32_t* exps, int32_t* sugars);   /* sugars may be NULL */
 
 uint32_t bbx_agent_hash(uint32_t seed, uint32_t t);
 uint32_t bbx_agent_action(uint32_t seed, uint32_t t, uint32_t rows);   /* (hash * rows) >> 32 */
