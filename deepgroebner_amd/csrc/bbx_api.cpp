@@ -131,6 +131,7 @@ struct bbx_batch {
   BbxParams ps_p{};                   // the parameters of the call that began it (later calls must match to join)
   int ps_sessions = 0, ps_joined = 0, ps_kernels = 0; // statistics: sessions begun, calls that joined a running one, kernels
   std::mt19937_64 value_rng;          // seeds of value("random") / value("sample") rollouts when the caller gives none
+  bool gen_to_wide = false;           // general class with <= 16-byte monomials: long-polynomial environments continue in the wide class
   bool no_growth = false;             // bbx_caps.no_growth: the configured capacities are hard limits (BBX_E_CAPACITY)
   int grow_events = 0;                // times the records were enlarged (bbx_capacities)
   bbx_batch() = default;
@@ -316,6 +317,10 @@ int enqueue(bbx_batch* b, const BbxParams& p0, bool resume, hipStream_t stream) 
   else if (p.ctl) { kinds[nk++] = 3; kinds[nk++] = 0; }   // a kernel of a persistent session, and behind it the HBM-resident
                                                       // class for the environments that outgrew the register/LDS class
   else if (b->wide) kinds[nk++] = 4;
+  else if (b->gen_to_wide) {                          // general class, <= 7 variables: wave-per-environment kernel, and behind it the
+    kinds[nk++] = 0; kinds[nk++] = 4;                 // workgroup-per-environment kernel for the environments whose polynomials got long
+    p.spill_terms = 384;
+  }
   else {   // the hand-tuned kernel knows the external / random / degree / first agents; the others take the class kernel
     const bool pol_hbm_only = p.policy && p.policy->rollout == 2;     // a policy rollout outside the register/LDS class
     if (b->staged && !pol_hbm_only) kinds[nk++] = (b->fast && p.agent <= BBX_AGENT_FIRST) ? 3 : 1;
@@ -348,7 +353,7 @@ int enqueue(bbx_batch* b, const BbxParams& p0, bool resume, hipStream_t stream) 
       HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
       HIPCHK(hipEventRecord(e0, stream));
     }
-    int lrc = bbx_launch_step(&p, kinds[i], kinds[i] == 4 ? b->wide : b->envs_per_block, stream);
+    int lrc = bbx_launch_step(&p, kinds[i], kinds[i] == 4 ? (b->wide ? b->wide : 8) : b->envs_per_block, stream);
     if (lrc) return fail(BBX_E_DEVICE, "kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
     if (timed) { HIPCHK(hipEventRecord(e1, stream)); b->ev_open.push_back({e0, e1}); }
   }
@@ -756,6 +761,9 @@ int create_common(std::unique_ptr<bbx::IdealGen> proto, int nvars_obs, int elimi
     // the hand-tuned kernel covers exactly the reference C++ class's fixed options
     b->fast = b->binom && elimination == BBX_GEBAUERMOELLER && sort_reducers && lg <= 128 && !getenv("BBX_NO_FAST");
   }
+  // non-binomial random ideals in <= 7 variables: wave-per-environment kernel, long-polynomial environments continue one
+  // workgroup each (bbx_wide.h) behind it
+  b->gen_to_wide = !b->binom && !b->wide && !b->staged && !b->fixed && !list && b->W <= 4 && c.wide_waves >= 0 && !getenv("BBX_NO_WIDE");
   if (c.max_basis > 65535 || c.max_poly_terms > (1 << 22) || c.max_basis < 2 || c.max_pairs < 2 || c.max_poly_terms < 4 || c.queue_slots < 1)
     return fail(BBX_E_ARG, "capacities out of range");
   b->L = b->binom ? make_layout_binom(b->W, c.max_basis, c.max_pairs)
@@ -902,7 +910,7 @@ int bbx_copy(const bbx_batch* s, bbx_batch** out) {
   b->elim = s->elim; b->rewards = s->rewards; b->sort_input = s->sort_input; b->sort_reducers = s->sort_reducers;
   b->fixed = s->fixed; b->listed = s->listed; b->binom = s->binom; b->L = s->L; b->LL = s->LL; b->slot_words = s->slot_words; b->nslots = s->nslots;
   b->h_q = s->h_q; b->h_tail = s->h_tail; b->h_head = s->h_head; b->q_dirty = true;
-  b->no_growth = s->no_growth; b->value_rng = s->value_rng;
+  b->no_growth = s->no_growth; b->value_rng = s->value_rng; b->gen_to_wide = s->gen_to_wide;
   b->wide = s->wide; b->wide_terms = s->wide_terms; b->accounting = s->accounting; b->staged = s->staged; b->fast = s->fast; b->envs_per_block = s->envs_per_block;
   if (s->device_gen) {
     HIPCHK(hipMalloc((void**)&b->d_gen, s->gen_words * sizeof(uint32_t)));
@@ -1437,7 +1445,9 @@ int value_rollouts(bbx_batch* b, const std::vector<int32_t>& src, int agent, con
       const bool vfast = b->fast && b->staged && (agent == BBX_AGENT_DEGREE || agent == BBX_AGENT_FIRST || agent == BBX_AGENT_STDRANDOM || agent == BBX_AGENT_HASH);
       lrc = 0;
       if (vfast) lrc = bbx_launch_step(&p, 3, b->envs_per_block, 0);
+      if (b->gen_to_wide) p.spill_terms = 384;
       if (!lrc) { if (vfast) { p.set_budget = 0; p.pass = 1; } lrc = bbx_launch_step(&p, 0, b->envs_per_block, 0); }
+      if (!lrc && b->gen_to_wide) { p.set_budget = 0; p.pass = 1; p.spill_terms = 0; lrc = bbx_launch_step(&p, 4, 8, 0); }
     }
     if (lrc) return fail(BBX_E_DEVICE, "kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
     lrc = bbx_launch_value_collect(b->d_vrecs, b->L.rec_bytes, n, b->d_vvals, 0);

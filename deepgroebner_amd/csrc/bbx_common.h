@@ -177,6 +177,8 @@ struct BbxParams {
   unsigned long long* ctl_stats;   // statistics: steps the closing launches had to take (null: not counted)
   int32_t sess_target;      // != 0: every environment owes sess_target - BbxHdr.sess_done steps (later slices of a session, and
                             // the launch of the HBM-resident class behind them)
+  int32_t spill_terms;      // general class, != 0: a merge of more than this many terms hands the environment (untouched: the
+                            // step is restartable) to the wide class — one workgroup per environment — launched right behind
   uint32_t slice_ticks;     // persistent kernels: leave after this many ticks of the 100 MHz clock (0: no limit)
   int32_t wide_hc, wide_fc, wide_rc, wide_sc;   // wide class: LDS capacities (terms) of the polynomial being reduced, the
                                        // reducer-tail window, the reducer table and the accumulator; wide_hc == 0: chosen by the launcher

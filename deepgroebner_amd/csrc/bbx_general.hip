@@ -117,6 +117,7 @@ __device__ __forceinline__ void step_body(const BbxParams& p, char* smem, unsign
       int si = uni((int)e.psug[gi]) + (int)m_deg(A.shift), sj = uni((int)e.psug[gj]) + (int)m_deg(Bv.shift);
       hsug = uni(si > sj ? si : sj);
       if (hsug > 65535) { status = BBX_ST_DEG_OVERFLOW; break; }
+      if (!STAGED && p.spill_terms && A.n + Bv.n > p.spill_terms) { status = BBX_ST_SPILL; break; }   // long polynomials: a workgroup's job
       if (A.n + Bv.n > 2 * maxT) { status = BBX_ST_POLY_TOO_LONG; break; }
       GSTAMP(0);                                   // 0: loop top, agent, pair removal
       const bool big = mlds && A.n > 0 && Bv.n > 0 && A.n + Bv.n > 64;
@@ -150,6 +151,7 @@ __device__ __forceinline__ void step_body(const BbxParams& p, char* smem, unsign
         int fs = uni((int)e.psug[g]) + (int)m_deg(Bv.shift);
         hsug = uni(fs > hsug ? fs : hsug);
         if (hsug > 65535) { status = BBX_ST_DEG_OVERFLOW; overflow = true; break; }
+        if (!STAGED && p.spill_terms && A.n + Bv.n > p.spill_terms) { status = BBX_ST_SPILL; overflow = true; break; }
         if (A.n + Bv.n > 2 * maxT) { status = BBX_ST_POLY_TOO_LONG; overflow = true; break; }
         Mono<W>* nm = (hm == hm0) ? hm1 : hm0; uint16_t* nc = (hc == hc0) ? hc1 : hc0;
         GSTAMP(3);                                // 3: reducer fetch / setup
@@ -222,7 +224,7 @@ __device__ __forceinline__ void step_body(const BbxParams& p, char* smem, unsign
     }
   }
 
-  if (bbx_st_capacity(status)) std_rng = rng_mark;   // the step did not happen: its draw is taken again
+  if (bbx_st_capacity(status) || status == BBX_ST_SPILL) std_rng = rng_mark;   // the step did not happen: its draw is taken again
   if (PROF && prof_out && lane == 0) for (int i = 0; i < 10; i++) prof_out[(size_t)env * 10 + i] = ps[i];
   // an environment that must continue in the follow-up pass reports nothing yet
   const bool handoff = status == BBX_ST_SPILL;
