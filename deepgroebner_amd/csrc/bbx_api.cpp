@@ -129,6 +129,7 @@ struct bbx_batch {
   hipEvent_t ps_ev = nullptr;
   long long ps_target = 0;            // steps issued since the session began
   BbxParams ps_p{};                   // the parameters of the call that began it (later calls must match to join)
+  BbxPolicy ps_pol{};                 // ... and its policy arguments (ps_p.policy points here), when it is a session of policy steps
   int ps_sessions = 0, ps_joined = 0, ps_kernels = 0; // statistics: sessions begun, calls that joined a running one, kernels
   std::mt19937_64 value_rng;          // seeds of value("random") / value("sample") rollouts when the caller gives none
   bool gen_to_wide = false;           // general class with <= 16-byte monomials: long-polynomial environments continue in the wide class
@@ -638,11 +639,16 @@ int launch(bbx_batch* b, BbxParams& p, hipStream_t stream, bool obs_external = f
   if (rc) return rc;
   // persistent sessions: asynchronous rollouts with a built-in agent on the register/LDS-resident class, lean and untraced,
   // ideals drawn on the device (nothing for the host to do between launches), every wave of the batch resident at once
-  const bool ps = b->ps_enabled && device_async && b->fast && b->staged && b->device_gen && !b->accounting && !p.policy && p.nsteps >= 1 &&
-                  p.auto_reset && p.obs_fill == 0 && (p.agent == BBX_AGENT_HASH || p.agent == BBX_AGENT_DEGREE || p.agent == BBX_AGENT_FIRST) &&
+  const bool pol_steps = p.policy && p.policy->rollout == 1 && p.policy->post_obs;   // bbx_policy_step_device calls
+  const bool ps = b->ps_enabled && device_async && b->fast && b->staged && b->device_gen && !b->accounting && p.nsteps >= 1 && p.auto_reset &&
+                  (pol_steps || (!p.policy && p.obs_fill == 0 && (p.agent == BBX_AGENT_HASH || p.agent == BBX_AGENT_DEGREE || p.agent == BBX_AGENT_FIRST))) &&
                   !(b->d_trace && b->trace_cap >= 1) && !b->timing && b->B <= 4096 && p.set_budget == 1;
   if (b->ps_active) {
-    if (ps && session_same_call(b->ps_p, p) && b->ps_target + p.nsteps < (1ll << 30)) {
+    const BbxPolicy* a = b->ps_p.policy; const BbxPolicy* c = p.policy;
+    const bool same_policy = (!a && !c) || (a && c && pol_steps && a->wp == c->wp && a->hidden == c->hidden && a->actions == c->actions &&
+                                            a->logprobs == c->logprobs && a->rewards_t == c->rewards_t && a->dones_t == c->dones_t && a->rows_t == c->rows_t &&
+                                            c->u == a->u + (size_t)b->ps_target * (size_t)b->B);
+    if (ps && same_policy && session_same_call(b->ps_p, p) && b->ps_target + p.nsteps < (1ll << 30)) {
       b->ps_target += p.nsteps;                        // the waves see the new total the next time they look
       rc = ps_write_ctl(b, false);
       if (rc) return rc;
@@ -657,6 +663,7 @@ int launch(bbx_batch* b, BbxParams& p, hipStream_t stream, bool obs_external = f
   }
   if (ps) {
     b->ps_p = p; b->ps_p.ctl = nullptr;
+    if (p.policy) { b->ps_pol = *p.policy; b->ps_p.policy = &b->ps_pol; }
     b->ps_target = p.nsteps; b->ps_active = true; b->ps_sessions++;
     rc = ps_write_ctl(b, false);
     if (rc) return rc;
@@ -1242,7 +1249,18 @@ int bbx_policy_step_device(bbx_batch* b, const float* d_prepared, int hidden, co
     return step_device(b, d_actions, d_rewards, d_dones, d_rows, d_obs, obs_rows, obs_fill, stream, 1);
   }
   HIPCHK(hipSetDevice(b->device));
-  BbxPolicy pol{d_prepared, hidden, d_u, d_actions, d_logprobs, 0, nullptr, nullptr, nullptr, 0};
+  if (b->ps_enabled && b->nvars == 3 && b->k == 2 && b->device_gen) {
+    // persistent sessions: the call joins (or begins) a session whose kernel has the policy inside its step loop — the
+    // uniforms of consecutive calls must then be consecutive [B] slices of one array (what a rollout loop that draws its
+    // random numbers a chunk of steps at a time passes), every other argument the same from call to call
+    BbxPolicy spol{d_prepared, hidden, d_u, d_actions, d_logprobs, 1, d_rewards, d_dones, d_rows, 0, 0, 1};
+    BbxParams sp; fill_params(b, &sp);
+    sp.nsteps = 1; sp.set_budget = 1; sp.agent = BBX_AGENT_EXTERNAL; sp.auto_reset = 1;
+    sp.obs = d_obs; sp.obs_rows = obs_rows; sp.obs_fill = obs_fill; sp.trace = nullptr;
+    sp.policy = &spol;
+    return launch(b, sp, (hipStream_t)stream, true, true);
+  }
+  BbxPolicy pol{d_prepared, hidden, d_u, d_actions, d_logprobs, 0, nullptr, nullptr, nullptr, 0, 0, 0};
   BbxParams p; fill_params(b, &p);
   p.nsteps = 1; p.set_budget = 1; p.agent = BBX_AGENT_EXTERNAL; p.auto_reset = 1; p.actions = d_actions;   // (the follow-up pass reads them)
   p.rewards = d_rewards; p.dones = d_dones; p.rows = d_rows; p.obs = d_obs; p.obs_rows = obs_rows; p.obs_fill = obs_fill;
@@ -1269,7 +1287,7 @@ int bbx_policy_rollout_device(bbx_batch* b, const float* d_prepared, int hidden,
   if (b->d_trace && b->trace_cap >= 1) return fail(BBX_E_UNSUPPORTED, "policy rollouts are not traced");
   if (d_obs && obs_step_stride != 0 && obs_step_stride < (long long)b->B * obs_rows * cols) return fail(BBX_E_ARG, "obs_step_stride smaller than one block");
   HIPCHK(hipSetDevice(b->device));
-  BbxPolicy pol{d_prepared, hidden, d_u, d_actions, d_logprobs, 1, d_rewards, d_dones, d_rows, obs_step_stride};
+  BbxPolicy pol{d_prepared, hidden, d_u, d_actions, d_logprobs, 1, d_rewards, d_dones, d_rows, obs_step_stride, b->B, 0};
   BbxParams p; fill_params(b, &p);
   p.nsteps = nsteps; p.set_budget = 1; p.agent = BBX_AGENT_EXTERNAL; p.auto_reset = 1;
   p.obs = d_obs; p.obs_rows = obs_rows; p.obs_fill = 0;

@@ -369,11 +369,13 @@ __device__ __forceinline__ void binom_body(const BbxParams& p, char* smem, const
     int action;
     int pol_tt = 0;
     if constexpr (POL > 0) {
-      pol_tt = uni(p.nsteps - budget);                       // (a continuation: the budget carries on from the first pass)
+      pol_tt = uni((p.sess_target ? p.sess_target : p.nsteps) - budget);   // (a continuation: the budget carries on from the first pass;
+                                                                            // behind a session's kernel: what is owed of the session's total)
       const size_t tb = (size_t)pol_tt * (size_t)p.B + (size_t)env;
       const float uu = pol->u[tb];
-      if (p.obs) { bin_obs<W, false>(e, p, env, nP, true, false, nullptr, (size_t)pol_tt * (size_t)pol->obs_tstride); obs_trunc |= nP > p.obs_rows ? 1 : 0; }
-      if (lane == 0 && pol->rows_t) pol->rows_t[tb] = nP;
+      const bool pre_obs = pol->post_obs == 0;
+      if (p.obs && pre_obs) { bin_obs<W, false>(e, p, env, nP, true, false, nullptr, (size_t)pol_tt * (size_t)pol->obs_tstride); obs_trunc |= nP > p.obs_rows ? 1 : 0; }
+      if (lane == 0 && pol->rows_t && pre_obs) pol->rows_t[tb] = nP;
       int n = nP < PMLP_MAXROWS ? nP : PMLP_MAXROWS;            // (rows beyond what the policy can score: reported, like rows
       obs_trunc |= nP > PMLP_MAXROWS ? 1 : 0;                    // beyond the caller's block — bbx_sync returns BBX_E_CAPACITY)
       if (p.obs) n = n < p.obs_rows ? n : p.obs_rows;
@@ -408,7 +410,7 @@ __device__ __forceinline__ void binom_body(const BbxParams& p, char* smem, const
         if (plk == 0 && r < n) lg[r] = logit + b2;
       }
       wave_sync();
-      action = pmlp_sample(lg, n, env, uu, pol->actions + (size_t)pol_tt * (size_t)p.B, pol->logprobs + (size_t)pol_tt * (size_t)p.B);
+      action = pmlp_sample(lg, n, env, uu, pol->actions + (size_t)pol_tt * (size_t)pol->stride_out, pol->logprobs + (size_t)pol_tt * (size_t)pol->stride_out);
     } else
     if (p.agent == BBX_AGENT_EXTERNAL) action = p.actions[env];
     else if (p.agent == BBX_AGENT_HASH) action = (int)bbx_agent_action32(agent_seed, (uint32_t)t_agent, (uint32_t)nP);
@@ -545,10 +547,12 @@ __device__ __forceinline__ void binom_body(const BbxParams& p, char* smem, const
     BSTAMP(5);
     if (POL == 0 && p.obs_every_step && p.obs) { bin_obs<W, false>(e, p, env, nP, true, false, peel_lds); obs_trunc |= nP > p.obs_rows ? 1 : 0; }
     if constexpr (POL > 0) {
+      if (pol->post_obs && p.obs) { bin_obs<W, false>(e, p, env, nP, true, false, nullptr); obs_trunc |= nP > p.obs_rows ? 1 : 0; }
       if (lane == 0) {
-        const size_t tb = (size_t)pol_tt * (size_t)p.B + (size_t)env;
+        const size_t tb = (size_t)pol_tt * (size_t)pol->stride_out + (size_t)env;
         if (pol->rewards_t) pol->rewards_t[tb] = reward;
         if (pol->dones_t) pol->dones_t[tb] = done ? 1 : 0;
+        if (pol->post_obs && pol->rows_t) pol->rows_t[env] = nP;
       }
     }
     BSTAMP(6);

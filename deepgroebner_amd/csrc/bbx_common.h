@@ -134,6 +134,10 @@ struct BbxPolicy {
   // the policy saw at step t goes to obs + t * obs_tstride (0: one block, overwritten every step)
   int32_t rollout;                     // 0: per-step call; 1: rollout, register/LDS-resident kernel first; 2: rollout, HBM-resident kernel only
   double* rewards_t; uint8_t* dones_t; int32_t* rows_t; long long obs_tstride;
+  // calls of bbx_policy_step_device served by a persistent session: u is [steps][B] (call t reads slice t), every other
+  // array is the [B] array of the calls, rewritten at each step (stride_out = 0), and the observation block and row
+  // counts describe the state AFTER the step, as that call leaves them (post_obs = 1).  Rollouts: stride_out = B, post_obs = 0.
+  int32_t stride_out, post_obs;
 };
 struct BbxParams {
   char* recs;

@@ -170,6 +170,8 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem, in
   if (p.set_budget) { budget = bbx_st_capacity(status) ? budget + p.nsteps : p.nsteps; rollout_pos = 0; done_last = 0; }   // (bbx_common.h: bbx_st_capacity)
   if (p.sess_target) budget = p.sess_target - uni(ghdr->sess_done);   // later kernels of a persistent session: what is still owed
   const uint32_t t_begin = PERSIST ? (uint32_t)__builtin_amdgcn_s_memrealtime() : 0u;
+  int pol_t0 = 0;                                      // POL + PERSIST: agent step counter minus session step, fixed for the kernel
+  if (POL > 0 && PERSIST) { int vz_; asm volatile("v_mov_b32 %0, 0" : "=v"(vz_)); pol_t0 = vz_ + (t_agent - (p.set_budget ? 0 : uni(ghdr->sess_done))); }
   if (p.pass == 1 && !(status == BBX_ST_OK && (need_reset || (budget > 0 && nP > 0)))) return;
 
   // HBM record arrays (binomial layout: every array 16-B aligned, capacities hbmG / maxP); the addresses are only
@@ -547,11 +549,14 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem, in
     int pol_tt = 0;
     if constexpr (POL > 0) {
       const FColdPolicy pol = f_cold_policy();
-      pol_tt = uni(p.nsteps - budget);                       // step of this launch (the budget was set to nsteps)
+      // step of the rollout (the budget was set to nsteps; closing launches of a session: what is owed of its total), or of
+      // the session (PERSIST: the agent's step counter against what it was when the session began)
+      pol_tt = PERSIST ? uni(t_agent - pol_t0) : uni((p.sess_target ? p.sess_target : p.nsteps) - budget);
       const size_t tb = (size_t)pol_tt * (size_t)p.B + (size_t)env;
       const float uu = pol->u[tb];                           // (requested before the observation goes out)
-      if (p.obs) { o3_toff = (size_t)pol_tt * (size_t)pol->obs_tstride; write_obs32(); obs_trunc |= nP > p.obs_rows ? 1 : 0; }
-      if (lane == 0 && pol->rows_t) pol->rows_t[tb] = nP;
+      const bool pre_obs = pol->post_obs == 0;
+      if (p.obs && pre_obs) { o3_toff = (size_t)pol_tt * (size_t)pol->obs_tstride; write_obs32(); obs_trunc |= nP > p.obs_rows ? 1 : 0; }
+      if (lane == 0 && pol->rows_t && pre_obs) pol->rows_t[tb] = nP;
       const PolW wp = pol_w;
       const int plr = lane & 31, plk = lane >> 5;
       float* lg = (float*)(lbase + FLDS_BYTES);
@@ -572,7 +577,7 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem, in
         if (plk == 0 && r < pn) lg[r] = logit + b2;
       }
       wave_sync();
-      action = pmlp_sample(lg, pn, env, uu, pol->actions + (size_t)pol_tt * (size_t)p.B, pol->logprobs + (size_t)pol_tt * (size_t)p.B);
+      action = pmlp_sample(lg, pn, env, uu, pol->actions + (size_t)pol_tt * (size_t)pol->stride_out, pol->logprobs + (size_t)pol_tt * (size_t)pol->stride_out);
     } else
     if (agent == BBX_AGENT_HASH) action = (int)(((uint64_t)f_readlane(hv, t_agent & 63) * (uint32_t)nP) >> 32);   // bbx_agent_action32
     else if (agent == BBX_AGENT_EXTERNAL) action = ext_action >= 0 ? ext_action : uni(f_cold_params()->actions[env]);
@@ -788,10 +793,12 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem, in
     }
     if constexpr (POL > 0) {
       const FColdPolicy pol = f_cold_policy();
+      if (pol->post_obs && p.obs) { write_obs32(); obs_trunc |= nP > p.obs_rows ? 1 : 0; }   // (the block a per-step call leaves: the NEW state)
       if (lane == 0) {
-        const size_t tb = (size_t)pol_tt * (size_t)p.B + (size_t)env;
+        const size_t tb = (size_t)pol_tt * (size_t)pol->stride_out + (size_t)env;
         if (pol->rewards_t) pol->rewards_t[tb] = p.rewards_mode == BBX_REW_ADDITIONS ? (-1.0 - (double)nred) : -1.0;
         if (pol->dones_t) pol->dones_t[tb] = done ? 1 : 0;
+        if (pol->post_obs && pol->rows_t) pol->rows_t[env] = nP;
       }
     }
     budget--; if (TRACE) trace_pos++;
@@ -867,6 +874,12 @@ __global__ __launch_bounds__(256) void bbx_fast_headline_kernel(BbxFastParams p)
 __global__ __launch_bounds__(256) void bbx_fast_value_kernel(BbxFastParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   fast_body<false, false, false, false, 0, false, true>(p, smem);
+}
+// bbx_policy_step_device calls served by a persistent session (fast_body POL + PERSIST)
+template <int NB>
+__global__ __launch_bounds__(256, 4) void bbx_fast_policy_session_kernel(BbxFastPolicyParams q) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  fast_body<false, false, false, false, NB, true>(q.f, smem);
 }
 // the kernels of persistent sessions (fast_body PERSIST): the headline shape and the general lean one
 __global__ __launch_bounds__(256) void bbx_fast_headline_persistent_kernel(BbxFastParams p) {

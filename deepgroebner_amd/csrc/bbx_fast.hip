@@ -42,8 +42,13 @@ extern "C" int bbx_launch_fast(const BbxParams* p, int blocks, int threads, int 
     BbxFastPolicyParams q; q.f = f; q.pol = *p->policy;
     q.f.agent = BBX_AGENT_EXTERNAL; q.f.actions = q.pol.actions;
     if (q.pol.rollout) {                                   // nsteps steps, the policy inside the step loop (3 variables, k = 2)
-      q.f.actions = nullptr; q.f.rewards = nullptr; q.f.dones = nullptr; q.f.rows = nullptr; q.f.obs_every_step = 0; q.f.auto_reset = 1;
+      q.f.actions = nullptr; q.f.rewards = nullptr; q.f.dones = nullptr; q.f.rows = q.pol.post_obs ? q.pol.rows_t : nullptr; q.f.obs_every_step = 0; q.f.auto_reset = 1;
       const size_t rl = (size_t)envs_per_block * (FLDS_BYTES + 4 * FP) + ((size_t)(2 * 6 + 2) * 32 * pmlp_nb_for(q.pol.hidden) + 4) * sizeof(float);
+      if (p->ctl) {                                        // per-step calls served by a persistent session
+        if (pmlp_nb_for(q.pol.hidden) == 2) hipLaunchKernelGGL((bbx_fast_policy_session_kernel<2>), dim3(blocks), dim3(threads), rl, stream, q);
+        else hipLaunchKernelGGL((bbx_fast_policy_session_kernel<4>), dim3(blocks), dim3(threads), rl, stream, q);
+        return 0;
+      }
       if (pmlp_nb_for(q.pol.hidden) == 2) hipLaunchKernelGGL((bbx_fast_policy_rollout_kernel<2>), dim3(blocks), dim3(threads), rl, stream, q);
       else hipLaunchKernelGGL((bbx_fast_policy_rollout_kernel<4>), dim3(blocks), dim3(threads), rl, stream, q);
       return 0;

@@ -28,6 +28,7 @@ ap.add_argument("--per-step", action="store_true", help="one library call per ve
                                                        "kernel (bbx_policy_rollout_device: --chunk steps per launch, policy inside the step loop)")
 ap.add_argument("--chunk", type=int, default=256)
 ap.add_argument("--store-states", action="store_true", help="--store plus the observation block of every step")
+ap.add_argument("--no-persistent", action="store_true", help="--per-step: one kernel per call instead of calls that join a persistent session")
 a = ap.parse_args()
 torch.manual_seed(0)
 B = a.batch
@@ -35,6 +36,8 @@ env = VecLeadMonomialsEnv(a.dist, batch=B, k=a.k)
 env.seed(np.arange(B) + 1000); env.reset()
 env.accounting(False)
 policy = PMLPPolicy(env.cols, [a.hidden]).cuda()
+if a.per_step and not a.no_persistent and not a.store and not a.store_states:
+    env.persistent(True)      # (per-step outputs are then only final at sync(): nothing in this mode reads them in between)
 def go(nsteps, buf):
     if a.per_step:
         return run_rollout(env, policy, nsteps, buffer=buf, obs_rows=a.obs_rows)
@@ -53,7 +56,7 @@ d = st - st0
 assert (d[:, 0] == a.steps).all() and (st[:, 4] == 0).all()
 assert int(episodes.sum()) == int(d[:, 2].sum()) and float(total.sum()) == -float(d[:, 1].sum())
 print(json.dumps({"dist": a.dist, "batch": B, "steps": a.steps, "policy": "PMLP([%d])" % a.hidden,
-                  "mode": "one call per step (bbx_policy_step_device)" if a.per_step else "policy rollout kernel, %d steps per launch" % a.chunk,
+                  "mode": ("one call per step (bbx_policy_step_device)" + (", calls joining persistent sessions" if a.per_step and not a.no_persistent and not a.store and not a.store_states else "")) if a.per_step else "policy rollout kernel, %d steps per launch" % a.chunk,
                   "store": "trajectory + states" if a.store_states else ("trajectory" if a.store else "nothing"),
                   "env_steps_per_s": B * a.steps / dt, "us_per_vector_step": dt / a.steps * 1e6,
                   "mean_return_per_episode": float(total.sum()) / max(1, int(episodes.sum())), "episodes": int(episodes.sum())}))

@@ -130,3 +130,42 @@ def test_session_only_where_admitted():
         env.sync()
         assert env.session_stats()["sessions"] == 0
         _check(env, want, rows, sample_every=5)
+
+
+@pytest.mark.parametrize("caps", [None, {"lds_max_basis": 16}])
+def test_policy_step_calls_join_a_session(caps):
+    """bbx_policy_step_device under bbx_persistent: consecutive calls whose uniforms are consecutive [B] slices of one array
+    are served by one running kernel with the policy inside its step loop.  Final outputs (actions, log-probabilities,
+    rewards, dones, rows, the observation block with its -1 padding) and the environments equal those of the same calls
+    made one kernel each."""
+    import torch
+    from deepgroebner_amd import VecLeadMonomialsEnv
+    from deepgroebner_amd.rollout import PMLPPolicy
+    torch.manual_seed(1)
+    B, T, R = 96, 37, 256
+    envs = []
+    for persistent in (False, True):
+        env = VecLeadMonomialsEnv(DIST, batch=B, k=2, caps=caps)
+        env.seed(np.arange(B) + 1000); env.reset(); env.accounting(False)
+        env.persistent(persistent)
+        envs.append(env)
+    policy = PMLPPolicy(envs[0].cols, [64]).cuda()
+    w = policy._fused_weights()
+    u = torch.rand((T, B), device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    outs = []
+    for env in envs:
+        obs = torch.zeros((B, R, env.cols), dtype=torch.int32, device="cuda")
+        rew = torch.zeros(B, dtype=torch.float64, device="cuda"); done = torch.zeros(B, dtype=torch.uint8, device="cuda")
+        rows = torch.zeros(B, dtype=torch.int32, device="cuda"); act = torch.zeros(B, dtype=torch.int32, device="cuda")
+        logp = torch.zeros(B, dtype=torch.float32, device="cuda")
+        env.rollout_device("first", 0, False, s, rew, done, rows, obs, R, True, False)   # the block the first call's policy reads
+        env.sync()
+        for t in range(T):
+            env.policy_step_device(w["prepared"], w["hidden"], u[t], act, logp, rew, done, rows, obs, R, 2, s)
+        env.sync()
+        outs.append([x.cpu().numpy().copy() for x in (act, logp, rew, done, rows, obs)] + [np.delete(env.stats(), 6, axis=1)])   # (without the
+                                                                  # algorithmic-byte column: only the accounting variants keep it)
+    assert envs[1].session_stats()["sessions"] == 1 and envs[1].session_stats()["joined"] == T - 1
+    for a, b, name in zip(outs[0], outs[1], ("actions", "logprobs", "rewards", "dones", "rows", "obs", "stats")):
+        assert np.array_equal(a, b), name
