@@ -207,14 +207,23 @@ __device__ uint64_t bin_obs(const BEnv<W>& e, const BbxParams& p, int env, int n
     // a trip to L2/HBM, and a single dependent chain per trip left the wave idle for microseconds.  tm[g] is the
     // zero monomial when G[g] has no tail (bin_add_poly stores it that way), so no look at ginfo is needed.
     constexpr int U = 4;
+    // (the pair words of the NEXT trip are requested before this trip's gathers: a trip then costs one dependent round trip
+    // to memory — pair word -> monomial — instead of two: +4 %.  Measured and dropped this round: eight sweeps in flight through
+    // direct-to-LDS gathers (global_load_lds_dwordx4: 81 M against 88 M), 16-byte aligned stores staged through LDS (52 M):
+    // the observation is bound by the issue of its stores, not by the latency of its gathers.)
+    uint32_t prn[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) { const int r = u * rows_per_sweep + rl; prn[u] = (active && r < rows) ? e.pairs[r] : 0u; }
     for (int r0 = 0; r0 < rows; r0 += U * rows_per_sweep) {
       int rr[U]; bool on[U]; uint32_t pr[U]; Mono<W> mm[U];
 #pragma unroll
       for (int u = 0; u < U; u++) {
         rr[u] = r0 + u * rows_per_sweep + rl;
         on[u] = active && rr[u] < rows;
-        pr[u] = on[u] ? e.pairs[rr[u]] : 0u;
+        pr[u] = prn[u];
       }
+#pragma unroll
+      for (int u = 0; u < U; u++) { const int r = rr[u] + U * rows_per_sweep; prn[u] = (active && r < rows) ? e.pairs[r] : 0u; }
 #pragma unroll
       for (int u = 0; u < U; u++) {
         const int g = half ? (int)(pr[u] >> 16) : (int)(pr[u] & 0xffffu);
