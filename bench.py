@@ -45,7 +45,7 @@ K_LEADS = 2
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
 PREROLL = 256
 MIN_REGION_MS = 60.0
-PMC_PROFILE = os.path.join("profiles", "r02_pmc_fast_kernel.json")
+PMC_PROFILE = os.path.join("profiles", "r03_pmc_fast_kernel.json")
 
 
 def parse_args():
@@ -248,6 +248,9 @@ def main():
                 "alg_bytes_per_launch": per_launch_bytes, "alg_bytes_per_env_step": alg_bytes / steps_done,
                 "kernel": kernel, "kernel_ms_per_launch": region_ms / R, "launches": R, "timed_region_ms": region_ms,
                 "kernels_in_timed_region": (sess["kernels"] - sess0["kernels"]) if persistent else R,
+                # every batch step this process pushed through that kernel (pre-roll, warm-up, calibration, timed region): a
+                # rocprofv3 --stats run of the same command shows the kernel's total time, total / this = time per batch step
+                "batch_steps_through_kernel": (max(args.preroll, 0) or 1) + Wm + ncal * K + R * K + (8 * 1024 if long_launch else 0),
                 "launch_note": ("the R launches of the timed region are served by the kernels of one persistent session (time slices of 10 ms); "
                                 "kernel_ms_per_launch = HIP-event time of the region / R") if persistent else "one kernel per launch"}
         pf = os.path.join(ROOT, PMC_PROFILE)

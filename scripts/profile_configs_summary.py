@@ -3,10 +3,10 @@ per workload the rocprofv3 kernel-trace stats, the PMC summary of the step kerne
 measured HBM traffic of the launch (PMC) put next to its algorithmic bytes.
     python scripts/profile_configs_summary.py r02"""
 import glob, json, os, shutil, sys
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 os.makedirs("profiles", exist_ok=True)
 lines = []
-for name, kern in (("cyclic7", "wide_kernel"), ("u5", "binom_kernel")):
+for name, kern in (("cyclic7", "wide_kernel"), ("u5", "binom_kernel"), ("general", "general_kernel")):
     for f in glob.glob("gpurun_out/cfg_%s_%s_stats/**/*kernel_stats.csv" % (tag, name), recursive=True):
         shutil.copy(f, "profiles/%s_%s_kernel_stats.csv" % (tag, kern))
     pj = "gpurun_out/pmc_%s_%s.json" % (tag, name)
@@ -33,6 +33,16 @@ for name, kern in (("cyclic7", "wide_kernel"), ("u5", "binom_kernel")):
                     d["roofline"]["traffic_source"] = "profiles/%s_pmc_%s.json" % (tag, kern)
                     d["roofline"]["traffic_over_algorithmic"] = pmc["hbm_traffic_bytes_per_launch"] / d["roofline"]["alg_bytes_total"]
                 lines.append(d)
+for f in glob.glob("gpurun_out/cfg_%s_general_long_stats/**/*kernel_stats.csv" % tag, recursive=True):
+    shutil.copy(f, "profiles/%s_general_long_kernel_stats.csv" % tag)
+for extra in ("cfg_%s_general_long.json" % tag, "cfg_%s_cyclic7_single.json" % tag):
+    if os.path.exists("gpurun_out/" + extra):
+        for l in open("gpurun_out/" + extra):
+            if l.startswith("{"):
+                lines.append(json.loads(l))
+for src, dst in (("value_%s.json" % tag, "%s_bench_value.json" % tag), ("gym_%s.log" % tag, "%s_bench_gym.log" % tag), ("single_%s.log" % tag, "%s_bench_single.log" % tag)):
+    if os.path.exists("gpurun_out/" + src):
+        shutil.copy("gpurun_out/" + src, "profiles/" + dst)
 for f in glob.glob("gpurun_out/prof_policy*/**/*kernel_stats.csv", recursive=True):
     shutil.copy(f, "profiles/%s_policy_%s_kernel_stats.csv" % (tag, "per_step" if "per_step" in f else "rollout"))
 for f in sorted(glob.glob("gpurun_out/policy_%s_*.json" % tag)):
