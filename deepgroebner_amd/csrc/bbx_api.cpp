@@ -18,24 +18,7 @@
 #include "../../include/bbx.h"
 #include "bbx_common.h"
 #include "bbx_ideals.h"
-#include "bbx_host.h"
-
-extern "C" int bbx_launch_step(const BbxParams* p, int kind, int envs_per_block, hipStream_t stream);
-extern "C" int bbx_launch_clone(const char* src_recs, char* dst_recs, const BbxLayout* L, const int32_t* src, const int32_t* dst, int n,
-                                const uint32_t* seeds, int keep_counters, int seed_std, int ngen, uint8_t* flags, hipStream_t stream);
-extern "C" int bbx_launch_value_resort(char* recs, const BbxLayout* L, int n, const uint8_t* flags, hipStream_t stream);
-extern "C" int bbx_launch_value_collect(const char* recs, uint32_t rec_bytes, int n, double* out2, hipStream_t stream);
-extern "C" int bbx_launch_relayout(const char* src_recs, char* dst_recs, const BbxLayout* Ls, const BbxLayout* Ld, int B, hipStream_t stream);
-extern "C" int bbx_launch_ctl(unsigned long long* ctl, unsigned long long value, hipStream_t stream);
-extern "C" int bbx_launch_gather_lite(const char* recs, uint32_t rec_bytes, int B, void* out, hipStream_t stream);
-extern "C" int bbx_launch_gather_hdr(const char* recs, uint32_t rec_bytes, int B, BbxHdr* out, hipStream_t stream);
-extern "C" int bbx_launch_scatter_queue(const uint32_t* stage, int n, uint32_t ring_words, uint32_t* q, int32_t* tail, hipStream_t stream);
-extern "C" int bbx_launch_obs_pack(const int32_t* padded, int cap, int cols, const int32_t* rows, int B, int32_t* off, int32_t* packed, hipStream_t stream);
-extern "C" int bbx_launch_init(char* recs, uint32_t rec_bytes, int B, const uint32_t* agent_seeds, hipStream_t stream);
-extern "C" int bbx_launch_mark_reset(char* recs, uint32_t rec_bytes, int B, const uint8_t* mask, hipStream_t stream);
-extern "C" int bbx_launch_pmlp_prepare(const float* w1, const float* b1, const float* w2, float b2, int cols, int hidden, float* out, hipStream_t stream);
-extern "C" int bbx_launch_pmlp_act(const int32_t* obs, const int32_t* rows, int B, int obs_rows, int cols, const float* wp, int hidden, const float* u,
-                                   int32_t* actions, float* logprobs, hipStream_t stream);
+#include "bbx_batch.h"
 
 namespace {
 
@@ -57,90 +40,6 @@ struct OutBuf {            // one contiguous device block so a step needs a sing
 
 }  // namespace
 
-struct bbx_gen {
-  std::unique_ptr<bbx::IdealGen> g;
-  bbx::HIdeal last;
-};
-
-struct bbx_batch {
-  int B = 0, device = 0, k = 1, nvars = 0, W = 2;
-  int elim = 0, rewards = 0, sort_input = 0, sort_reducers = 1;
-  bool fixed = false, binom = false, listed = false;   // listed: the ideals come from a caller's list (bbx_create_ideals)
-  BbxLayout L{}, LL{};
-  uint16_t* d_inv = nullptr;           // GF(32003) inverse table
-  std::vector<std::unique_ptr<bbx::IdealGen>> gens;   // one per environment (one shared when fixed)
-  uint32_t slot_words = 0, nslots = 0;
-  std::vector<uint32_t> h_q;          // host mirror of the ideal queue
-  std::vector<int32_t> h_tail, h_head;
-  std::vector<BbxHdr> h_hdr;
-  std::vector<int32_t> h_lite;        // per environment {status, q_head, budget, nP}: what is polled after every launch
-  bool q_dirty = true;
-  std::vector<uint8_t> q_dirty_env;
-  // ideals drawn on the device (binomial distributions): the table the kernels read, the per-environment engine state
-  // lives in the record headers (BbxHdr.gen_rng); the host-side generators and the ideal queue are then unused
-  uint32_t* d_gen = nullptr; size_t gen_words = 0; bool device_gen = false;
-  std::vector<std::string> gen_error;   // per environment: a generator failure met while drawing ahead (see fill_queues)
-  // device
-  char* d_recs = nullptr;
-  uint32_t* d_q = nullptr;
-  int32_t* d_tail = nullptr;
-  // one device block polled after every launch: lite[B][4] {status, q_head, budget, |P|} | rewards f64[B] | rows i32[B] |
-  // dones u8[B]; the kernels write it themselves, the host fetches it with ONE copy into pinned memory
-  char* d_out = nullptr; int32_t* d_lite = nullptr; double* d_rewards = nullptr; int32_t* d_rows = nullptr; uint8_t* d_dones = nullptr;
-  char* h_io = nullptr; size_t io_bytes = 0;      // pinned mirror of d_out
-  int32_t* h_act = nullptr;                       // pinned staging of host actions
-  // small batches (the single-environment drop-in): the kernels read the actions from and write their outputs and the
-  // observation straight into pinned host memory — no copy calls on the latency path, one stream synchronisation per step
-  bool zero_copy = false, zc_active = false;
-  bool poll_active = false; int poll_seq = 0, poll_misses = 0; unsigned polled_launches = 0;                   // the launch in flight signals completion through h_io (done_seq)
-  char* zc_io_dev = nullptr; int32_t* zc_act_dev = nullptr;     // device-side addresses of h_io / h_act
-  int32_t* h_zobs = nullptr; int32_t* zc_obs_dev = nullptr; size_t zobs_rows_cap = 0;
-  // ragged observations (bbx_step_obs): device offsets [B+1] + packed rows, and their pinned mirror handed to the caller
-  int32_t* d_obs_off = nullptr; int32_t* d_obs_packed = nullptr; int32_t* h_obs = nullptr; size_t obs_packed_cap = 0;
-  uint32_t* h_stage = nullptr; uint32_t* d_stage = nullptr; size_t stage_words = 0;   // queue refill staging (pinned / device)
-  int32_t* d_actions = nullptr; uint8_t* d_mask = nullptr; uint32_t* d_seeds = nullptr;
-  int32_t* d_obs = nullptr; size_t obs_rows_cap = 0;
-  BbxTraceRec* d_trace = nullptr; int trace_cap = 0;
-  BbxHdr* d_hdr = nullptr;            // compact header copy (bbx_gather_hdr_kernel)
-  // scratch for value(): cloned records, their headers, source indices, agent seeds, results
-  char* d_vrecs = nullptr; BbxHdr* d_vhdr = nullptr; int32_t* d_vsrc = nullptr; uint32_t* d_vseeds = nullptr; double* d_vvals = nullptr;
-  int vcap = 0;
-  // HIP-event timing of the step-kernel launches (bbx_timing)
-  bool accounting = true;             // count algorithmic bytes (bbx_accounting)
-  bool timing = false;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_open;
-  double kernel_ms = 0.0; int kernel_launches = 0;
-  std::vector<char> h_out;
-  // the rollout in flight (so bbx_sync can finish environments that waited for ideals)
-  BbxParams last{};
-  hipStream_t last_stream = 0;
-  bool in_flight = false;
-  bool policy_rollout = false;           // the launch in flight is a policy rollout (bbx_policy_rollout_device)
-  int staged = 0, fast = 0, envs_per_block = 4;
-  int wide = 0;                       // > 0: waves per environment of the wide (one workgroup per environment) class
-  int wide_terms = 0;                 // forced LDS capacity of the wide class (caps.wide_lds_terms), 0 = automatic
-  bool device_async = false;          // the launch in flight came through a *_device entry point (no host poll per step)
-  bool obs_external = false;          // the launch in flight writes observations into a caller-owned block: rows cut for
-                                      // lack of space are an error the caller must hear about (bbx_sync)
-  // persistent sessions (bbx_persistent): see BbxParams::ctl
-  bool ps_enabled = false, ps_active = false;
-  unsigned long long* d_ctl = nullptr;
-  hipStream_t ps_stream = nullptr, ps_ctl_stream = nullptr;   // the session's kernel / the writes to its control word
-  hipEvent_t ps_ev = nullptr;
-  long long ps_target = 0;            // steps issued since the session began
-  BbxParams ps_p{};                   // the parameters of the call that began it (later calls must match to join)
-  BbxPolicy ps_pol{};                 // ... and its policy arguments (ps_p.policy points here), when it is a session of policy steps
-  int ps_sessions = 0, ps_joined = 0, ps_kernels = 0; // statistics: sessions begun, calls that joined a running one, kernels
-  std::mt19937_64 value_rng;          // seeds of value("random") / value("sample") rollouts when the caller gives none
-  bool gen_to_wide = false;           // general class with <= 16-byte monomials: long-polynomial environments continue in the wide class
-  bool no_growth = false;             // bbx_caps.no_growth: the configured capacities are hard limits (BBX_E_CAPACITY)
-  int grow_events = 0;                // times the records were enlarged (bbx_capacities)
-  bbx_batch() = default;
-  bbx_batch(const bbx_batch&) = delete;
-  bbx_batch& operator=(const bbx_batch&) = delete;
-  ~bbx_batch();                       // frees every device / pinned allocation (also on half-built handles)
-};
-
 bbx_batch::~bbx_batch() {
   if (!d_recs && !d_q && !d_out && !d_inv && !h_io) return;   // nothing was ever allocated
   (void)hipSetDevice(device);
@@ -157,7 +56,7 @@ bbx_batch::~bbx_batch() {
   for (void* q : pinned) if (q) (void)hipHostFree(q);
 }
 
-namespace {
+namespace bbx_host {
 
 int pack_mono(const bbx_batch* b, const bbx::HTerm& t, uint32_t* w) {
   const int W = b->W, slots = 2 * W;
@@ -269,7 +168,7 @@ int fill_queues(bbx_batch* b, int min_avail = 1, hipStream_t stream = 0) {
   return upload_queue(b, stream);
 }
 
-int read_headers(bbx_batch* b, hipStream_t stream = 0) {
+int read_headers(bbx_batch* b, hipStream_t stream) {
   b->h_hdr.resize(b->B);
   int lrc = bbx_launch_gather_hdr(b->d_recs, b->L.rec_bytes, b->B, b->d_hdr, stream);
   if (lrc) return fail(BBX_E_DEVICE, "gather launch failed: %s", hipGetErrorString((hipError_t)lrc));
@@ -496,7 +395,6 @@ int grow_records(bbx_batch* b, unsigned need, int env, hipStream_t stream) {
 // errors.  Whatever happens, the handle is left with nothing in flight: an error is reported once, not re-raised by
 // every later call, and environments that only needed service (STARVED / SPILL) have been served before the first
 // error of another environment is returned.
-int session_close(bbx_batch* b, bool wait, hipStream_t then, bool sliced);
 int session_kernel(bbx_batch* b, bool first, hipStream_t after, bool sliced);
 
 int finish(bbx_batch* b, hipStream_t stream) {
@@ -842,7 +740,8 @@ int create_common(std::unique_ptr<bbx::IdealGen> proto, int nvars_obs, int elimi
   return BBX_OK;
 }
 
-}  // namespace
+}  // namespace bbx_host
+using namespace bbx_host;
 
 extern "C" {
 
@@ -1403,394 +1302,5 @@ int bbx_obs(bbx_batch* b, int32_t* out, int max_rows, int fill) {
 int bbx_cols(const bbx_batch* b) { return b ? 2 * b->nvars * b->k : 0; }
 int bbx_nvars(const bbx_batch* b) { return b ? b->nvars : 0; }
 int bbx_batch_size(const bbx_batch* b) { return b ? b->B : 0; }
-
-}  // extern "C" (reopened below)
-
-// ---- value(): discounted return of full Buchberger rollouts from clones of the current states ---------------------
-namespace {
-
-int agent_of_strategy(const char* s) {   // unknown keys select First: std::map::operator[] default (buchberger.cpp:342-349)
-  if (!strcmp(s, "degree")) return BBX_AGENT_DEGREE;
-  if (!strcmp(s, "normal")) return BBX_AGENT_NORMAL;
-  if (!strcmp(s, "sugar")) return BBX_AGENT_SUGAR;
-  if (!strcmp(s, "random")) return BBX_AGENT_STDRANDOM;   // choice(P, rng) of a seeded std::default_random_engine (buchberger.cpp:200-203, 244)
-  return BBX_AGENT_FIRST;
-}
-
-// std::default_random_engine::seed(s) (linear_congruential_engine<uint_fast32_t, 16807, 0, 2^31-1>, libstdc++ bits/random.tcc):
-// the int seed converts to the unsigned result type first; x = s mod m, and 0 becomes 1
-uint32_t minstd_state_of_seed(long long seed) {
-  const uint32_t x = (uint32_t)((uint64_t)seed % 2147483647ull);
-  return x ? x : 1u;
-}
-
-// One rollout to completion per entry of src (indices into b), from clones of the current states; seeds != null: the
-// engine states of the clones' seeded Random selection.  Everything runs on the default stream without a copy in between
-// and with one wait: values + completion marks come back in one transfer at the end (clones whose generator lead monomials
-// tie get the reducer order buchberger()'s std::sort would give them from a kernel: bbx_value_resort_kernel).  3-variable binomial batches run on the register/LDS-resident class (bbx_fast_value_kernel),
-// environments that outgrow it and every other batch on the HBM-resident class of the batch, long-polynomial
-// environments one workgroup per clone.  A clone that runs out of room enlarges the records of the whole batch
-// (grow_records) and the rollouts start again.
-int value_rollouts(bbx_batch* b, const std::vector<int32_t>& src, int agent, const std::vector<uint32_t>* seeds, double gamma, double* out) {
-  const int n = (int)src.size();
-  if (b->in_flight) { int rc = finish(b, b->last_stream); if (rc) return rc; }
-  for (int attempt = 0; attempt < 40; attempt++) {
-    if (n > b->vcap) {
-      void* old[] = {b->d_vrecs, b->d_vhdr, b->d_vsrc, b->d_vseeds, b->d_vvals};
-      for (void* q : old) (void)hipFree(q);
-      b->d_vrecs = nullptr; b->d_vhdr = nullptr; b->d_vsrc = nullptr; b->d_vseeds = nullptr; b->d_vvals = nullptr; b->vcap = 0;
-      HIPCHK(hipMalloc((void**)&b->d_vrecs, (size_t)n * b->L.rec_bytes));
-      HIPCHK(hipMalloc((void**)&b->d_vhdr, (size_t)n));                        // clone flags (u8)
-      HIPCHK(hipMalloc((void**)&b->d_vsrc, (size_t)n * sizeof(int32_t)));
-      HIPCHK(hipMalloc((void**)&b->d_vseeds, (size_t)n * sizeof(uint32_t)));
-      HIPCHK(hipMalloc((void**)&b->d_vvals, (size_t)n * 2 * sizeof(double)));  // {value, completion mark} per clone
-      b->vcap = n;
-    }
-    HIPCHK(hipMemcpyAsync(b->d_vsrc, src.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, 0));
-    if (seeds) HIPCHK(hipMemcpyAsync(b->d_vseeds, seeds->data(), (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, 0));
-    const int ngen = b->sort_reducers ? b->gens[0]->npolys() : 0;
-    uint8_t* d_flags = (uint8_t*)b->d_vhdr;
-    int lrc = bbx_launch_clone(b->d_recs, b->d_vrecs, &b->L, b->d_vsrc, nullptr, n, seeds ? b->d_vseeds : nullptr, 0, 1, ngen, d_flags, 0);
-    if (lrc) return fail(BBX_E_DEVICE, "clone launch failed: %s", hipGetErrorString((hipError_t)lrc));
-    lrc = bbx_launch_value_resort(b->d_vrecs, &b->L, n, d_flags, 0);   // (clones whose generators tie: std::sort's order)
-    if (lrc) return fail(BBX_E_DEVICE, "resort launch failed: %s", hipGetErrorString((hipError_t)lrc));
-    BbxParams p; fill_params(b, &p);
-    p.recs = b->d_vrecs; p.B = n; p.nsteps = 1 << 30; p.set_budget = 1; p.agent = agent; p.auto_reset = 0;
-    p.value_mode = 1; p.gamma = gamma; p.values = nullptr; p.trace = nullptr; p.accounting = 0;
-    p.lite = nullptr;                                           // the clones are not the batch's environments
-    if (b->wide) lrc = bbx_launch_step(&p, 4, b->wide, 0);
-    else {
-      const bool vfast = b->fast && b->staged && (agent == BBX_AGENT_DEGREE || agent == BBX_AGENT_FIRST || agent == BBX_AGENT_STDRANDOM || agent == BBX_AGENT_HASH);
-      lrc = 0;
-      if (vfast) lrc = bbx_launch_step(&p, 3, b->envs_per_block, 0);
-      if (b->gen_to_wide) p.spill_terms = 384;
-      if (!lrc) { if (vfast) { p.set_budget = 0; p.pass = 1; } lrc = bbx_launch_step(&p, 0, b->envs_per_block, 0); }
-      if (!lrc && b->gen_to_wide) { p.set_budget = 0; p.pass = 1; p.spill_terms = 0; lrc = bbx_launch_step(&p, 4, 8, 0); }
-    }
-    if (lrc) return fail(BBX_E_DEVICE, "kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
-    lrc = bbx_launch_value_collect(b->d_vrecs, b->L.rec_bytes, n, b->d_vvals, 0);
-    if (lrc) return fail(BBX_E_DEVICE, "collect launch failed: %s", hipGetErrorString((hipError_t)lrc));
-    std::vector<double> v2((size_t)n * 2);
-    HIPCHK(hipMemcpy(v2.data(), b->d_vvals, v2.size() * sizeof(double), hipMemcpyDeviceToHost));   // the only wait of the call
-    unsigned grow = 0; int grow_k = -1;
-    for (int k = 0; k < n; k++) {
-      const int st = (int)v2[2 * (size_t)k + 1];
-      if (st == 0) continue;
-      if (st > 0 && bbx_st_capacity(st) && !b->no_growth) { grow |= 1u << st; if (grow_k < 0) grow_k = k; continue; }
-      return fail(BBX_E_CAPACITY, "value rollout of environment %d did not finish: %s", src[k], st > 0 ? status_name(st) : "pairs left");
-    }
-    if (!grow) {
-      for (int k = 0; k < n; k++) out[k] = v2[2 * (size_t)k];
-      return BBX_OK;
-    }
-    int rc = grow_records(b, grow, src[grow_k], 0);             // (frees the clones: sized by the old layout)
-    if (rc) return rc;
-  }
-  return fail(BBX_E_CAPACITY, "value rollouts kept outgrowing the records");
-}
-
-// `seeds`: explicit seeds of the Random rollouts — [n] for "random", [n][100] for "sample" — or null: drawn from the
-// handle's own stream (the reference seeds from std::random_device: ours starts from the handle's seed base, so a run is
-// reproducible under BBX_DEFAULT_SEED)
-int values_for(bbx_batch* b, const std::vector<int32_t>& envs, const char* strategy, double gamma, const int64_t* seeds, double* out) {
-  const int n = (int)envs.size();
-  auto draw = [b]() { return (long long)(b->value_rng() & 0x7fffffffull); };
-  if (!strcmp(strategy, "sample")) {          // best of one Degree and 100 Random rollouts (buchberger.cpp:333-341)
-    int rc = value_rollouts(b, envs, BBX_AGENT_DEGREE, nullptr, gamma, out);
-    if (rc) return rc;
-    std::vector<int32_t> src; std::vector<uint32_t> st;
-    src.reserve((size_t)n * 100); st.reserve((size_t)n * 100);
-    for (int k = 0; k < n; k++) for (int i = 0; i < 100; i++) { src.push_back(envs[k]); st.push_back(minstd_state_of_seed(seeds ? seeds[(size_t)k * 100 + i] : draw())); }
-    std::vector<double> r(src.size());
-    rc = value_rollouts(b, src, BBX_AGENT_STDRANDOM, &st, gamma, r.data());
-    if (rc) return rc;
-    for (int k = 0; k < n; k++) for (int i = 0; i < 100; i++) out[k] = std::max(out[k], r[(size_t)k * 100 + i]);
-    return BBX_OK;
-  }
-  const int agent = agent_of_strategy(strategy);
-  if (agent == BBX_AGENT_STDRANDOM) {
-    std::vector<uint32_t> st(n);
-    for (int k = 0; k < n; k++) st[k] = minstd_state_of_seed(seeds ? seeds[k] : draw());
-    return value_rollouts(b, envs, agent, &st, gamma, out);
-  }
-  return value_rollouts(b, envs, agent, nullptr, gamma, out);
-}
-
-}  // namespace
-
-extern "C" int bbx_value(bbx_batch* b, int idx, const char* strategy, double gamma, double* out) {
-  if (!b || !strategy || !out || idx < 0 || idx >= b->B) return fail(BBX_E_ARG, "bad arguments");
-  HIPCHK(hipSetDevice(b->device));
-  return values_for(b, std::vector<int32_t>{idx}, strategy, gamma, nullptr, out);
-}
-
-extern "C" int bbx_values_seeded(bbx_batch* b, const char* strategy, double gamma, const int64_t* seeds, double* out) {
-  if (!b || !strategy || !out) return fail(BBX_E_ARG, "bad arguments");
-  HIPCHK(hipSetDevice(b->device));
-  std::vector<int32_t> envs(b->B);
-  for (int e = 0; e < b->B; e++) envs[e] = e;
-  return values_for(b, envs, strategy, gamma, seeds, out);
-}
-
-extern "C" int bbx_values(bbx_batch* b, const char* strategy, double gamma, double* out) {
-  if (!b || !strategy || !out) return fail(BBX_E_ARG, "bad arguments");
-  HIPCHK(hipSetDevice(b->device));
-  std::vector<int32_t> envs(b->B);
-  for (int e = 0; e < b->B; e++) envs[e] = e;
-  return values_for(b, envs, strategy, gamma, nullptr, out);
-}
-
-extern "C" {
-
-int bbx_stats(bbx_batch* b, int64_t* out8) {
-  int64_t* out6 = out8;
-  if (!b || !out6) return fail(BBX_E_ARG, "null argument");
-  HIPCHK(hipSetDevice(b->device));
-  if (b->ps_active) { int rc_ = session_close(b, false, nullptr, false); if (rc_) return rc_; }
-  HIPCHK(hipDeviceSynchronize());
-  int rc = read_headers(b);
-  if (rc) return rc;
-  for (int e = 0; e < b->B; e++) {
-    const BbxHdr& h = b->h_hdr[e];
-    int64_t* o = out6 + (size_t)e * 8;
-    o[0] = h.total_steps; o[1] = h.total_additions; o[2] = h.episodes; o[3] = h.zero_reductions; o[4] = h.status; o[5] = h.q_head;
-    o[6] = h.alg_bytes; o[7] = h.nG;
-  }
-  return BBX_OK;
-}
-
-// (bbx_alg.cpp) where the records of a quiet batch live
-int bbx_internal_records(bbx_batch* b, const char** recs, BbxLayout* L, int* device, int* W, int* batch) {
-  if (!b) return fail(BBX_E_ARG, "null argument");
-  HIPCHK(hipSetDevice(b->device));
-  if (b->in_flight) { int rc = finish(b, b->last_stream); if (rc) return rc; }
-  HIPCHK(hipDeviceSynchronize());
-  *recs = b->d_recs; *L = b->L; *device = b->device; *W = b->W; *batch = b->B;
-  return BBX_OK;
-}
-
-int bbx_capacities(bbx_batch* b, int32_t* out5) {
-  if (!b || !out5) return fail(BBX_E_ARG, "null argument");
-  out5[0] = (int32_t)b->L.maxG; out5[1] = (int32_t)b->L.maxP; out5[2] = (int32_t)b->L.arena; out5[3] = (int32_t)b->L.maxT; out5[4] = b->grow_events;
-  return BBX_OK;
-}
-
-int bbx_env_status(bbx_batch* b, int32_t* status) {
-  if (!b || !status) return fail(BBX_E_ARG, "null argument");
-  HIPCHK(hipSetDevice(b->device));
-  if (b->ps_active) { int rc_ = session_close(b, false, nullptr, false); if (rc_) return rc_; }
-  HIPCHK(hipDeviceSynchronize());
-  int rc = read_headers(b);
-  if (rc) return rc;
-  for (int e = 0; e < b->B; e++) status[e] = b->h_hdr[e].status;
-  return BBX_OK;
-}
-
-int bbx_state_sizes(bbx_batch* b, int idx, int32_t* basis_size, int32_t* npairs, int32_t* nterms_total) {
-  if (!b || idx < 0 || idx >= b->B) return fail(BBX_E_ARG, "bad environment index");
-  HIPCHK(hipSetDevice(b->device));
-  if (b->ps_active) { int rc_ = session_close(b, false, nullptr, false); if (rc_) return rc_; }
-  HIPCHK(hipDeviceSynchronize());
-  BbxHdr h;
-  HIPCHK(hipMemcpy(&h, b->d_recs + (size_t)idx * b->L.rec_bytes, sizeof h, hipMemcpyDeviceToHost));
-  if (basis_size) *basis_size = h.nG;
-  if (npairs) *npairs = h.nP;
-  if (nterms_total) *nterms_total = b->binom ? 2 * h.nG : h.arena_used;   // binomial class: upper bound
-  return BBX_OK;
-}
-
-int bbx_state_get(bbx_batch* b, int idx, int32_t* nterms, int32_t* coefs, int32_t* exps, int32_t* pairs, int32_t* order) {
-  if (!b || idx < 0 || idx >= b->B) return fail(BBX_E_ARG, "bad environment index");
-  HIPCHK(hipSetDevice(b->device));
-  if (b->ps_active) { int rc_ = session_close(b, false, nullptr, false); if (rc_) return rc_; }
-  HIPCHK(hipDeviceSynchronize());
-  const char* rec = b->d_recs + (size_t)idx * b->L.rec_bytes;
-  BbxHdr h;
-  HIPCHK(hipMemcpy(&h, rec, sizeof h, hipMemcpyDeviceToHost));
-  if (b->binom) {
-    const int W = b->W, nG = h.nG, nP = h.nP;
-    std::vector<uint32_t> lm((size_t)std::max(nG, 1) * W), tm((size_t)std::max(nG, 1) * W), gi((size_t)std::max(nG, 1) * 2),
-        si((size_t)std::max(nG, 1) * 2), pr(std::max(nP, 1));
-    if (nG) {
-      HIPCHK(hipMemcpy(lm.data(), rec + b->L.off_lm, (size_t)nG * W * 4, hipMemcpyDeviceToHost));
-      HIPCHK(hipMemcpy(tm.data(), rec + b->L.off_tm, (size_t)nG * W * 4, hipMemcpyDeviceToHost));
-      HIPCHK(hipMemcpy(gi.data(), rec + b->L.off_ginfo, (size_t)nG * 8, hipMemcpyDeviceToHost));
-      HIPCHK(hipMemcpy(si.data(), rec + b->L.off_sinfo, (size_t)nG * 8, hipMemcpyDeviceToHost));
-    }
-    if (nP) HIPCHK(hipMemcpy(pr.data(), rec + b->L.off_pairs, (size_t)nP * 4, hipMemcpyDeviceToHost));
-    auto unpack = [W](const uint32_t* w, int32_t* e8) {
-      for (int v = 0; v < bbx::kN; v++)
-        e8[v] = v < 2 * W - 1 ? ((v & 1) ? (int)(w[v >> 1] >> 16) : (int)(w[v >> 1] & 0xffffu)) : 0;
-    };
-    size_t at = 0;
-    for (int g = 0; g < nG; g++) {
-      const uint32_t c0 = gi[2 * g] & 0xffffu, c1 = gi[2 * g] >> 16;
-      if (nterms) nterms[g] = c1 ? 2 : 1;
-      if (coefs) coefs[at] = (int)c0;
-      if (exps) unpack(lm.data() + (size_t)g * W, exps + at * bbx::kN);
-      at++;
-      if (c1) {
-        if (coefs) coefs[at] = (int)c1;
-        if (exps) unpack(tm.data() + (size_t)g * W, exps + at * bbx::kN);
-        at++;
-      }
-      if (order) order[g] = (int)(si[2 * g + 1] >> 16);
-    }
-    if (pairs) for (int r = 0; r < nP; r++) { pairs[2 * r] = (int)(pr[r] & 0xffffu); pairs[2 * r + 1] = (int)(pr[r] >> 16); }
-    return BBX_OK;
-  }
-  const int W = b->W, nG = h.nG, nP = h.nP, nt = h.arena_used;
-  std::vector<uint32_t> am((size_t)std::max(nt, 1) * W), poff(std::max(nG, 1)), pr(std::max(nP, 1));
-  std::vector<uint16_t> ac(std::max(nt, 1)), plen(std::max(nG, 1)), sidx(std::max(nG, 1));
-  if (nt) {
-    HIPCHK(hipMemcpy(am.data(), rec + b->L.off_am, (size_t)nt * W * 4, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(ac.data(), rec + b->L.off_ac, (size_t)nt * 2, hipMemcpyDeviceToHost));
-  }
-  if (nG) {
-    HIPCHK(hipMemcpy(poff.data(), rec + b->L.off_poff, (size_t)nG * 4, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(plen.data(), rec + b->L.off_plen, (size_t)nG * 2, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(sidx.data(), rec + b->L.off_sidx, (size_t)nG * 2, hipMemcpyDeviceToHost));
-  }
-  if (nP) HIPCHK(hipMemcpy(pr.data(), rec + b->L.off_pairs, (size_t)nP * 4, hipMemcpyDeviceToHost));
-  size_t at = 0;
-  for (int g = 0; g < nG; g++) {
-    if (nterms) nterms[g] = plen[g];
-    for (int t = 0; t < plen[g]; t++, at++) {
-      const uint32_t* w = am.data() + ((size_t)poff[g] + t) * W;
-      if (coefs) coefs[at] = ac[poff[g] + t];
-      if (exps) {
-        for (int v = 0; v < bbx::kN; v++) {
-          int x = 0;
-          if (v < 2 * W - 1) x = (v & 1) ? (int)(w[v >> 1] >> 16) : (int)(w[v >> 1] & 0xffffu);
-          exps[at * bbx::kN + v] = x;
-        }
-      }
-    }
-    if (order) order[g] = sidx[g];
-  }
-  if (pairs) for (int r = 0; r < nP; r++) { pairs[2 * r] = (int)(pr[r] & 0xffffu); pairs[2 * r + 1] = (int)(pr[r] >> 16); }
-  return BBX_OK;
-}
-
-// interreduce(minimalize(G)) of environment idx's current basis (what buchberger() returns, buchberger.cpp:265), computed on
-// the device (bbx_alg_from_envs + bbx_alg_minimalize + bbx_alg_interreduce).  Two-call protocol like bbx_state_get: sizes
-// first (nterms == NULL), then the data.
-int bbx_reduced_basis(bbx_batch* b, int idx, int32_t* basis_size, int32_t* nterms_total, int32_t* nterms, int32_t* coefs, int32_t* exps) {
-  if (!b || idx < 0 || idx >= b->B) return fail(BBX_E_ARG, "bad environment index");
-  bbx_alg* a = nullptr;
-  const int32_t e = idx;
-  int rc = bbx_alg_from_envs(b, 1, &e, &a);                 // the basis as a device-resident list, then the two kernels
-  if (!rc) rc = bbx_alg_minimalize(a);
-  if (!rc) rc = bbx_alg_interreduce(a);
-  int32_t n = 0, tot = 0;
-  if (!rc) rc = bbx_alg_sizes(a, &n, &tot);
-  if (!rc) {
-    if (basis_size) *basis_size = n;
-    if (nterms_total) *nterms_total = tot;
-    if (nterms) rc = bbx_alg_get(a, 0, nterms, coefs, exps, nullptr);
-  }
-  bbx_alg_destroy(a);
-  return rc;
-}
-
-int bbx_trace_enable(bbx_batch* b, int capacity_steps) {
-  if (!b || capacity_steps < 0) return fail(BBX_E_ARG, "bad arguments");
-  HIPCHK(hipSetDevice(b->device));
-  HIPCHK(hipDeviceSynchronize());
-  if (b->d_trace) { HIPCHK(hipFree(b->d_trace)); b->d_trace = nullptr; }
-  b->trace_cap = capacity_steps;
-  if (capacity_steps) {
-    HIPCHK(hipMalloc((void**)&b->d_trace, (size_t)b->B * capacity_steps * sizeof(BbxTraceRec)));
-    HIPCHK(hipMemset(b->d_trace, 0, (size_t)b->B * capacity_steps * sizeof(BbxTraceRec)));
-  }
-  return BBX_OK;
-}
-
-int bbx_trace_read(bbx_batch* b, int env, int first, int count, bbx_trace_rec* out) {
-  if (!b || !out || !b->d_trace || env < 0 || env >= b->B || first < 0 || count < 0 || first + count > b->trace_cap)
-    return fail(BBX_E_ARG, "bad trace range");
-  static_assert(sizeof(bbx_trace_rec) == sizeof(BbxTraceRec), "trace record layouts must match");
-  HIPCHK(hipSetDevice(b->device));
-  HIPCHK(hipMemcpy(out, b->d_trace + (size_t)env * b->trace_cap + first, (size_t)count * sizeof(BbxTraceRec), hipMemcpyDeviceToHost));
-  return BBX_OK;
-}
-
-// ---- generators on their own -------------------------------------------------------------------
-int bbx_gen_create(const char* ideal_dist, bbx_gen** out) {
-  if (!ideal_dist || !out) return fail(BBX_E_ARG, "null argument");
-  std::string err;
-  auto g = bbx::parse_ideal_dist(ideal_dist, &err);
-  if (!g) return fail(BBX_E_ARG, "%s", err.c_str());
-  *out = new bbx_gen{std::move(g), {}};
-  return BBX_OK;
-}
-void bbx_gen_destroy(bbx_gen* g) { delete g; }
-int bbx_gen_seed(bbx_gen* g, int64_t seed) { if (!g) return fail(BBX_E_ARG, "null"); g->g->seed(seed); return BBX_OK; }
-int bbx_gen_nvars(const bbx_gen* g) { return g ? g->g->nvars() : 0; }
-int bbx_gen_next(bbx_gen* g, int32_t* npolys, int32_t* nterms_total) {
-  if (!g) return fail(BBX_E_ARG, "null");
-  std::string err;
-  if (!g->g->next(g->last, &err)) return fail(BBX_E_GENERATOR, "%s", err.c_str());
-  int tot = 0;
-  for (auto& f : g->last) tot += (int)f.t.size();
-  if (npolys) *npolys = (int)g->last.size();
-  if (nterms_total) *nterms_total = tot;
-  return BBX_OK;
-}
-int bbx_gen_get(const bbx_gen* g, int32_t* nterms, int32_t* coefs, int32_t* exps, int32_t* sugars) {
-  if (!g) return fail(BBX_E_ARG, "null");
-  size_t at = 0;
-  for (size_t p = 0; p < g->last.size(); p++) {
-    const auto& f = g->last[p];
-    if (nterms) nterms[p] = (int)f.t.size();
-    if (sugars) sugars[p] = f.sugar;
-    for (auto& t : f.t) {
-      if (coefs) coefs[at] = t.c;
-      if (exps) for (int v = 0; v < bbx::kN; v++) exps[at * bbx::kN + v] = t.e[v];
-      at++;
-    }
-  }
-  return BBX_OK;
-}
-
-int bbx_parse_ideal(const char* text, int32_t cap_polys, int32_t cap_terms, int32_t* npolys, int32_t* nterms_total,
-                    int32_t* nterms, int32_t* coefs, int32_t* exps) {
-  if (!text || !npolys || !nterms_total) return fail(BBX_E_ARG, "null argument");
-  bbx::HIdeal F; std::string err;
-  if (!bbx::parse_ideal_string(text, F, &err)) return fail(BBX_E_ARG, "%s", err.c_str());
-  size_t total = 0;
-  for (auto& f : F) total += f.t.size();
-  *npolys = (int32_t)F.size(); *nterms_total = (int32_t)total;
-  if (!nterms && !coefs && !exps) return BBX_OK;             // size query
-  if ((int64_t)F.size() > cap_polys || (int64_t)total > cap_terms) return fail(BBX_E_CAPACITY, "output buffers too small: %zu polynomials, %zu terms", F.size(), total);
-  size_t at = 0;
-  for (size_t p = 0; p < F.size(); p++) {
-    if (nterms) nterms[p] = (int32_t)F[p].t.size();
-    for (auto& t : F[p].t) {
-      if (coefs) coefs[at] = t.c;
-      if (exps) for (int v = 0; v < bbx::kN; v++) exps[at * bbx::kN + v] = t.e[v];
-      at++;
-    }
-  }
-  return BBX_OK;
-}
-
-int bbx_format_ideal(int npolys, const int32_t* nterms, const int32_t* coefs, const int32_t* exps, char* out, int cap) {
-  if (npolys < 0 || (npolys && (!nterms || !coefs || !exps)) || cap < 0 || (cap && !out)) return fail(BBX_E_ARG, "bad argument");
-  std::string s;
-  size_t at = 0;
-  for (int p = 0; p < npolys; p++) {
-    std::vector<bbx::HTerm> ts;
-    for (int k = 0; k < nterms[p]; k++, at++) {
-      bbx::HTerm t; t.c = bbx::coef_norm(coefs[at]); t.deg = 0;
-      for (int v = 0; v < bbx::kN; v++) { t.e[v] = exps[at * bbx::kN + v]; if (t.e[v] < 0) return fail(BBX_E_ARG, "negative exponent"); t.deg += t.e[v]; }
-      if (t.c) ts.push_back(t);
-    }
-    if (p) s += '|';
-    s += bbx::format_polynomial(bbx::poly_from_terms(ts));
-  }
-  if ((int)s.size() + 1 <= cap) memcpy(out, s.c_str(), s.size() + 1);
-  return (int)s.size();                                          // length needed, excluding the terminator
-}
 
 }  // extern "C"
