@@ -228,28 +228,13 @@ __device__ uint64_t bin_obs(const BEnv<W>& e, const BbxParams& p, int env, int n
       for (int u = 0; u < U; u++) {
         const int g = half ? (int)(pr[u] >> 16) : (int)(pr[u] & 0xffffu);
         mm[u] = m_zero<W>();
-#if defined(BBX_ABL_OBS) && BBX_ABL_OBS == 2   // ablation experiment: no gathers
-        if (on[u]) { mm[u].w[0] = (uint32_t)g; }
-#else
         if (on[u]) { if (t == 0) mm[u] = e.lm[g]; else if (t == 1) mm[u] = e.tm[g]; }
-#endif
       }
 #pragma unroll
       for (int u = 0; u < U; u++) {
         if (on[u]) {
           const int base = (rr[u] * per_row + slot) * n;
-#if defined(BBX_ABL_OBS) && BBX_ABL_OBS == 1   // ablation experiment: no stores (one per sweep keeps the gathers alive)
-          if (out && mm[u].w[0] == 0x12345678u) obs_store<W>(out + base, mm[u], n);
-#elif defined(BBX_ABL_OBS) && BBX_ABL_OBS == 3 // ablation experiment: the same bytes as ideal stores (16-byte aligned, lane-contiguous)
-          if (out) {                             // 64 lanes x 20 B = 1280 B per sweep = 80 aligned 16-byte units: lanes 0..63 + lanes 0..15
-            const int sweep = rr[u] / rows_per_sweep;
-            ObsI4* o4 = (ObsI4*)(out + (size_t)sweep * rows_per_sweep * per_row * n);
-            o4[lane] = ObsI4{(int)mm[u].w[0], (int)mm[u].w[1], (int)mm[u].w[2], (int)mm[u].w[3]};
-            if (lane < 16) o4[64 + lane] = ObsI4{(int)mm[u].w[0], 0, 0, 0};
-          }
-#else
           if (out) obs_store<W>(out + base, mm[u], n);
-#endif
           if (HASH && want_hash) for (int v = 0; v < n; v++) h += bbx_mix64((uint64_t)(base + v), m_exp(mm[u], v));
         }
       }

@@ -620,22 +620,6 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem, in
     }
 
     FSTAMP(2);                                             // 2: S-polynomial
-#ifdef BBX_EXP_SALU   // experiment: N independent scalar / vector / no-op instructions per step
-    { uint32_t sa_ = (uint32_t)nP, sb_ = (uint32_t)nG;
-#pragma unroll
-      for (int q_ = 0; q_ < BBX_EXP_SALU / 2; q_++) asm volatile("s_add_u32 %0, %0, 0x11\n\ts_mul_i32 %1, %1, 3" : "+s"(sa_), "+s"(sb_));
-      asm volatile("" :: "s"(sa_), "s"(sb_)); }
-#endif
-#ifdef BBX_EXP_VALU
-    { uint32_t va_ = (uint32_t)lane, vb_ = (uint32_t)lane + 1u;
-#pragma unroll
-      for (int q_ = 0; q_ < BBX_EXP_VALU / 2; q_++) asm volatile("v_add_u32 %0, 0x11, %0\n\tv_mul_lo_u32 %1, %1, 3" : "+v"(va_), "+v"(vb_));
-      asm volatile("" :: "v"(va_), "v"(vb_)); }
-#endif
-#ifdef BBX_EXP_NOP
-#pragma unroll
-    for (int q_ = 0; q_ < BBX_EXP_NOP; q_++) asm volatile("s_nop 0");
-#endif
     // ---- reduce (buchberger.cpp:24-49), entirely in registers -----------------------------------------------------------
     // (Measured alternatives, DESIGN.md section 4: the same loop in select form on the vector unit — v_cndmask instead of
     // branches — is 12-15 % slower, on the scalar unit 25 % slower: the branches skip work, and 32-bit multiplies of the
