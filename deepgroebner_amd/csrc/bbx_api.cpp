@@ -248,7 +248,8 @@ int enqueue(bbx_batch* b, const BbxParams& p0, bool resume, hipStream_t stream) 
     // a policy rollout: the HBM-resident continuation pass has the policy too
     if (p.policy && !(p.policy->rollout ? (!resume && (kinds[i] == 3 || kinds[i] == 0)) : (!resume && i == 0 && kinds[i] == 3))) p.policy = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    const bool timed = b->timing && i == 0 && kinds[i] != 2;   // the primary (dominant) kernel of the sequence
+    // the primary (dominant) kernel of the sequence; where long polynomials continue in the wide kernel, that one too
+    const bool timed = b->timing && kinds[i] != 2 && (i == 0 || (b->gen_to_wide && kinds[i] == 4));
     if (timed) {
       HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
       HIPCHK(hipEventRecord(e0, stream));
