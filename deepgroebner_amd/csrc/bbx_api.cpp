@@ -476,9 +476,11 @@ int finish(bbx_batch* b, hipStream_t stream) {
 }
 
 // ---- persistent sessions (bbx_persistent; see BbxParams::ctl) --------------------------------------------------------
-// A kernel that runs for more than ~100 ms is clocked down to about half speed (measured: scripts/exp_overlap.py,
-// DESIGN.md), so a session runs as a sequence of kernels of at most PS_SLICE_TICKS each: a kernel whose slice is over
-// leaves with what its environments still owe (BBX_ST_TIMESLICE) and the next call on the handle starts the next one.
+// A session runs as a sequence of kernels of at most PS_SLICE_TICKS each: a kernel whose slice is over leaves with what
+// its environments still owe (BBX_ST_TIMESLICE) and the next call on the handle starts the next one.  The slice ends are
+// where environments that left the register/LDS class (and were served by the HBM-resident pass meanwhile) come back
+// to it — long kernels were slower per step because such stragglers stayed behind until the kernel ended (DESIGN.md
+// 4.1.1) — and they bound how long a consumer that went away keeps the device busy.
 constexpr uint32_t PS_SLICE_TICKS = 1000000u;            // 10 ms of the 100 MHz clock
 
 int ps_write_ctl(bbx_batch* b, bool stop) {              // all writes to the control word travel on one stream, in order
@@ -649,27 +651,27 @@ int create_common(std::unique_ptr<bbx::IdealGen> proto, int nvars_obs, int elimi
   // every array of a record starts 16-byte aligned; the hand-tuned kernel derives the array offsets of the 8-byte
   // monomial layout from the basis capacity alone (bbx_fast.h F_HBM_PTRS), which is exact for even capacities
   if (c.max_basis & 1) c.max_basis += c.max_basis < 65535 ? 1 : -1;
-  b->binom = binomial && !c.general_class && !getenv("BBX_NO_BINOM");
+  b->binom = binomial && !c.general_class;
   // long-polynomial environments (fixed ideals such as cyclic-n) in small batches: one workgroup per environment
-  if ((b->fixed || list) && b->W <= 4 && !getenv("BBX_NO_WIDE")) b->wide = c.wide_waves > 0 ? std::min(8, c.wide_waves) : (c.wide_waves < 0 ? 0 : (batch <= 4096 ? 8 : 0));
+  if ((b->fixed || list) && b->W <= 4) b->wide = c.wide_waves > 0 ? std::min(8, c.wide_waves) : (c.wide_waves < 0 ? 0 : (batch <= 4096 ? 8 : 0));
   if (c.wide_lds_terms < 0 || c.wide_lds_terms > 4096) return fail(BBX_E_ARG, "wide_lds_terms out of range");
   b->wide_terms = c.wide_lds_terms;
   b->no_growth = c.no_growth != 0;
   // LDS-resident class: small binomial environments work out of LDS for the whole launch; anything that
   // outgrows it continues in the HBM-resident pass of the same launch sequence
   b->staged = 0;
-  if (binomial && b->W == 2 && c.lds_max_basis >= 0 && !getenv("BBX_NO_STAGE")) {
+  if (binomial && b->W == 2 && c.lds_max_basis >= 0) {
     int lg = c.lds_max_basis ? c.lds_max_basis : 128;
     lg = std::min((lg + 15) & ~15, c.max_basis);       // the working copy never exceeds the HBM record
     b->LL = b->binom ? make_layout_binom(b->W, lg, std::min(2 * lg, c.max_pairs))
                      : make_layout(b->W, lg, std::min(2 * lg, c.max_pairs), std::min(2 * lg + 16, c.arena_terms), c.max_poly_terms);
     b->staged = 1;
     // the hand-tuned kernel covers exactly the reference C++ class's fixed options
-    b->fast = b->binom && elimination == BBX_GEBAUERMOELLER && sort_reducers && lg <= 128 && !getenv("BBX_NO_FAST");
+    b->fast = b->binom && elimination == BBX_GEBAUERMOELLER && sort_reducers && lg <= 128;
   }
   // non-binomial random ideals in <= 7 variables: wave-per-environment kernel, long-polynomial environments continue one
   // workgroup each (bbx_wide.h) behind it
-  b->gen_to_wide = !b->binom && !b->wide && !b->staged && !b->fixed && !list && b->W <= 4 && c.wide_waves >= 0 && !getenv("BBX_NO_WIDE");
+  b->gen_to_wide = !b->binom && !b->wide && !b->staged && !b->fixed && !list && b->W <= 4 && c.wide_waves >= 0;
   if (c.max_basis > 65535 || c.max_poly_terms > (1 << 22) || c.max_basis < 2 || c.max_pairs < 2 || c.max_poly_terms < 4 || c.queue_slots < 1)
     return fail(BBX_E_ARG, "capacities out of range");
   b->L = b->binom ? make_layout_binom(b->W, c.max_basis, c.max_pairs)

@@ -18,7 +18,7 @@ run u5 bbx_binom_kernel 5-10-5-uniform --batch 4096 --steps 2048 --obs-rows 2048
 run general bbx_step_kernel 3-5-4-0.5-uniform --batch 4096 --steps 512 --obs-rows 512
 # ... and where polynomials get long (thousands of terms): environments continue one workgroup each in the wide kernel
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/cfg_${tag}_general_long_stats -o s -- python3 scripts/bench_configs.py 5-4-4-1.0-uniform --batch 4096 --steps 64 --obs-rows 1024 --cpu-envs 0 --no-twin > gpurun_out/cfg_${tag}_general_long_stats.log 2>&1 || echo "stats run general_long failed"
-timeout -k 10 900 python3 scripts/bench_configs.py 5-4-4-1.0-uniform --batch 4096 --steps 64 --obs-rows 1024 --cpu-envs 2 --kernel "bbx_step_kernel + bbx_wide_kernel" > gpurun_out/cfg_${tag}_general_long.json 2> gpurun_out/cfg_${tag}_general_long.err || echo "bench line general_long failed"
+timeout -k 10 900 python3 scripts/bench_configs.py 5-4-4-1.0-uniform --batch 4096 --steps 64 --obs-rows 1024 --cpu-envs 64 --kernel "bbx_step_kernel + bbx_wide_kernel" > gpurun_out/cfg_${tag}_general_long.json 2> gpurun_out/cfg_${tag}_general_long.err || echo "bench line general_long failed"
 timeout -k 10 300 python3 scripts/bench_configs.py cyclic-7 --batch 1 --agent degree --to-completion --obs-rows 4096 --cpu-envs 1 > gpurun_out/cfg_${tag}_cyclic7_single.json 2>/dev/null || echo "cyclic-7 single failed"
 # the policy in the loop (scripts/bench_policy.py): kernel-trace stats of the rollout kernel and of the per-step path, and the lines
 for mode in rollout per_step; do
