@@ -633,6 +633,127 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem, in
     uint32_t h1c = (uint32_t)uni((int)h1.c), h1a = (uint32_t)uni((int)h1.m.w[0]), h1b = (uint32_t)uni((int)h1.m.w[1]);
     uint32_t r0c = 0, r0a = 0, r0b = 0, r1c = 0, r1a = 0, r1b = 0;
     int nred = 0, rsug = 0;
+    if constexpr (!ACCT) {
+      // The lean variants run this loop as hand-scheduled assembly.  Written in C++ (the loop below, which the accounting
+      // variants keep: it is the specification) the compiler carries the joins of its paths as 64-bit flag words and
+      // scalar moves — about 58 scalar-pipe instructions per reduction round, on the unit that binds this kernel
+      // (DESIGN.md section 4.1); here a round in which the first 64 reducers hold the divisor takes 22.
+      // Register roles: h0 = (h0c; h0a, h0b) lead term of h, h1 its tail term (coefficient 0: none), r0 / r1 the remainder,
+      // nred / rsug / hsug as in the C++ loop.  Lane l holds reducers l (A) and l + 64 (B): lead monomial (lm0, lm1), tail
+      // monomial (tm0, tm1), inx = tail coefficient | (-tc / lc) << 16, sug = sugar.  gfx950 wait states observed: a packed
+      // (VOP3P) result needs one state before a VALU reads it (s_nop 0); everything else here is interlocked.
+      const uint32_t sugA = S.sinA.y & 0xffffu, sugB = S.sinB.y & 0xffffu;
+      const uint32_t two = (uint32_t)uni(nG > 64 ? 1 : 0);
+      uint32_t nred_u = 0, rsug_u = 0, hsug_u = (uint32_t)hsug;
+      uint32_t sl, sf, sx_, sxx, sq;
+      uint32_t t0, t1, t2;
+      asm volatile(
+        "L_top_%=:\n\t"
+        "s_cmp_eq_u32 %[h0c], 0\n\t"
+        "s_cbranch_scc1 L_done_%=\n\t"
+        "v_pk_sub_u16 %[t0], %[alm0], %[h0a] clamp\n\t"
+        "v_pk_sub_u16 %[t1], %[alm1], %[h0b] clamp\n\t"
+        "s_nop 0\n\t"
+        "v_or_b32 %[t0], %[t0], %[t1]\n\t"
+        "v_cmp_eq_u32 vcc, 0, %[t0]\n\t"
+        "v_sub_u32 %[t1], %[h0b], %[alm1]\n\t"
+        "v_sub_u32 %[t0], %[h0a], %[alm0]\n\t"
+        "v_add_u32 %[t2], %[t1], %[atm1]\n\t"
+        "v_add_u32 %[t0], %[t0], %[atm0]\n\t"
+        "v_lshrrev_b32 %[t1], 16, %[t1]\n\t"
+        "v_add_u32 %[t1], %[t1], %[asug]\n\t"
+        "s_cbranch_vccz L_tryB_%=\n\t"
+        "s_ff1_i32_b64 %[sl], vcc\n\t"
+        "v_readlane_b32 %[sf], %[t1], %[sl]\n\t"
+        "v_readlane_b32 %[sx], %[ainx], %[sl]\n\t"
+        "s_max_i32 %[hsug], %[hsug], %[sf]\n\t"
+        "s_cmp_gt_i32 %[hsug], 0xffff\n\t"
+        "s_cbranch_scc1 L_done_%=\n\t"
+        "v_readlane_b32 %[h0a], %[t0], %[sl]\n\t"
+        "v_readlane_b32 %[h0b], %[t2], %[sl]\n\t"
+        "L_red_%=:\n\t"                                   // h <- h - (LT h / LT f) f: the new term takes the lead term's place
+        "s_lshr_b32 %[sq], %[sx], 16\n\t"
+        "s_mul_i32 %[sxx], %[h0c], %[sq]\n\t"
+        "s_mul_hi_u32 %[sq], %[sxx], 0x4187a4af\n\t"
+        "s_lshr_b32 %[sq], %[sq], 13\n\t"
+        "s_mul_i32 %[sq], %[sq], 0x7d03\n\t"
+        "s_sub_u32 %[h0c], %[sxx], %[sq]\n\t"
+        "s_add_u32 %[nred], %[nred], 1\n\t"
+        "s_cmp_eq_u32 %[h0c], 0\n\t"
+        "s_cbranch_scc1 L_shift_%=\n\t"
+        "s_cmp_eq_u32 %[h1c], 0\n\t"
+        "s_cbranch_scc1 L_top_%=\n\t"
+        "s_xor_b32 %[sxx], %[h1b], 0xffff\n\t"           // grevlex keys: high word ^ 0xffff, low word complemented
+        "s_xor_b32 %[sq], %[h0b], 0xffff\n\t"
+        "s_cmp_lt_u32 %[sxx], %[sq]\n\t"
+        "s_cbranch_scc1 L_top_%=\n\t"                     // the new term leads: nothing moves
+        "s_cmp_eq_u32 %[sxx], %[sq]\n\t"
+        "s_cbranch_scc0 L_swap_%=\n\t"
+        "s_cmp_lt_u32 %[h1a], %[h0a]\n\t"
+        "s_cbranch_scc1 L_swap_%=\n\t"
+        "s_cmp_eq_u32 %[h1a], %[h0a]\n\t"
+        "s_cbranch_scc0 L_top_%=\n\t"
+        "s_add_u32 %[sxx], %[h0c], %[h1c]\n\t"            // equal monomials: one term, coefficients added mod p
+        "s_add_u32 %[sq], %[sxx], 0xffff82fd\n\t"
+        "s_min_u32 %[h0c], %[sxx], %[sq]\n\t"
+        "s_mov_b32 %[h1c], 0\n\t"
+        "s_branch L_top_%=\n\t"
+        "L_swap_%=:\n\t"                                  // the old tail leads
+        "s_mov_b32 %[sxx], %[h0c]\n\t" "s_mov_b32 %[h0c], %[h1c]\n\t" "s_mov_b32 %[h1c], %[sxx]\n\t"
+        "s_mov_b32 %[sxx], %[h0a]\n\t" "s_mov_b32 %[h0a], %[h1a]\n\t" "s_mov_b32 %[h1a], %[sxx]\n\t"
+        "s_mov_b32 %[sxx], %[h0b]\n\t" "s_mov_b32 %[h0b], %[h1b]\n\t" "s_mov_b32 %[h1b], %[sxx]\n\t"
+        "s_branch L_top_%=\n\t"
+        "L_shift_%=:\n\t"                                 // the new term vanished (a reducer without tail): h <- its tail term
+        "s_mov_b32 %[h0c], %[h1c]\n\t" "s_mov_b32 %[h0a], %[h1a]\n\t" "s_mov_b32 %[h0b], %[h1b]\n\t" "s_mov_b32 %[h1c], 0\n\t"
+        "s_branch L_top_%=\n\t"
+        "L_tryB_%=:\n\t"                                  // no divisor among reducers 0..63
+        "s_cmp_eq_u32 %[two], 0\n\t"
+        "s_cbranch_scc1 L_tm_%=\n\t"
+        "v_pk_sub_u16 %[t0], %[blm0], %[h0a] clamp\n\t"
+        "v_pk_sub_u16 %[t1], %[blm1], %[h0b] clamp\n\t"
+        "s_nop 0\n\t"
+        "v_or_b32 %[t0], %[t0], %[t1]\n\t"
+        "v_cmp_eq_u32 vcc, 0, %[t0]\n\t"
+        "v_sub_u32 %[t1], %[h0b], %[blm1]\n\t"
+        "v_sub_u32 %[t0], %[h0a], %[blm0]\n\t"
+        "v_add_u32 %[t2], %[t1], %[btm1]\n\t"
+        "v_add_u32 %[t0], %[t0], %[btm0]\n\t"
+        "v_lshrrev_b32 %[t1], 16, %[t1]\n\t"
+        "v_add_u32 %[t1], %[t1], %[bsug]\n\t"
+        "s_cbranch_vccz L_tm_%=\n\t"
+        "s_ff1_i32_b64 %[sl], vcc\n\t"
+        "v_readlane_b32 %[sf], %[t1], %[sl]\n\t"
+        "v_readlane_b32 %[sx], %[binx], %[sl]\n\t"
+        "s_max_i32 %[hsug], %[hsug], %[sf]\n\t"
+        "s_cmp_gt_i32 %[hsug], 0xffff\n\t"
+        "s_cbranch_scc1 L_done_%=\n\t"
+        "v_readlane_b32 %[h0a], %[t0], %[sl]\n\t"
+        "v_readlane_b32 %[h0b], %[t2], %[sl]\n\t"
+        "s_branch L_red_%=\n\t"
+        "L_tm_%=:\n\t"                                    // r <- r + LT h ; h <- h - LT h
+        "s_cmp_eq_u32 %[r0c], 0\n\t"
+        "s_cbranch_scc0 L_tm1_%=\n\t"
+        "s_mov_b32 %[r0c], %[h0c]\n\t" "s_mov_b32 %[r0a], %[h0a]\n\t" "s_mov_b32 %[r0b], %[h0b]\n\t"
+        "s_branch L_tm2_%=\n\t"
+        "L_tm1_%=:\n\t"
+        "s_mov_b32 %[r1c], %[h0c]\n\t" "s_mov_b32 %[r1a], %[h0a]\n\t" "s_mov_b32 %[r1b], %[h0b]\n\t"
+        "L_tm2_%=:\n\t"
+        "s_lshr_b32 %[sxx], %[h0b], 16\n\t"
+        "s_max_i32 %[rsug], %[rsug], %[sxx]\n\t"
+        "s_mov_b32 %[h0c], %[h1c]\n\t" "s_mov_b32 %[h0a], %[h1a]\n\t" "s_mov_b32 %[h0b], %[h1b]\n\t" "s_mov_b32 %[h1c], 0\n\t"
+        "s_branch L_top_%=\n\t"
+        "L_done_%=:"
+        : [h0c] "+s"(h0c), [h0a] "+s"(h0a), [h0b] "+s"(h0b), [h1c] "+s"(h1c), [h1a] "+s"(h1a), [h1b] "+s"(h1b),
+          [r0c] "+s"(r0c), [r0a] "+s"(r0a), [r0b] "+s"(r0b), [r1c] "+s"(r1c), [r1a] "+s"(r1a), [r1b] "+s"(r1b),
+          [nred] "+s"(nred_u), [rsug] "+s"(rsug_u), [hsug] "+s"(hsug_u),
+          [sl] "=&s"(sl), [sf] "=&s"(sf), [sx] "=&s"(sx_), [sxx] "=&s"(sxx), [sq] "=&s"(sq),
+          [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2)
+        : [alm0] "v"(S.slmA.w[0]), [alm1] "v"(S.slmA.w[1]), [atm0] "v"(S.stmA.w[0]), [atm1] "v"(S.stmA.w[1]), [ainx] "v"(S.sinA.x), [asug] "v"(sugA),
+          [blm0] "v"(S.slmB.w[0]), [blm1] "v"(S.slmB.w[1]), [btm0] "v"(S.stmB.w[0]), [btm1] "v"(S.stmB.w[1]), [binx] "v"(S.sinB.x), [bsug] "v"(sugB),
+          [two] "s"(two)
+        : "vcc", "scc");
+      nred = (int)nred_u; rsug = (int)rsug_u; hsug = (int)hsug_u;
+    } else
     while (h0c != 0) {
       const int hn = h1c ? 2 : 1;
       M2 hm; hm.w[0] = h0a; hm.w[1] = h0b;
