@@ -242,18 +242,26 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem, in
   const bool obs32 = HL ? true : (n == 3 && kk == 2 && p.obs != nullptr);
   const int o3_row = lane >> 2, o3_hi = (lane >> 1) & 1;
   const char* o3_mono = lbase + ((lane & 1) ? FOFF_TM : FOFF_LM);
-  int32_t* const o3_out = obs32 ? p.obs + (size_t)env * p.obs_rows * 12 + lane * 3 : nullptr;
+  int32_t* const o3_base = obs32 ? p.obs + (size_t)env * p.obs_rows * 12 : nullptr;   // (wave-uniform: the block of this environment)
+  typedef int32_t ObsV3 __attribute__((ext_vector_type(3)));
   size_t o3_toff = 0;                                    // POL: the step's slice of a [nsteps][B][rows][12] block
   auto write_obs32 = [&]() {
     const int rows = nP < p.obs_rows ? nP : p.obs_rows;
+    // The rows go out through a buffer descriptor whose size is exactly the live part of the block: the hardware drops the
+    // stores of lanes beyond it, so no lane is ever masked — the exec-mask bookkeeping of predicated gathers and stores
+    // was ~16 scalar instructions per 32 rows, on the unit that binds this kernel.  The gathers run for all lanes: a pair
+    // index beyond |P| stays inside the pair array (|P| <= 256 = its capacity, and a trip covers rows r0 .. r0 + 31 with
+    // r0 <= 224), what it reads is a stale pair, and the basis index taken from it is clamped to the arrays' 128 entries.
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(o3_base + o3_toff), 0, rows * 48, 0x00020000);
     for (int r0 = 0; r0 < rows; r0 += 32) {
       const int ra = r0 + o3_row, rb = ra + 16;
-      const bool oa = ra < rows, ob = rb < rows;
-      const uint32_t pa = oa ? pairs[ra] : 0u, pb = ob ? pairs[rb] : 0u;
-      const uint32_t ga = o3_hi ? pa >> 16 : pa & 0xffffu, gb = o3_hi ? pb >> 16 : pb & 0xffffu;
+      const uint32_t pa = pairs[ra], pb = pairs[rb];
+      const uint32_t ga = (o3_hi ? pa >> 16 : pa) & 127u, gb = (o3_hi ? pb >> 16 : pb) & 127u;
       const M2 ma = *(const M2*)(o3_mono + ga * 8), mb = *(const M2*)(o3_mono + gb * 8);
-      if (oa) *(ObsI3*)(o3_out + o3_toff + r0 * 12) = ObsI3{(int32_t)(ma.w[0] & 0xffffu), (int32_t)(ma.w[0] >> 16), (int32_t)(ma.w[1] & 0xffffu)};
-      if (ob) *(ObsI3*)(o3_out + o3_toff + r0 * 12 + 192) = ObsI3{(int32_t)(mb.w[0] & 0xffffu), (int32_t)(mb.w[0] >> 16), (int32_t)(mb.w[1] & 0xffffu)};
+      const ObsV3 va = {(int32_t)(ma.w[0] & 0xffffu), (int32_t)(ma.w[0] >> 16), (int32_t)(ma.w[1] & 0xffffu)};
+      const ObsV3 vb = {(int32_t)(mb.w[0] & 0xffffu), (int32_t)(mb.w[0] >> 16), (int32_t)(mb.w[1] & 0xffffu)};
+      __builtin_amdgcn_raw_buffer_store_b96(va, rs, r0 * 48 + lane * 12, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b96(vb, rs, r0 * 48 + lane * 12 + 768, 0, 0);
     }
     if (obs_fill) {
       int32_t* out = p.obs + (size_t)env * p.obs_rows * 12;
