@@ -547,8 +547,11 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem, in
     }
     if (nP == 0) break;
     if constexpr (PERSIST) {                               // the time slice (see BBX_ST_TIMESLICE): steps are still owed
-      const uint32_t lim = f_cold_params()->slice_ticks;
-      if (lim && (uint32_t)__builtin_amdgcn_s_memrealtime() - t_begin > lim) { status = BBX_ST_TIMESLICE; break; }
+      // (looked at every 16th step: the clock read and the load of the limit are ~15 scalar instructions and two waits)
+      if ((t_agent & 15) == 0) {
+        const uint32_t lim = f_cold_params()->slice_ticks;
+        if (lim && (uint32_t)__builtin_amdgcn_s_memrealtime() - t_begin > lim) { status = BBX_ST_TIMESLICE; break; }
+      }
     }
     if (nG + 1 > limG || nP - 1 + nG > limP) { status = BBX_ST_SPILL; break; }   // before anything is modified
 
@@ -604,8 +607,10 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem, in
       }
       action = (int)(f_wave_min(best) & 0xffffu);
     }
-    if (action < 0 || action >= nP) { status = BBX_ST_BAD_ACTION; break; }
-    const uint32_t pr = action < 64 ? f_readlane(PA, action) : (uint32_t)uni((int)pairs[action]);
+    // (the hash agent's action is floor(hash * |P| / 2^32): in range by construction)
+    if (!(HL || agent == BBX_AGENT_HASH) && (action < 0 || action >= nP)) { status = BBX_ST_BAD_ACTION; break; }
+    uint32_t pr = f_readlane(PA, action & 63);             // the first 64 pairs are in the register copy
+    if (action >= 64) pr = (uint32_t)uni((int)pairs[action]);
     const int gi_ = pr & 0xffffu, gj_ = pr >> 16;            // the pair leaves P below, fused with the update's compaction
     FSTAMP(1);                                             // 1: agent + pair removal
     // ---- S-polynomial (buchberger.cpp:18-21): the lead terms cancel, the scaled tails remain ------------------------
