@@ -652,11 +652,11 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem, in
       // scalar moves — about 58 scalar-pipe instructions per reduction round, on the unit that binds this kernel
       // (DESIGN.md section 4.1); here a round in which the first 64 reducers hold the divisor takes 22.
       // Register roles: h0 = (h0c; h0a, h0b) lead term of h, h1 its tail term (coefficient 0: none), r0 / r1 the remainder,
-      // nred / rsug / hsug as in the C++ loop.  Lane l holds reducers l (A) and l + 64 (B): lead monomial (lm0, lm1), tail
+      // (its monomials are outputs only: whoever reads them looks at the coefficient first), nred / rsug / hsug as in the C++ loop.  Lane l holds reducers l (A) and l + 64 (B): lead monomial (lm0, lm1), tail
       // monomial (tm0, tm1), inx = tail coefficient | (-tc / lc) << 16, sug = sugar.  gfx950 wait states observed: a packed
       // (VOP3P) result needs one state before a VALU reads it (s_nop 0); everything else here is interlocked.
       const uint32_t sugA = S.sinA.y & 0xffffu, sugB = S.sinB.y & 0xffffu;
-      const uint32_t two = (uint32_t)uni(nG > 64 ? 1 : 0);
+      const int ng_s = uni(nG);
       uint32_t nred_u = 0, rsug_u = 0, hsug_u = (uint32_t)hsug;
       uint32_t sl, sf, sx_, sxx, sq;
       uint32_t t0, t1, t2;
@@ -720,7 +720,7 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem, in
         "s_mov_b32 %[h0c], %[h1c]\n\t" "s_mov_b32 %[h0a], %[h1a]\n\t" "s_mov_b32 %[h0b], %[h1b]\n\t" "s_mov_b32 %[h1c], 0\n\t"
         "s_branch L_top_%=\n\t"
         "L_tryB_%=:\n\t"                                  // no divisor among reducers 0..63
-        "s_cmp_eq_u32 %[two], 0\n\t"
+        "s_cmp_lt_i32 %[ng], 65\n\t"
         "s_cbranch_scc1 L_tm_%=\n\t"
         "v_pk_sub_u16 %[t0], %[blm0], %[h0a] clamp\n\t"
         "v_pk_sub_u16 %[t1], %[blm1], %[h0b] clamp\n\t"
@@ -757,13 +757,13 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem, in
         "s_branch L_top_%=\n\t"
         "L_done_%=:"
         : [h0c] "+s"(h0c), [h0a] "+s"(h0a), [h0b] "+s"(h0b), [h1c] "+s"(h1c), [h1a] "+s"(h1a), [h1b] "+s"(h1b),
-          [r0c] "+s"(r0c), [r0a] "+s"(r0a), [r0b] "+s"(r0b), [r1c] "+s"(r1c), [r1a] "+s"(r1a), [r1b] "+s"(r1b),
+          [r0c] "+s"(r0c), [r0a] "=&s"(r0a), [r0b] "=&s"(r0b), [r1c] "+s"(r1c), [r1a] "=&s"(r1a), [r1b] "=&s"(r1b),
           [nred] "+s"(nred_u), [rsug] "+s"(rsug_u), [hsug] "+s"(hsug_u),
           [sl] "=&s"(sl), [sf] "=&s"(sf), [sx] "=&s"(sx_), [sxx] "=&s"(sxx), [sq] "=&s"(sq),
           [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2)
         : [alm0] "v"(S.slmA.w[0]), [alm1] "v"(S.slmA.w[1]), [atm0] "v"(S.stmA.w[0]), [atm1] "v"(S.stmA.w[1]), [ainx] "v"(S.sinA.x), [asug] "v"(sugA),
           [blm0] "v"(S.slmB.w[0]), [blm1] "v"(S.slmB.w[1]), [btm0] "v"(S.stmB.w[0]), [btm1] "v"(S.stmB.w[1]), [binx] "v"(S.sinB.x), [bsug] "v"(sugB),
-          [two] "s"(two)
+          [ng] "s"(ng_s)
         : "vcc", "scc");
       nred = (int)nred_u; rsug = (int)rsug_u; hsug = (int)hsug_u;
     } else
