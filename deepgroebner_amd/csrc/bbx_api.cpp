@@ -49,6 +49,7 @@ bbx_batch::~bbx_batch() {
   if (ps_ev) (void)hipEventDestroy(ps_ev);
   if (ps_stream) (void)hipStreamDestroy(ps_stream);
   if (ps_ctl_stream) (void)hipStreamDestroy(ps_ctl_stream);
+  if (d_clone_idx) (void)hipFree(d_clone_idx);
   void* dev[] = {d_recs, d_q, d_tail, d_out, d_actions, d_mask, d_seeds, d_obs, d_trace, d_hdr, d_inv,
                  d_vrecs, d_vhdr, d_vsrc, d_vseeds, d_vvals, d_stage, d_gen, d_obs_off, d_obs_packed};
   for (void* q : dev) if (q) (void)hipFree(q);
@@ -853,21 +854,34 @@ int bbx_clone_envs(bbx_batch* b, int n, const int32_t* src, const int32_t* dst) 
   if (!b || n < 0 || (n && (!src || !dst))) return fail(BBX_E_ARG, "bad arguments");
   HIPCHK(hipSetDevice(b->device));
   if (b->in_flight) { int rc = finish(b, b->last_stream); if (rc) return rc; }
-  for (int i = 0; i < n; i++) {
-    if (src[i] < 0 || src[i] >= b->B || dst[i] < 0 || dst[i] >= b->B) return fail(BBX_E_ARG, "environment index out of range");
-    for (int j = 0; j < n; j++) if (src[i] == dst[j]) return fail(BBX_E_ARG, "source and destination sets overlap");
+  {
+    std::vector<uint8_t> role((size_t)b->B, 0);          // 1: read, 2: written (a destination may be named once)
+    for (int i = 0; i < n; i++) {
+      if (src[i] < 0 || src[i] >= b->B || dst[i] < 0 || dst[i] >= b->B) return fail(BBX_E_ARG, "environment index out of range");
+      role[src[i]] |= 1;
+    }
+    for (int i = 0; i < n; i++) {
+      if (role[dst[i]] & 1) return fail(BBX_E_ARG, "source and destination sets overlap");
+      if (role[dst[i]] & 2) return fail(BBX_E_ARG, "environment %d is the destination of two clones", dst[i]);
+      role[dst[i]] |= 2;
+    }
   }
   if (n == 0) return BBX_OK;
   int rc = read_lite(b, 0);                       // current queue heads
   if (rc) return rc;
-  int32_t *d_s = nullptr, *d_d = nullptr;
-  HIPCHK(hipMalloc((void**)&d_s, (size_t)n * 4)); HIPCHK(hipMalloc((void**)&d_d, (size_t)n * 4));
-  HIPCHK(hipMemcpy(d_s, src, (size_t)n * 4, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(d_d, dst, (size_t)n * 4, hipMemcpyHostToDevice));
+  if (b->clone_cap < n) {                         // index arrays of the clone kernel: kept with the handle
+    if (b->d_clone_idx) (void)hipFree(b->d_clone_idx);
+    b->d_clone_idx = nullptr; b->clone_cap = 0;
+    HIPCHK(hipMalloc((void**)&b->d_clone_idx, (size_t)2 * n * sizeof(int32_t)));
+    b->clone_cap = n;
+  }
+  int32_t* d_s = b->d_clone_idx; int32_t* d_d = b->d_clone_idx + n;
+  HIPCHK(hipMemcpyAsync(d_s, src, (size_t)n * 4, hipMemcpyHostToDevice, nullptr));
+  HIPCHK(hipMemcpyAsync(d_d, dst, (size_t)n * 4, hipMemcpyHostToDevice, nullptr));
   int lrc = bbx_launch_clone(b->d_recs, b->d_recs, &b->L, d_s, d_d, n, nullptr, 1, 0, 0, nullptr, 0);
-  HIPCHK(hipDeviceSynchronize());
-  (void)hipFree(d_s); (void)hipFree(d_d);
+  HIPCHK(hipStreamSynchronize(nullptr));
   if (lrc) return fail(BBX_E_DEVICE, "clone launch failed: %s", hipGetErrorString((hipError_t)lrc));
+  if (b->device_gen) return BBX_OK;                // (the generator's state is a header field: it travelled with the record)
   if (!b->fixed) {
     const size_t stride = (size_t)b->nslots * b->slot_words;
     if (b->q_dirty_env.size() != (size_t)b->B) b->q_dirty_env.assign(b->B, b->q_dirty ? 1 : 0);

@@ -103,6 +103,7 @@ struct bbx_batch {
   BbxParams ps_p{};                   // the parameters of the call that began it (later calls must match to join)
   BbxPolicy ps_pol{};                 // ... and its policy arguments (ps_p.policy points here), when it is a session of policy steps
   int ps_sessions = 0, ps_joined = 0, ps_kernels = 0; // statistics: sessions begun, calls that joined a running one, kernels
+  int32_t* d_clone_idx = nullptr; int clone_cap = 0;   // bbx_clone_envs: source / destination indices on the device
   std::mt19937_64 value_rng;          // seeds of value("random") / value("sample") rollouts when the caller gives none
   bool gen_to_wide = false;           // general class with <= 16-byte monomials: long-polynomial environments continue in the wide class
   bool no_growth = false;             // bbx_caps.no_growth: the configured capacities are hard limits (BBX_E_CAPACITY)
