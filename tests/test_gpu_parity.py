@@ -248,6 +248,39 @@ def test_capacity_is_a_cliff_not_a_failure(dist, B, T, caps, cls):
     assert env.capacities()["grown"] > 0, cls
 
 
+@pytest.mark.parametrize("persistent", [0, 1])
+def test_fast_class_second_reducer_bank_lean(persistent):
+    """3-20-40-weighted starts every episode with 40 generators, so bases pass 64 elements within a few steps: the lean fast
+    kernels (the reduction loop written in assembly, bbx_fast.h) find divisors in the second bank of reducer registers
+    (reducers 64..127), environments that outgrow 128 continue in the HBM-resident class and come back — counters of every
+    environment and sampled final states against the oracle, with one kernel per launch and through a persistent session."""
+    import torch
+    from deepgroebner_amd import VecLeadMonomialsEnv
+    bo = ffi.load("bo")
+    dist, B, T = "3-20-40-weighted", 96, 120
+    want = bo.run_random_many(dist, 2, range(700, 700 + B), range(B), T, True, 0)
+    assert max(r["nG"] for r in want) > 64
+    env = VecLeadMonomialsEnv(dist, batch=B, k=2)
+    env.seed(np.arange(B) + 700); env.seed_agent(np.arange(B)); env.reset()
+    env.accounting(False)
+    R = 512
+    d_obs = torch.empty((B, R, env.cols), dtype=torch.int32, device="cuda")
+    d_rew = torch.empty(B, dtype=torch.float64, device="cuda"); d_done = torch.empty(B, dtype=torch.uint8, device="cuda")
+    d_rows = torch.empty(B, dtype=torch.int32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    if persistent:
+        env.persistent(True)
+    for _ in range(T // 20):
+        env.rollout_device("random", 20, True, stream, d_rew, d_done, d_rows, d_obs, R, False, True)
+    env.sync(); torch.cuda.synchronize()
+    _assert_equals_oracle_run(env, want, sample_every=8)
+    rows = d_rows.cpu().numpy()
+    host = env.observations(max_rows=R, fill=False)                  # the block the last step left is the final state's observation
+    got = d_obs.cpu().numpy()
+    for e in range(B):
+        assert np.array_equal(got[e, :rows[e]], host[e, :rows[e]]), e
+
+
 def test_capacity_growth_keeps_owed_steps_across_async_launches():
     """Three asynchronous launches queued behind each other, none synchronised: an environment that stops for room in the
     first keeps adding the later launches' steps to what it owes and takes them all once bbx_sync has enlarged the records."""
