@@ -513,11 +513,32 @@ int session_kernel(bbx_batch* b, bool first, hipStream_t after, bool sliced) {
 // the last steps were issued (slice over, 20 ms without news) or had handed its environment to the HBM-resident class.
 // `wait`: the stream `then` is made to wait for all of it.  `sliced`: the caller (finish) looks after kernels that
 // leave at the end of their slice; otherwise the closing kernel runs to completion whatever it takes.
+double ps_now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+void ps_note_steps(bbx_batch* b, long long nsteps) {
+  const double t = ps_now_ms();
+  b->ps_recent.emplace_back(t, nsteps);
+  while (!b->ps_recent.empty() && b->ps_recent.front().first < t - 50.0) b->ps_recent.pop_front();
+}
+
 int session_close(bbx_batch* b, bool wait, hipStream_t then, bool sliced) {
   if (!b->ps_active) return BBX_OK;
   b->ps_active = false;
   int rc = ps_write_ctl(b, true);
   if (rc) return rc;
+  if (!sliced) {
+    // The host will not be there to start the next kernel when a slice ends, and ONE kernel without time limit would keep
+    // every environment that leaves the register/LDS class on the HBM-resident pass until the very end (a straggler of
+    // thousands of steps: measured 65 ms instead of 22 for 8 x 1024 steps).  So the rest is queued as a chain of sliced
+    // kernels — as many as the steps issued lately can need at 5 us a step, at most 32; one that finds nothing owed costs
+    // a few microseconds — and the kernel without limit behind them takes whatever is left after that.
+    const double t = ps_now_ms();
+    long long lately = 0;
+    for (const auto& e : b->ps_recent) if (e.first >= t - 50.0) lately += e.second;
+    long long chain = (lately + 2047) / 2048;
+    chain = chain < 1 ? 1 : (chain > 32 ? 32 : chain);
+    for (long long i = 0; i < chain; i++) { rc = session_kernel(b, false, nullptr, true); if (rc) return rc; }
+  }
+  b->ps_recent.clear();
   rc = session_kernel(b, false, nullptr, sliced);
   if (rc) return rc;
   b->last = b->ps_p; b->last.recs = b->d_recs; b->last.L = b->L;   // (a resumed pass continues from the budgets left in the headers)
@@ -552,6 +573,7 @@ int launch(bbx_batch* b, BbxParams& p, hipStream_t stream, bool obs_external = f
                                             c->u == a->u + (size_t)b->ps_target * (size_t)b->B);
     if (ps && same_policy && session_same_call(b->ps_p, p) && b->ps_target + p.nsteps < (1ll << 30)) {
       b->ps_target += p.nsteps;                        // the waves see the new total the next time they look
+      ps_note_steps(b, p.nsteps);
       rc = ps_write_ctl(b, false);
       if (rc) return rc;
       // the session's kernel may have left meanwhile (its slice was over, or no news for 20 ms): the next one
@@ -567,6 +589,7 @@ int launch(bbx_batch* b, BbxParams& p, hipStream_t stream, bool obs_external = f
     b->ps_p = p; b->ps_p.ctl = nullptr;
     if (p.policy) { b->ps_pol = *p.policy; b->ps_p.policy = &b->ps_pol; }
     b->ps_target = p.nsteps; b->ps_active = true; b->ps_sessions++;
+    b->ps_recent.clear(); ps_note_steps(b, p.nsteps);
     rc = ps_write_ctl(b, false);
     if (rc) return rc;
     b->last = p; b->last.ctl = nullptr; b->last.policy = nullptr;

@@ -6,6 +6,7 @@
 #include <memory>
 #include <random>
 #include <string>
+#include <deque>
 #include <vector>
 
 #include "bbx_host.h"
@@ -100,6 +101,7 @@ struct bbx_batch {
   hipStream_t ps_stream = nullptr, ps_ctl_stream = nullptr;   // the session's kernel / the writes to its control word
   hipEvent_t ps_ev = nullptr;
   long long ps_target = 0;            // steps issued since the session began
+  std::deque<std::pair<double, long long>> ps_recent;   // (host time in ms, steps) of the latest calls: how much may still be owed when the session closes
   BbxParams ps_p{};                   // the parameters of the call that began it (later calls must match to join)
   BbxPolicy ps_pol{};                 // ... and its policy arguments (ps_p.policy points here), when it is a session of policy steps
   int ps_sessions = 0, ps_joined = 0, ps_kernels = 0; // statistics: sessions begun, calls that joined a running one, kernels
