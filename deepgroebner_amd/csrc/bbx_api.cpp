@@ -9,6 +9,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
+#include <unordered_map>
 #include <random>
 #include <string>
 #include <vector>
@@ -41,23 +43,113 @@ struct OutBuf {            // one contiguous device block so a step needs a sing
 }  // namespace
 
 bbx_batch::~bbx_batch() {
-  if (!d_recs && !d_q && !d_out && !d_inv && !h_io) return;   // nothing was ever allocated
+  if (!d_recs && !d_q && !d_out && !h_io && !gen_owner) return;   // nothing was ever allocated
   (void)hipSetDevice(device);
   (void)hipDeviceSynchronize();
+  bbx_host::pool_synced(true);
   for (auto& ev : ev_open) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
   if (d_ctl) (void)hipFree(d_ctl);
   if (ps_ev) (void)hipEventDestroy(ps_ev);
   if (ps_stream) (void)hipStreamDestroy(ps_stream);
   if (ps_ctl_stream) (void)hipStreamDestroy(ps_ctl_stream);
   if (d_clone_idx) (void)hipFree(d_clone_idx);
-  void* dev[] = {d_recs, d_q, d_tail, d_out, d_actions, d_mask, d_seeds, d_obs, d_trace, d_hdr, d_inv,
-                 d_vrecs, d_vhdr, d_vsrc, d_vseeds, d_vvals, d_stage, d_gen, d_obs_off, d_obs_packed};
+  void* dev[] = {d_recs, d_q, d_tail, d_out, d_actions, d_mask, d_seeds, d_obs, d_trace, d_hdr,
+                 d_vrecs, d_vhdr, d_vsrc, d_vseeds, d_vvals, d_stage, d_obs_off, d_obs_packed};
   for (void* q : dev) if (q) (void)hipFree(q);
   void* pinned[] = {h_io, h_act, h_stage, h_zobs, h_obs};
   for (void* q : pinned) if (q) (void)hipHostFree(q);
+  bbx_host::pool_synced(false);
 }
 
 namespace bbx_host {
+
+// ---- buffer cache (bbx_host.h) ---------------------------------------------------------------------------------------
+#undef hipMalloc
+#undef hipFree
+#undef hipHostMalloc
+#undef hipHostFree
+namespace {
+struct Pool {
+  std::mutex mu;
+  std::unordered_map<void*, std::pair<size_t, uint64_t>> live;          // pointer -> (rounded size, key)
+  std::unordered_map<uint64_t, std::vector<void*>> idle;               // key (device, kind, flags, size class) -> blocks
+  size_t cached_dev = 0, cached_pin = 0;
+};
+Pool& pool() { static Pool* p = new Pool; return *p; }                   // (never destroyed: handles may outlive static destructors)
+size_t pool_round(size_t n) { size_t r = 256; while (r < n) r <<= 1; return r; }
+uint64_t pool_key(int dev, int kind, unsigned flags, size_t rounded) {
+  int cls = 0; while ((size_t(1) << cls) < rounded) cls++;
+  return ((uint64_t)(dev & 0xff) << 56) | ((uint64_t)(kind & 1) << 55) | ((uint64_t)(flags & 0xffff) << 32) | (uint64_t)cls;
+}
+hipError_t pool_get(void** p, size_t n, int kind, unsigned flags) {
+  if (n == 0) n = 1;
+  int dev = 0; (void)hipGetDevice(&dev);
+  const size_t r = pool_round(n);
+  const uint64_t key = pool_key(dev, kind, flags, r);
+  Pool& P = pool();
+  {
+    std::lock_guard<std::mutex> g(P.mu);
+    auto it = P.idle.find(key);
+    if (it != P.idle.end() && !it->second.empty()) {
+      *p = it->second.back(); it->second.pop_back();
+      (kind ? P.cached_pin : P.cached_dev) -= r;
+      P.live[*p] = {r, key};
+      return hipSuccess;
+    }
+  }
+  const hipError_t e = kind ? hipHostMalloc(p, r, flags) : hipMalloc(p, r);
+  if (e != hipSuccess) return e;
+  std::lock_guard<std::mutex> g(P.mu);
+  P.live[*p] = {r, key};
+  return hipSuccess;
+}
+thread_local bool pool_caller_synced = false;
+hipError_t pool_put(void* p, int kind) {
+  if (!p) return hipSuccess;
+  // (hipFree waits for the device before it releases memory, and callers rely on that: so does this, unless the caller has
+  // just synchronised itself — a handle's destructor, which returns a dozen buffers)
+  if (!pool_caller_synced) (void)hipDeviceSynchronize();
+  Pool& P = pool();
+  size_t r = 0; uint64_t key = 0; bool known = false, keep = false;
+  {
+    std::lock_guard<std::mutex> g(P.mu);
+    auto it = P.live.find(p);
+    if (it != P.live.end()) {
+      known = true; r = it->second.first; key = it->second.second; P.live.erase(it);
+      size_t& cached = kind ? P.cached_pin : P.cached_dev;
+      const size_t cap = kind ? (size_t(64) << 20) : (size_t(256) << 20);
+      if (r <= (size_t(32) << 20) && cached + r <= cap) { P.idle[key].push_back(p); cached += r; keep = true; }
+    }
+  }
+  (void)known;
+  if (keep) return hipSuccess;
+  return kind ? hipHostFree(p) : hipFree(p);
+}
+}  // namespace
+void pool_synced(bool on) { pool_caller_synced = on; }
+hipError_t pool_malloc(void** p, size_t n) { return pool_get(p, n, 0, 0u); }
+hipError_t pool_free(void* p) { return pool_put(p, 0); }
+hipError_t pool_host_malloc(void** p, size_t n, unsigned flags) { return pool_get(p, n, 1, flags); }
+hipError_t pool_host_free(void* p) { return pool_put(p, 1); }
+// 1/x mod 32003 for every x, on the device: computed and uploaded once per device and process
+uint16_t* inv_table(int device) {
+  static std::mutex mu; static uint16_t* tab[64] = {nullptr};
+  if (device < 0 || device >= 64) return nullptr;
+  std::lock_guard<std::mutex> g(mu);
+  if (!tab[device]) {
+    std::vector<uint16_t> inv(BBX_P, 0);
+    for (uint32_t x = 1; x < BBX_P; x++) inv[x] = (uint16_t)bbx::coef_inv((int)x);
+    uint16_t* d = nullptr;
+    if (hipMalloc((void**)&d, BBX_P * sizeof(uint16_t)) != hipSuccess) return nullptr;
+    if (hipMemcpy(d, inv.data(), BBX_P * sizeof(uint16_t), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return nullptr; }
+    tab[device] = d;
+  }
+  return tab[device];
+}
+#define hipMalloc(p, n) bbx_host::pool_malloc((void**)(p), (n))
+#define hipFree(p) bbx_host::pool_free((void*)(p))
+#define hipHostMalloc(p, n, fl) bbx_host::pool_host_malloc((void**)(p), (n), (fl))
+#define hipHostFree(p) bbx_host::pool_host_free((void*)(p))
 
 int pack_mono(const bbx_batch* b, const bbx::HTerm& t, uint32_t* w) {
   const int W = b->W, slots = 2 * W;
@@ -742,16 +834,13 @@ int create_common(std::unique_ptr<bbx::IdealGen> proto, int nvars_obs, int elimi
   HIPCHK(hipMalloc((void**)&b->d_mask, (size_t)batch));
   HIPCHK(hipMalloc((void**)&b->d_seeds, (size_t)batch * sizeof(uint32_t)));
   HIPCHK(hipMalloc((void**)&b->d_hdr, (size_t)batch * sizeof(BbxHdr)));
-  {
-    std::vector<uint16_t> inv(BBX_P, 0);
-    for (uint32_t x = 1; x < BBX_P; x++) inv[x] = (uint16_t)bbx::coef_inv((int)x);
-    HIPCHK(hipMalloc((void**)&b->d_inv, BBX_P * sizeof(uint16_t)));
-    HIPCHK(hipMemcpy(b->d_inv, inv.data(), BBX_P * sizeof(uint16_t), hipMemcpyHostToDevice));
-  }
+  b->d_inv = inv_table(device);
+  if (!b->d_inv) return fail(BBX_E_DEVICE, "no room for the inverse table");
   int lrc = bbx_launch_init(b->d_recs, b->L.rec_bytes, batch, nullptr, 0);
   if (lrc) return fail(BBX_E_DEVICE, "init launch failed: %s", hipGetErrorString((hipError_t)lrc));
   if (!gen_table.empty()) {
     HIPCHK(hipMalloc((void**)&b->d_gen, gen_table.size() * sizeof(uint32_t)));
+    b->gen_owner = std::shared_ptr<uint32_t>(b->d_gen, [](uint32_t* q) { (void)hipFree(q); });
     HIPCHK(hipMemcpy(b->d_gen, gen_table.data(), gen_table.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     b->device_gen = true; b->gen_words = gen_table.size();
     std::vector<long long> seeds(batch);
@@ -846,8 +935,7 @@ int bbx_copy(const bbx_batch* s, bbx_batch** out) {
   b->no_growth = s->no_growth; b->value_rng = s->value_rng; b->gen_to_wide = s->gen_to_wide;
   b->wide = s->wide; b->wide_terms = s->wide_terms; b->accounting = s->accounting; b->staged = s->staged; b->fast = s->fast; b->envs_per_block = s->envs_per_block;
   if (s->device_gen) {
-    HIPCHK(hipMalloc((void**)&b->d_gen, s->gen_words * sizeof(uint32_t)));
-    HIPCHK(hipMemcpy(b->d_gen, s->d_gen, s->gen_words * sizeof(uint32_t), hipMemcpyDeviceToDevice));
+    b->gen_owner = s->gen_owner; b->d_gen = s->d_gen;      // (immutable: shared)
     b->device_gen = true; b->gen_words = s->gen_words;
   }
   for (auto& g : s->gens) b->gens.push_back(g->clone());
@@ -862,8 +950,7 @@ int bbx_copy(const bbx_batch* s, bbx_batch** out) {
   HIPCHK(hipMalloc((void**)&b->d_mask, (size_t)batch));
   HIPCHK(hipMalloc((void**)&b->d_seeds, (size_t)batch * sizeof(uint32_t)));
   HIPCHK(hipMalloc((void**)&b->d_hdr, (size_t)batch * sizeof(BbxHdr)));
-  HIPCHK(hipMalloc((void**)&b->d_inv, BBX_P * sizeof(uint16_t)));
-  HIPCHK(hipMemcpy(b->d_inv, s->d_inv, BBX_P * sizeof(uint16_t), hipMemcpyDeviceToDevice));
+  b->d_inv = s->d_inv;
   int rc = upload_queue(b.get());
   if (rc) return rc;
   *out = b.release();

@@ -40,7 +40,7 @@ struct bbx_batch {
   int elim = 0, rewards = 0, sort_input = 0, sort_reducers = 1;
   bool fixed = false, binom = false, listed = false;   // listed: the ideals come from a caller's list (bbx_create_ideals)
   BbxLayout L{}, LL{};
-  uint16_t* d_inv = nullptr;           // GF(32003) inverse table
+  uint16_t* d_inv = nullptr;           // GF(32003) inverse table: one per device and process (bbx_host::inv_table), never freed
   std::vector<std::unique_ptr<bbx::IdealGen>> gens;   // one per environment (one shared when fixed)
   uint32_t slot_words = 0, nslots = 0;
   std::vector<uint32_t> h_q;          // host mirror of the ideal queue
@@ -52,6 +52,7 @@ struct bbx_batch {
   // ideals drawn on the device (binomial distributions): the table the kernels read, the per-environment engine state
   // lives in the record headers (BbxHdr.gen_rng); the host-side generators and the ideal queue are then unused
   uint32_t* d_gen = nullptr; size_t gen_words = 0; bool device_gen = false;
+  std::shared_ptr<uint32_t> gen_owner;   // the table is immutable: copies of a handle share it (d_gen == gen_owner.get())
   std::vector<std::string> gen_error;   // per environment: a generator failure met while drawing ahead (see fill_queues)
   // device
   char* d_recs = nullptr;

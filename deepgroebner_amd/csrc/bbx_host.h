@@ -42,4 +42,20 @@ inline BbxLayout make_layout_binom(int W, int maxG, int maxP) {
 }
 
 
+// Device and pinned-host buffers of destroyed handles are kept for the next handle (sizes rounded up to powers of two, at
+// most 256 MiB of device and 64 MiB of pinned memory cached, blocks of up to 32 MiB): a tree search that calls env.copy()
+// per node (mcts.py:89,96,147) creates and destroys one-environment handles by the thousand, and a dozen hipMalloc /
+// hipHostMalloc calls per handle were 85 % of such a copy.  Contents are never assumed zero (hipMalloc does not zero either).
+hipError_t pool_malloc(void** p, size_t n);
+hipError_t pool_free(void* p);
+hipError_t pool_host_malloc(void** p, size_t n, unsigned flags);
+hipError_t pool_host_free(void* p);
+uint16_t* inv_table(int device);                      // GF(32003) inverses on the device (one table per device and process)
+void pool_synced(bool on);                          // the calling thread has synchronised the device: frees need not
 }  // namespace bbx_host
+#ifndef BBX_NO_POOL_MACROS
+#define hipMalloc(p, n) bbx_host::pool_malloc((void**)(p), (n))
+#define hipFree(p) bbx_host::pool_free((void*)(p))
+#define hipHostMalloc(p, n, fl) bbx_host::pool_host_malloc((void**)(p), (n), (fl))
+#define hipHostFree(p) bbx_host::pool_host_free((void*)(p))
+#endif

@@ -43,6 +43,20 @@ env.sync()
 dt_clone = (time.perf_counter() - t0) / a.repeats
 st = env.stats()
 assert np.array_equal(st[dst][:, [7]], st[src][:, [7]])              # (basis sizes of the clones are their roots')
+# the drop-in form: ONE environment, copy() as mcts.py calls it per node (a new one-environment handle each time)
+from deepgroebner_amd import CLeadMonomialsEnv
+one = CLeadMonomialsEnv(a.dist, k=2); one.seed(1000); one.reset()
+for t in range(a.steps):
+    _, _, done, _ = one.step(0)                       # (first pair: any mid-episode state will do)
+    if done:
+        one.reset()
+c1 = one.copy(); del c1
+t0 = time.perf_counter()
+for _ in range(200):
+    c1 = one.copy()
+    del c1
+dt_one = (time.perf_counter() - t0) / 200
+
 kind = "reference" if ffi.available("ref") else "port"
 lib = ffi.load("ref" if kind == "reference" else "bo")
 cpu = []
@@ -58,6 +72,8 @@ copies = [o.copy() for o in cpu for _ in range(4)]
 dc = time.perf_counter() - t0
 print(json.dumps({"dist": a.dist, "batch": B, "steps_before": a.steps, "cpu_baseline_kind": kind,
                   "bbx_copy": {"ms_per_batch": dt_copy * 1e3, "clones_per_s": B / dt_copy},
+                  "single_env_copy": {"us_per_copy": dt_one * 1e6, "clones_per_s": 1.0 / dt_one,
+                                      "note": "CLeadMonomialsEnv.copy(): a new one-environment handle per copy (allocation + record copy)"},
                   "bbx_clone_envs": {"clones_per_call": int(len(src)), "ms_per_call": dt_clone * 1e3, "clones_per_s": len(src) / dt_clone},
                   "cpu_copy_constructor": {"clones_per_s": len(copies) / dc, "sample": len(copies), "cores": 1,
                                            "note": "ctypes call overhead included (about 1 us per call)"}}))
