@@ -951,6 +951,9 @@ int bbx_copy(const bbx_batch* s, bbx_batch** out) {
   HIPCHK(hipMalloc((void**)&b->d_seeds, (size_t)batch * sizeof(uint32_t)));
   HIPCHK(hipMalloc((void**)&b->d_hdr, (size_t)batch * sizeof(BbxHdr)));
   b->d_inv = s->d_inv;
+  // (ideals drawn on the device: the host-side queue is never read by a kernel, so there is nothing to upload — two
+  // pageable host-to-device copies that were a third of a one-environment copy)
+  if (b->device_gen) { b->q_dirty = false; }
   int rc = upload_queue(b.get());
   if (rc) return rc;
   *out = b.release();
