@@ -281,6 +281,41 @@ def test_fast_class_second_reducer_bank_lean(persistent):
         assert np.array_equal(got[e, :rows[e]], host[e, :rows[e]]), e
 
 
+@pytest.mark.parametrize("caps,lean", [(None, 0), (None, 1), ({"wide_lds_terms": 64}, 1), ({"wide_waves": 3}, 0), ({"wide_waves": -1}, 0)])
+def test_exponents_beyond_a_byte_wide_and_general(caps, lean):
+    """A fixed ideal whose exponents pass 255 (degrees up to 350 and beyond during the reductions): the wide class cannot pack
+    such monomials into its 8-byte sort keys, so the polynomial being reduced lives in HBM as plain monomials, lead terms are
+    fetched one by one and merges run on HBM-resident views (bbx_wide.h, tier 3 and the unkeyed remainder path); wide_waves =
+    -1 is the wave-per-environment general kernel on the same ideal.  Every step's reward, the counters and the complete
+    final state against the oracle."""
+    from deepgroebner_amd import VecLeadMonomialsEnv
+    from deepgroebner_amd.ideals import FixedIdealGenerator
+    bo = ffi.load("bo")
+    F = [[(1, (300, 0, 0, 0)), (1, (0, 2, 1, 0)), (5, (0, 0, 0, 0))],
+         [(1, (0, 200, 150, 0)), (1, (1, 0, 0, 1)), (7, (0, 0, 0, 0))],
+         [(1, (120, 130, 0, 10)), (1, (0, 0, 3, 0)), (11, (0, 0, 0, 0))],
+         [(1, (1, 1, 1, 1)), (2, (0, 0, 0, 2)), (3, (0, 0, 0, 0))]]
+    B, T = 3, 60
+    env = VecLeadMonomialsEnv(FixedIdealGenerator(F), batch=B, k=2, caps=caps)
+    if lean:
+        env.accounting(False)
+    env.seed_agent(np.arange(B) + 3); env.reset()
+    oracles = []
+    for e in range(B):
+        o = bo.env(fixed=F); o.reset(); oracles.append(o)
+    for t in range(T):
+        rew, done, rows = env.rollout("random", 1, auto_reset=False)
+        for e, o in enumerate(oracles):
+            if o.nP == 0:
+                continue
+            r = o.step(ffi.agent_action(3 + e, t, o.nP))
+            assert rew[e] == r and rows[e] == o.nP, (t, e, rew[e], r)
+    for e, o in enumerate(oracles):
+        basis, pairs, order = env.state(e)
+        assert max(max(sum(x) for x in ex) for _, ex in basis) > 255          # (the point of the test)
+        assert np.array_equal(_state_words(basis, pairs, order), _state_words(o.basis(), o.pairs(), o.reducer_order())), e
+
+
 def test_capacity_growth_keeps_owed_steps_across_async_launches():
     """Three asynchronous launches queued behind each other, none synchronised: an environment that stops for room in the
     first keeps adding the later launches' steps to what it owes and takes them all once bbx_sync has enlarged the records."""
