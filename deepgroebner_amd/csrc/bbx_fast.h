@@ -546,13 +546,6 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem, in
       } else break;
     }
     if (nP == 0) break;
-    if constexpr (PERSIST) {                               // the time slice (see BBX_ST_TIMESLICE): steps are still owed
-      // (looked at every 16th step: the clock read and the load of the limit are ~15 scalar instructions and two waits)
-      if ((t_agent & 15) == 0) {
-        const uint32_t lim = f_cold_params()->slice_ticks;
-        if (lim && (uint32_t)__builtin_amdgcn_s_memrealtime() - t_begin > lim) { status = BBX_ST_TIMESLICE; break; }
-      }
-    }
     if (nG + 1 > limG || nP - 1 + nG > limP) { status = BBX_ST_SPILL; break; }   // before anything is modified
 
     // ---- choose the pair -----------------------------------------------------------------------------------------
@@ -860,11 +853,17 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem, in
     last_nred = vzero + nred;
     if (VAL) value_accumulate(vret, vdisc, p.rewards_mode == BBX_REW_ADDITIONS ? (-1.0 - (double)nred) : -1.0, p.gamma);
     adds += 1 + nred; t_agent++;
-    if ((t_agent & 63) == 0) hv = bbx_agent_hash32(agent_seed, (uint32_t)(t_agent + lane));
 #ifndef BBX_PRIO_SHIFT
 #define BBX_PRIO_SHIFT 6
 #endif
-    if ((t_agent & ((1 << BBX_PRIO_SHIFT) - 1)) == 0) {
+    static_assert(BBX_PRIO_SHIFT == 6, "one test per step serves the hash refill, the priority rotation and the time slice");
+    bool slice_over = false;
+    if ((t_agent & 63) == 0) {                             // every 64th step: the three things that need no finer grain
+      hv = bbx_agent_hash32(agent_seed, (uint32_t)(t_agent + lane));
+      if constexpr (PERSIST) {                             // the time slice (see BBX_ST_TIMESLICE): 64 steps are ~0.2 ms of a 10 ms slice
+        const uint32_t lim = f_cold_params()->slice_ticks;
+        slice_over = lim && (uint32_t)__builtin_amdgcn_s_memrealtime() - t_begin > lim;
+      }
 #ifndef BBX_NO_PRIO_ROTATION
       // The instruction arbiter serves the OLDEST wave first, and this kernel is bound by the one scalar unit its waves share:
       // left alone, the waves of the workgroups dispatched first run at 2.1 us per step and those dispatched last at 3.8,
@@ -922,6 +921,7 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem, in
     budget--; if (TRACE) trace_pos++;
     done_last = done ? 1 : 0;
     if (done) { episodes++; if (auto_reset) need_reset = 1; }
+    if (PERSIST && slice_over && budget > 0) { status = BBX_ST_TIMESLICE; FSTAMP(5); break; }   // steps are still owed: the next kernel takes them
     FSTAMP(5);                                             // 5: observation + bookkeeping
   }
   const FColdParams cz = f_cold_params();
