@@ -216,7 +216,9 @@ def run_rollout_fused(env, policy, nsteps, buffer=None, obs_rows=256, generator=
     """run_rollout with the policy INSIDE the step kernel (bbx_policy_rollout_device): `chunk` vector steps per launch,
     environments never wait for each other between steps.  Per-step outputs land in the trajectory buffer's own arrays
     (no copies).  Raises BbxError (BBX_E_UNSUPPORTED) where the batch's kernel class has no built-in policy — callers
-    fall back to run_rollout.  Returns (total reward per environment, finished episodes) like run_rollout."""
+    fall back to run_rollout.  Returns (total reward per environment, finished episodes) like run_rollout.
+    The rollout kernels are the lean ones (no algorithmic-byte accounting): the handle's accounting is switched off here."""
+    env.accounting(False)
     B, cols = env.batch, env.cols
     dev = torch.device("cuda", torch.cuda.current_device())
     stream = torch.cuda.current_stream()
