@@ -10,13 +10,19 @@ B, CH, N = 4096, 2000, int(sys.argv[1]) if len(sys.argv) > 1 else 10
 torch.cuda.init()
 env = VecLeadMonomialsEnv("3-20-10-weighted", batch=B, k=2)
 env.seed(np.arange(B) + 1000); env.seed_agent(np.arange(B)); env.reset()
-d_obs = torch.empty((B, 128, env.cols), dtype=torch.int32, device="cuda")
+env.accounting(False)
+if len(sys.argv) > 2 and sys.argv[2] == "persistent":
+    env.persistent(True)                      # the launches feed one session (bbx_persistent); every 10th is synchronised
+d_obs = torch.empty((B, 256, env.cols), dtype=torch.int32, device="cuda")
 d_rew = torch.empty(B, dtype=torch.float64, device="cuda"); d_done = torch.empty(B, dtype=torch.uint8, device="cuda")
 d_rows = torch.empty(B, dtype=torch.int32, device="cuda")
 s = torch.cuda.current_stream()
 t0 = time.perf_counter()
 for i in range(N):
-    env.rollout_device("random", CH, True, s.cuda_stream, d_rew, d_done, d_rows, d_obs, 128, False, True); env.sync()
+    env.rollout_device("random", CH, True, s.cuda_stream, d_rew, d_done, d_rows, d_obs, 256, False, True)
+    if i % 10 == 9 or not (len(sys.argv) > 2 and sys.argv[2] == "persistent"):
+        env.sync()
+env.sync()
 t1 = time.perf_counter()
 st = env.stats()
 assert (st[:, 0] == CH * N).all() and (st[:, 4] == 0).all()
