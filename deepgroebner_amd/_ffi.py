@@ -70,6 +70,9 @@ SIGNATURES = {
     "bbx_pmlp_prepared_floats": (C.c_int, [C.c_int, C.c_int]),
     "bbx_pmlp_prepare": (C.c_int, [_vp, _vp, _vp, C.c_float, C.c_int, C.c_int, _vp, _vp]),
     "bbx_pmlp_act": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp]),
+    "bbx_pmlp2_prepared_floats": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "bbx_pmlp2_prepare": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    "bbx_pmlp2_act": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
     "bbx_policy_step_device": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp]),
     "bbx_policy_rollout_device": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_longlong, _vp]),
     "bbx_rollout_device": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
@@ -93,6 +96,7 @@ SIGNATURES = {
     "bbx_values_seeded": (C.c_int, [_vp, C.c_char_p, C.c_double, _vp, _vp]),
     "bbx_persistent": (C.c_int, [_vp, C.c_int]),
     "bbx_join": (C.c_int, [_vp, _vp]),
+    "bbx_graph_replayed": (C.c_int, [_vp, _vp]),
     "bbx_session_stats": (C.c_int, [_vp, _vp]),
     "bbx_state_sizes": (C.c_int, [_vp, C.c_int, _i32p, _i32p, _i32p]),
     "bbx_state_get": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp]),

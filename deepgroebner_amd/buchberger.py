@@ -312,6 +312,11 @@ class VecLeadMonomialsEnv:
         """Device-side end of the persistent session in flight: `stream` waits for it (the host does not)."""
         _ffi.check(_ffi.lib().bbx_join(self._h, C.c_void_p(int(stream))))
 
+    def graph_replayed(self, stream=0):
+        """After replaying a HIP graph that holds recorded step_device / rollout_device / policy_* calls of this batch
+        (bbx_graph_replayed): the work is in flight on `stream`; the next sync() waits for it and reports its errors."""
+        _ffi.check(_ffi.lib().bbx_graph_replayed(self._h, C.c_void_p(int(stream))))
+
     def accounting(self, enable):
         """Toggle per-step algorithmic-byte accounting (stats()[:, 6]); off selects the leanest kernel."""
         _ffi.check(_ffi.lib().bbx_accounting(self._h, int(enable)))

@@ -562,6 +562,15 @@ bool session_same_call(const BbxParams& a, const BbxParams& c) {
 }
 
 int launch(bbx_batch* b, BbxParams& p, hipStream_t stream, bool obs_external = false, bool device_async = false) {
+  // a launch recorded into a HIP graph (the caller's stream is capturing) must be a pure function of device state: nothing
+  // for the host to upload, no events, no second stream
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (stream != nullptr && hipStreamIsCapturing(stream, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+  if (cap != hipStreamCaptureStatusNone) {
+    if (!device_async) return fail(BBX_E_UNSUPPORTED, "only the asynchronous device calls can be captured into a graph");
+    if (!(b->device_gen || (b->fixed && !b->q_dirty))) return fail(BBX_E_UNSUPPORTED, "a batch whose ideals are drawn on the host cannot be captured into a graph");
+    if (b->ps_enabled || b->ps_active || b->timing) return fail(BBX_E_UNSUPPORTED, "persistent sessions and kernel timing cannot be captured into a graph");
+  }
   int rc = fill_queues(b, 1, stream);
   if (rc) return rc;
   // persistent sessions: asynchronous rollouts with a built-in agent on the register/LDS-resident class, lean and untraced,
@@ -607,6 +616,9 @@ int launch(bbx_batch* b, BbxParams& p, hipStream_t stream, bool obs_external = f
   b->in_flight = true;
   b->obs_external = obs_external;
   b->device_async = device_async;
+  if (cap != hipStreamCaptureStatusNone) {  // what bbx_graph_replayed restores: the call the replays repeat
+    b->cap_last = b->last; b->cap_valid = true; b->cap_obs_external = obs_external; b->cap_policy_rollout = b->policy_rollout;
+  }
   return enqueue(b, p, false, stream);
 }
 
@@ -1172,6 +1184,43 @@ int bbx_pmlp_act(const int32_t* d_obs, const int32_t* d_rows, int batch, int obs
   return BBX_OK;
 }
 
+// ---- two hidden layers (bbx_pmlp2.hip)
+extern "C" int bbx_pmlp2_floats(int cols, int h1, int h2);
+extern "C" int bbx_launch_pmlp2_prepare(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, const float* b3,
+                                        int cols, int h1, int h2, float* out, hipStream_t stream);
+extern "C" int bbx_launch_pmlp2_act(const int32_t* obs, const int32_t* rows, int B, int obs_rows, int cols, const float* wp, int h1, int h2,
+                                    const float* u, int32_t* actions, float* logprobs, int max_blocks, hipStream_t stream);
+
+int bbx_pmlp2_prepared_floats(int cols, int hidden1, int hidden2) {
+  if (cols < 1 || cols > 64 || hidden1 < 1 || hidden1 > 128 || hidden2 < 1 || hidden2 > 128)
+    return fail(BBX_E_UNSUPPORTED, "policy shape %d x %d x %d is not built into the two-layer policy kernel", cols, hidden1, hidden2);
+  return bbx_pmlp2_floats(cols, hidden1, hidden2);
+}
+
+int bbx_pmlp2_prepare(const float* d_w1, const float* d_b1, const float* d_w2, const float* d_b2, const float* d_w3, const float* d_b3,
+                      int cols, int hidden1, int hidden2, float* d_prepared, void* stream) {
+  if (!d_w1 || !d_b1 || !d_w2 || !d_b2 || !d_w3 || !d_b3 || !d_prepared) return fail(BBX_E_ARG, "null argument");
+  if (bbx_pmlp2_prepared_floats(cols, hidden1, hidden2) < 0) return BBX_E_UNSUPPORTED;
+  int lrc = bbx_launch_pmlp2_prepare(d_w1, d_b1, d_w2, d_b2, d_w3, d_b3, cols, hidden1, hidden2, d_prepared, (hipStream_t)stream);
+  if (lrc) return fail(BBX_E_DEVICE, "policy launch failed: %s", hipGetErrorString((hipError_t)lrc));
+  return BBX_OK;
+}
+
+int bbx_pmlp2_act(const int32_t* d_obs, const int32_t* d_rows, int batch, int obs_rows, int cols, const float* d_prepared, int hidden1, int hidden2,
+                  const float* d_u, int32_t* d_actions, float* d_logprobs, void* stream) {
+  if (!d_obs || !d_rows || !d_prepared || !d_u || !d_actions || !d_logprobs) return fail(BBX_E_ARG, "null argument");
+  if (batch < 1 || obs_rows < 1) return fail(BBX_E_ARG, "bad policy shape");
+  if (obs_rows > 1024) return fail(BBX_E_UNSUPPORTED, "the policy kernels score at most 1024 rows per environment (obs_rows = %d)", obs_rows);
+  if (bbx_pmlp2_prepared_floats(cols, hidden1, hidden2) < 0) return BBX_E_UNSUPPORTED;
+  int dev = 0, cus = 0;
+  HIPCHK(hipGetDevice(&dev));
+  HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  int lrc = bbx_launch_pmlp2_act(d_obs, d_rows, batch, obs_rows, cols, d_prepared, hidden1, hidden2, d_u, d_actions, d_logprobs,
+                                 2 * (cus > 0 ? cus : 256), (hipStream_t)stream);
+  if (lrc) return fail(BBX_E_DEVICE, "policy launch failed: %s", hipGetErrorString((hipError_t)lrc));
+  return BBX_OK;
+}
+
 int bbx_policy_step_device(bbx_batch* b, const float* d_prepared, int hidden, const float* d_u, int32_t* d_actions, float* d_logprobs,
                            double* d_rewards, uint8_t* d_dones, int32_t* d_rows, int32_t* d_obs, int obs_rows, int obs_fill, void* stream) {
   if (!b || !d_prepared || !d_u || !d_actions || !d_logprobs || !d_rows || !d_obs) return fail(BBX_E_ARG, "null argument");
@@ -1294,6 +1343,16 @@ int bbx_join(bbx_batch* b, void* stream) {
   HIPCHK(hipSetDevice(b->device));
   if (!b->ps_active) return BBX_OK;
   return session_close(b, true, (hipStream_t)stream, false);
+}
+
+int bbx_graph_replayed(bbx_batch* b, void* stream) {
+  if (!b) return fail(BBX_E_ARG, "null argument");
+  if (b->ps_active) return fail(BBX_E_UNSUPPORTED, "a persistent session is running on this handle");
+  if (!b->cap_valid) return fail(BBX_E_ARG, "no asynchronous step or rollout of this handle has been recorded into a graph");
+  if (b->in_flight) { int rc = finish(b, b->last_stream); if (rc) return rc; }
+  b->last = b->cap_last; b->policy_rollout = b->cap_policy_rollout; b->obs_external = b->cap_obs_external; b->device_async = true;
+  b->in_flight = true; b->last_stream = (hipStream_t)stream;
+  return BBX_OK;
 }
 
 int bbx_accounting(bbx_batch* b, int enable) {

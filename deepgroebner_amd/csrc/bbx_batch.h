@@ -87,6 +87,7 @@ struct bbx_batch {
   std::vector<char> h_out;
   // the rollout in flight (so bbx_sync can finish environments that waited for ideals)
   BbxParams last{};
+  BbxParams cap_last{}; bool cap_valid = false, cap_obs_external = false, cap_policy_rollout = false;   // the last call recorded into a HIP graph (bbx_graph_replayed)
   hipStream_t last_stream = 0;
   bool in_flight = false;
   bool policy_rollout = false;           // the launch in flight is a policy rollout (bbx_policy_rollout_device)

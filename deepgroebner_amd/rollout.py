@@ -12,12 +12,37 @@ one-hidden-layer network runs in hand-written HIP: on the matrix cores, either a
 observation block (bbx_pmlp_act), in front of the step in the same launch (bbx_policy_step_device), or inside the step
 loop (bbx_policy_rollout_device); deeper networks take the torch path.  Actions never visit the host.
 """
+import contextlib
 import ctypes as C
+import functools
+import gc
 
 import numpy as np
 import torch
 
 from . import _ffi
+
+
+@contextlib.contextmanager
+def _gc_paused():
+    """The step loops below enqueue a few kernels per iteration and must not fall behind the device: a generation-2 pass of
+    Python's cyclic collector over a process that has torch loaded takes ~40 ms (measured: one in ~900 iterations, +40 us per
+    vector step averaged over a 1000-step rollout), so collection is paused for the duration of a rollout."""
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was:
+            gc.enable()
+
+
+def _with_gc_paused(fn):
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        with _gc_paused():
+            return fn(*args, **kwargs)
+    return wrapper
 
 
 def discount_rewards(rewards, gam):
@@ -63,7 +88,8 @@ class PMLPPolicy(torch.nn.Module):
     @torch.no_grad()
     def act(self, obs, rows, u, actions=None, logprobs=None, stream=None):
         """Sample one action per environment by inverse CDF from the uniforms u [B] -> (actions int32 [B], logprobs
-        float32 [B]) on the device.  One hidden layer: the fused HIP kernel (bbx_pmlp_act); otherwise torch ops."""
+        float32 [B]) on the device.  One hidden layer: the fused HIP kernel (bbx_pmlp_act); two hidden layers of at most 128
+        units: bbx_pmlp2_act; otherwise torch ops."""
         B, R, cols = obs.shape
         if actions is None:
             actions = torch.empty(B, dtype=torch.int32, device=obs.device)
@@ -75,7 +101,38 @@ class PMLPPolicy(torch.nn.Module):
             _ffi.check(_ffi.lib().bbx_pmlp_act(C.c_void_p(obs.data_ptr()), C.c_void_p(rows.data_ptr()), B, R, cols, w["prepared"], w["hidden"],
                                                C.c_void_p(u.data_ptr()), C.c_void_p(actions.data_ptr()), C.c_void_p(logprobs.data_ptr()), C.c_void_p(s)))
             return actions, logprobs
+        if len(self.embedding) == 2 and self.fused2_ok(cols, self.embedding[0].out_features, self.embedding[1].out_features) and R <= 1024:
+            w = self._fused2_weights()
+            s = (stream if stream is not None else torch.cuda.current_stream()).cuda_stream
+            _ffi.check(_ffi.lib().bbx_pmlp2_act(C.c_void_p(obs.data_ptr()), C.c_void_p(rows.data_ptr()), B, R, cols, w["prepared"], w["hidden1"], w["hidden2"],
+                                                C.c_void_p(u.data_ptr()), C.c_void_p(actions.data_ptr()), C.c_void_p(logprobs.data_ptr()), C.c_void_p(s)))
+            return actions, logprobs
         return self.act_torch(obs, rows, u, actions, logprobs)
+
+    @staticmethod
+    def fused2_ok(cols, hidden1, hidden2):
+        """Shapes the two-layer policy kernel is built for (bbx_pmlp2_prepared_floats >= 0)."""
+        return 1 <= hidden1 <= 128 and 1 <= hidden2 <= 128 and 1 <= cols <= 64
+
+    def _fused2_weights(self):
+        """The two-layer kernel's view of the weights (bbx_pmlp2_prepare), rebuilt only when a parameter changed."""
+        l1, l2 = self.embedding
+        key = tuple(p._version for p in self.parameters()) + tuple(p.data_ptr() for p in self.parameters())
+        c = self.__dict__.get("_fused2_cache")
+        if c is None or c["key"] != key:
+            cols, h1, h2 = l1.in_features, l1.out_features, l2.out_features
+            t = [l1.weight.detach().t().contiguous().float(), l1.bias.detach().contiguous().float(),
+                 l2.weight.detach().t().contiguous().float(), l2.bias.detach().contiguous().float(),
+                 self.deciding.weight.detach().reshape(-1).contiguous().float(), self.deciding.bias.detach().reshape(-1).contiguous().float()]
+            nfl = _ffi.lib().bbx_pmlp2_prepared_floats(cols, h1, h2)
+            _ffi.check(min(nfl, 0))
+            prep = c["keep"][0] if c is not None and c["keep"][0].numel() == nfl and c["keep"][0].device == t[0].device else \
+                torch.empty(nfl, dtype=torch.float32, device=t[0].device)   # (refilled in place: a recorded graph keeps reading this buffer)
+            _ffi.check(_ffi.lib().bbx_pmlp2_prepare(*[C.c_void_p(x.data_ptr()) for x in t], cols, h1, h2, C.c_void_p(prep.data_ptr()),
+                                                    C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+            c = {"key": key, "keep": (prep, t), "prepared": C.c_void_p(prep.data_ptr()), "hidden1": h1, "hidden2": h2}
+            self.__dict__["_fused2_cache"] = c
+        return c
 
     @staticmethod
     def fused_ok(cols, hidden):
@@ -211,6 +268,7 @@ class DeviceTrajectoryBuffer:
         return batches
 
 
+@_with_gc_paused
 @torch.no_grad()
 def run_rollout_fused(env, policy, nsteps, buffer=None, obs_rows=256, generator=None, chunk=256):
     """run_rollout with the policy INSIDE the step kernel (bbx_policy_rollout_device): `chunk` vector steps per launch,
@@ -257,17 +315,24 @@ def run_rollout_fused(env, policy, nsteps, buffer=None, obs_rows=256, generator=
     return total, episodes
 
 
+@_with_gc_paused
 @torch.no_grad()
-def run_rollout(env, policy, nsteps, buffer=None, obs_rows=256, generator=None, sync_every=64):
+def run_rollout(env, policy, nsteps, buffer=None, obs_rows=256, generator=None, sync_every=64, graph=False):
     """nsteps vector steps of `env` (a VecLeadMonomialsEnv already reset) under `policy`, everything on the device
     (obs_rows: rows of the observation block per environment — a pair set with more rows makes env.sync() raise
     BBX_E_CAPACITY, it is never cut silently; 256 is what the register/LDS-resident class holds):
     observation block -> policy.act (log-softmax + inverse-CDF draw) -> bbx_step_device_autoreset -> next block.  The
     host only enqueues kernels; it waits (env.sync: errors, environments that outgrew a kernel class) every
     `sync_every` steps and at the end.  Returns (total reward per environment float64 [B] — for `additions` rewards —,
-    finished episodes int64 [B])."""
+    finished episodes int64 [B]).
+    graph=True (policies without a fused kernel, i.e. more than one hidden layer; no buffer): the vector step — the
+    policy's torch ops and the step kernels — is recorded once into a HIP graph (kept on `env`) and replayed, one graph
+    launch per step instead of ~25 kernel launches from Python; same draws, same results."""
     B, cols = env.batch, env.cols
     dev = torch.device("cuda", torch.cuda.current_device())
+    one_call = len(policy.embedding) == 1 and policy.fused_ok(cols, policy.embedding[0].out_features) and hasattr(env, "policy_step_device")
+    if graph and not one_call and buffer is None:
+        return _run_rollout_graph(env, policy, nsteps, obs_rows, generator, sync_every)
     stream = torch.cuda.current_stream()
     obs = torch.empty((B, obs_rows, cols), dtype=torch.int32, device=dev)
     rew = torch.zeros(B, dtype=torch.float64, device=dev); done = torch.zeros(B, dtype=torch.uint8, device=dev)
@@ -278,7 +343,6 @@ def run_rollout(env, policy, nsteps, buffer=None, obs_rows=256, generator=None, 
     env.rollout_device("first", 0, False, stream.cuda_stream, rew, done, rows, obs, obs_rows, True, False)
     env.sync()
     keep_states = buffer is not None and buffer.states is not None
-    one_call = len(policy.embedding) == 1 and policy.fused_ok(cols, policy.embedding[0].out_features) and hasattr(env, "policy_step_device")
     w = policy._fused_weights() if one_call else None
     nsync = 0
     for t0 in range(0, nsteps, sync_every):
@@ -306,3 +370,55 @@ def run_rollout(env, policy, nsteps, buffer=None, obs_rows=256, generator=None, 
     total = torch.tensor(-d[:, 1].astype(np.float64), device=dev)
     episodes = torch.tensor(d[:, 2], device=dev)
     return total, episodes
+
+
+def _run_rollout_graph(env, policy, nsteps, obs_rows, generator, sync_every):
+    """run_rollout with the vector step replayed from a HIP graph (see there).  The graph and its buffers live on `env`
+    (one per policy object and block height) and are reused by later calls; the policy's parameters are read in place, so
+    optimiser steps between calls are seen."""
+    B, cols = env.batch, env.cols
+    dev = torch.device("cuda", torch.cuda.current_device())
+    cache = env.__dict__.setdefault("_step_graphs", {})
+    key = (id(policy), obs_rows, sync_every)
+    c = cache.get(key)
+    if c is None:
+        c = {"obs": torch.empty((B, obs_rows, cols), dtype=torch.int32, device=dev),
+             "rew": torch.zeros(B, dtype=torch.float64, device=dev), "done": torch.zeros(B, dtype=torch.uint8, device=dev),
+             "rows": torch.ones(B, dtype=torch.int32, device=dev), "act": torch.zeros(B, dtype=torch.int32, device=dev),
+             "logp": torch.zeros(B, dtype=torch.float32, device=dev),
+             "u": torch.zeros((sync_every, B), dtype=torch.float32, device=dev), "i": torch.zeros(1, dtype=torch.int64, device=dev),
+             "policy": policy}
+        c["obs"].fill_(-1)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                  # the library GEMMs pick their workspaces outside the capture
+            for _ in range(3):
+                policy.act(c["obs"], c["rows"], c["u"][0], c["act"], c["logp"], side)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        env.sync()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            cs = torch.cuda.current_stream()
+            u = c["u"].index_select(0, c["i"]).squeeze(0)
+            policy.act(c["obs"], c["rows"], u, c["act"], c["logp"], cs)
+            env.step_device(c["act"], c["rew"], c["done"], c["rows"], c["obs"], obs_rows, 2, cs.cuda_stream, auto_reset=True)
+            c["i"].add_(1)
+        c["graph"] = g
+        cache[key] = c
+    stream = torch.cuda.current_stream()
+    if len(policy.embedding) == 2 and policy.fused2_ok(cols, policy.embedding[0].out_features, policy.embedding[1].out_features) and obs_rows <= 1024:
+        policy._fused2_weights()                       # (weights changed since the recording: the prepared copy is refilled in place)
+    st0 = env.stats()
+    env.rollout_device("first", 0, False, stream.cuda_stream, c["rew"], c["done"], c["rows"], c["obs"], obs_rows, True, False)
+    env.sync()
+    for t0 in range(0, nsteps, sync_every):
+        n = min(sync_every, nsteps - t0)
+        c["u"][:n].copy_(torch.rand((n, B), device=dev, generator=generator))
+        c["i"].zero_()
+        for _ in range(n):
+            c["graph"].replay()
+        env.graph_replayed(stream.cuda_stream)
+        env.sync()
+    d = env.stats() - st0
+    return torch.tensor(-d[:, 1].astype(np.float64), device=dev), torch.tensor(d[:, 2], device=dev)

@@ -187,6 +187,18 @@ int bbx_pmlp_prepared_floats(int cols, int hidden);        /* < 0: shape not sup
 int bbx_pmlp_prepare(const float* d_w1, const float* d_b1, const float* d_w2, float b2, int cols, int hidden, float* d_prepared, void* stream);
 int bbx_pmlp_act(const int32_t* d_obs, const int32_t* d_rows, int batch, int obs_rows, int cols, const float* d_prepared, int hidden,
                  const float* d_u, int32_t* d_actions, float* d_logprobs, void* stream);
+/* The same for ParallelMultilayerPerceptron(hidden_layers=[hidden1, hidden2]) (networks.py:562-571: two dense layers in the
+ * embedding): logit_r = w3 . relu(W2^T relu(W1^T x_r + b1) + b2) + b3, both layers on the matrix cores in exact f32, the
+ * second layer's weights staged in LDS once per workgroup (bbx_pmlp2.hip); cols <= 64, hidden1, hidden2 <= 128, at most 1024
+ * rows per environment.  d_w1 [cols][hidden1], d_b1 [hidden1], d_w2 [hidden1][hidden2], d_b2 [hidden2], d_w3 [hidden2],
+ * d_b3 [1] (the transposed layouts of torch.nn.Linear weights; every argument on the device: preparing never reads back).
+ * Stands alone in front of bbx_step_device_autoreset (two launches per vector step, both recordable into a HIP graph);
+ * the fused per-step / rollout / session forms exist for one hidden layer only. */
+int bbx_pmlp2_prepared_floats(int cols, int hidden1, int hidden2);   /* < 0: shape not supported */
+int bbx_pmlp2_prepare(const float* d_w1, const float* d_b1, const float* d_w2, const float* d_b2, const float* d_w3, const float* d_b3,
+                      int cols, int hidden1, int hidden2, float* d_prepared, void* stream);
+int bbx_pmlp2_act(const int32_t* d_obs, const int32_t* d_rows, int batch, int obs_rows, int cols, const float* d_prepared, int hidden1, int hidden2,
+                  const float* d_u, int32_t* d_actions, float* d_logprobs, void* stream);
 /* One vector step with the policy in the loop: bbx_pmlp_act on the block the previous call left in d_obs / d_rows, then
  * bbx_step_device_autoreset with the sampled rows as actions, which rewrites d_obs / d_rows (the inner loop of
  * pg.py:451-503 run_episode, batched).  Where the step kernel has the policy built in (the register/LDS-resident class
@@ -237,6 +249,20 @@ int bbx_persistent(bbx_batch* b, int enable);
 int bbx_join(bbx_batch* b, void* stream);
 /* out4 = {sessions begun, calls that joined a running session, env-steps taken by later kernels of sessions, kernels} */
 int bbx_session_stats(bbx_batch* b, int64_t* out4);
+
+/* ---- HIP graphs ---------------------------------------------------------------------------------------------------------
+ * The asynchronous device calls (bbx_step_device[_autoreset], bbx_rollout_device, bbx_policy_step_device,
+ * bbx_policy_rollout_device) on a batch whose ideals are drawn on the device (or a fixed ideal) only enqueue kernels whose
+ * arguments do not depend on host-side counters, so they may be recorded while `stream` is capturing
+ * (hipStreamBeginCapture / torch.cuda.graph) together with whatever produces the actions — e.g. a policy of any depth as
+ * library GEMMs — and replayed as one graph launch per vector step: the reference's loop `action = policy(state);
+ * state, reward, done, _ = env.step(action)` (pg.py:451-465) without a host call per operation.  Launches that would need
+ * the host (ideals drawn on the host, persistent sessions, kernel timing) return BBX_E_UNSUPPORTED while capturing.
+ * Replays bypass the library, so tell it before the next bbx_sync: bbx_graph_replayed(b, stream) marks the handle as
+ * having work in flight on `stream` (the one the graph was replayed on); bbx_sync then waits for it, reports what the
+ * replayed steps reported (BBX_E_ACTION, capacities, ...) and continues environments that had to stop, exactly as after
+ * the same calls made directly. */
+int bbx_graph_replayed(bbx_batch* b, void* stream);
 
 /* Algorithmic-byte accounting (stats column 6, the roofline numerator) is on by default; the hand-tuned kernel
  * has a leaner variant without it, selected by bbx_accounting(b, 0).  The count is a property of the workload:

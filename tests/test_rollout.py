@@ -149,6 +149,113 @@ def test_fused_policy_kernel_matches_torch_module(dist, k, hidden):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dist,k,hidden", [("3-20-10-weighted", 2, (128, 128)), ("5-10-5-uniform", 1, (64, 128)), ("3-20-10-uniform", 3, (100, 40)),
+                                           ("4-5-4-uniform", 1, (32, 7)), ("5-10-5-uniform", 3, (128, 64)), ("6-3-4-uniform", 3, (128, 128))])
+def test_fused_two_layer_policy_kernel_matches_torch_module(dist, k, hidden):
+    """bbx_pmlp2_act (two hidden layers on the matrix cores, the second layer's k-steps in the order the first layer's
+    accumulators lie) against the torch module: every unit-block combination, all three k-step counts, layer sizes that do
+    not fill a tile, environments with more than one tile of rows."""
+    import torch
+    from deepgroebner_amd import VecLeadMonomialsEnv
+    from deepgroebner_amd.rollout import PMLPPolicy
+    torch.manual_seed(3)
+    B, R = 300, 192
+    env = VecLeadMonomialsEnv(dist, batch=B, k=k)
+    env.seed(np.arange(B) + 5); env.seed_agent(np.arange(B)); env.reset()
+    env.rollout("random", 25, auto_reset=True)
+    obs = torch.full((B, R, env.cols), -7, dtype=torch.int32, device="cuda")
+    rew = torch.zeros(B, dtype=torch.float64, device="cuda"); done = torch.zeros(B, dtype=torch.uint8, device="cuda")
+    rows = torch.zeros(B, dtype=torch.int32, device="cuda")
+    env.rollout_device("first", 0, False, torch.cuda.current_stream().cuda_stream, rew, done, rows, obs, R, True, False)
+    env.sync()
+    assert int(rows.max()) <= R and int(rows.min()) >= 1
+    policy = PMLPPolicy(env.cols, list(hidden)).cuda()
+    assert policy.fused2_ok(env.cols, *hidden)
+    with torch.no_grad():
+        for lin in list(policy.embedding) + [policy.deciding]:
+            lin.weight.mul_(0.3)
+    for trial in range(3):
+        u = torch.rand(B, device="cuda")
+        a_k, l_k = policy.act(obs, rows, u)
+        a_t, l_t = policy.act_torch(obs, rows, u)
+        torch.cuda.synchronize()
+        assert (a_k >= 0).all() and (a_k < rows).all()
+        lp = policy(obs)
+        assert torch.allclose(l_k, lp.gather(1, a_k.long()[:, None]).squeeze(1), atol=3e-4, rtol=1e-4)
+        same = (a_k == a_t)
+        assert same.float().mean() > 0.99
+        if not same.all():
+            cdf = torch.cumsum(lp.exp(), dim=1)
+            for e in torch.nonzero(~same).flatten().tolist():
+                lo, hi = sorted((int(a_k[e]), int(a_t[e])))
+                assert hi - lo == 1 and abs(float(cdf[e, lo]) - float(u[e])) < 1e-4, e
+        if trial == 0:                                            # an optimiser step: the prepared copy follows, in the same buffer
+            before = policy._fused2_weights()["prepared"].value
+            with torch.no_grad():
+                policy.embedding[1].weight.add_(0.01)
+            assert policy._fused2_weights()["prepared"].value == before
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hidden", [(64, 64), (32, 32, 32)])
+def test_rollout_replayed_from_a_hip_graph_equals_the_eager_rollout(hidden):
+    """run_rollout(graph=True): the vector step (policy ops + bbx_step_device_autoreset) recorded once and replayed gives the
+    rollout of the same calls made one by one — two hidden layers (bbx_pmlp2_act in the graph) and three (torch ops in the
+    graph); a second call reuses the recording; bbx_graph_replayed makes bbx_sync see the replayed work."""
+    import torch
+    from deepgroebner_amd import VecLeadMonomialsEnv
+    from deepgroebner_amd.rollout import PMLPPolicy, run_rollout
+    torch.manual_seed(4)
+    B, T = 96, 150
+    policy = None
+    res = {}
+    for graph in (False, True):
+        env = VecLeadMonomialsEnv("3-20-10-weighted", batch=B, k=2)
+        env.seed(np.arange(B) + 77); env.reset()
+        if policy is None:
+            policy = PMLPPolicy(env.cols, list(hidden)).cuda()
+        g = torch.Generator(device="cuda"); g.manual_seed(11)
+        tot1, ep1 = run_rollout(env, policy, T, obs_rows=128, generator=g, sync_every=40, graph=graph)
+        tot2, ep2 = run_rollout(env, policy, 30, obs_rows=128, generator=g, sync_every=40, graph=graph)
+        torch.cuda.synchronize()
+        res[graph] = (tot1.cpu().numpy(), ep1.cpu().numpy(), tot2.cpu().numpy(), ep2.cpu().numpy(), env.stats().copy())
+        if graph:
+            assert len(env._step_graphs) == 1
+    for a, b in zip(res[False], res[True]):
+        assert np.array_equal(a, b)
+    assert res[True][1].sum() > 0
+
+
+@pytest.mark.gpu
+def test_launches_that_need_the_host_refuse_graph_capture():
+    """A launch that could not be replayed faithfully (here: a handle with persistent sessions enabled, whose calls talk to a
+    running kernel through the host) is refused while the stream is capturing — BBX_E_UNSUPPORTED — and the handle works
+    normally afterwards."""
+    import torch
+    from deepgroebner_amd import VecLeadMonomialsEnv
+    from deepgroebner_amd._ffi import BbxError
+    B = 8
+    env = VecLeadMonomialsEnv("3-20-10-weighted", batch=B, k=1)
+    env.seed(np.arange(B)); env.reset()
+    env.persistent(True)
+    act = torch.zeros(B, dtype=torch.int32, device="cuda")
+    side = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    refused = False
+    with torch.cuda.graph(g, stream=side):
+        try:
+            env.step_device(act, stream=torch.cuda.current_stream().cuda_stream)
+        except BbxError as e:
+            refused = e.code == -5 and "graph" in str(e)
+        act.add_(0)                                                 # (something for the recording to hold)
+    assert refused
+    env.persistent(False)
+    env.step_device(act, stream=torch.cuda.current_stream().cuda_stream)
+    env.sync()
+    assert int(env.stats()[:, 0].sum()) == B
+
+
+@pytest.mark.gpu
 def test_device_rollout_with_policy_in_the_loop_replays_on_the_oracle():
     """Actions sampled on the device index the rows the oracle steps: a rollout with the PMLP policy in the loop (no host
     round trip per step), its recorded states / actions / rewards / dones replayed environment by environment on the CPU
