@@ -119,3 +119,19 @@ def test_parse_rejects_what_the_reference_leaves_undefined(ffi_, bad):
     from deepgroebner_amd import parse_ideal_string
     with pytest.raises(ffi_.BbxError):
         parse_ideal_string(bad)
+
+
+def test_policy_shapes_are_checked_on_the_host(ffi_):
+    """What the policy kernels are built for is answered without a device: prepared-buffer sizes for the supported shapes,
+    BBX_E_UNSUPPORTED (-5) with a message for the others (the Python side then takes its torch path)."""
+    dll = ffi_.lib()
+    assert dll.bbx_pmlp_prepared_floats(12, 128) == (2 * 6 + 2) * 128 + 4
+    assert dll.bbx_pmlp_prepared_floats(65, 128) == -5 and dll.bbx_pmlp_prepared_floats(12, 257) == -5
+    n = dll.bbx_pmlp2_prepared_floats(12, 128, 128)          # W1p [12][128] | b1p | A2 [128 x 128, permuted] | b2p | w3p | b3 + pad
+    assert n == (2 * 6 + 1) * 128 + 128 * 128 + 2 * 128 + 4
+    assert dll.bbx_pmlp2_prepared_floats(12, 64, 7) == (2 * 6 + 1) * 64 + 64 * 64 + 2 * 64 + 4      # (layers are padded to 64 units at least)
+    assert dll.bbx_pmlp2_prepared_floats(40, 128, 64) == (2 * 32 + 1) * 128 + 128 * 64 + 2 * 64 + 4
+    for bad in ((65, 128, 128), (12, 129, 128), (12, 128, 0)):
+        assert dll.bbx_pmlp2_prepared_floats(*bad) == -5
+        assert b"two-layer" in dll.bbx_last_error()
+    assert dll.bbx_graph_replayed(None, None) == -1                                                   # BBX_E_ARG
