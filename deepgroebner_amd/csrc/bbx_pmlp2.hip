@@ -79,13 +79,38 @@ __global__ __launch_bounds__(PMLP2_WAVES * WAVE, 2) void bbx_pmlp2_act_kernel(co
   float* lg = a2 + A2F + 2 * HP2 + (size_t)wave * lgcap;                      // logits of this wave's environment
   const int lr = lane & 15, lg4 = lane >> 4;
   const float b3 = a2g[A2F + 2 * HP2];
-  for (int env = (int)blockIdx.x * nw + wave; env < B; env += (int)gridDim.x * nw) {
-    int n = uni(rows[env]);
-    const float uu = u[env];
-    n = n < obs_rows ? n : obs_rows; n = n < PMLP_MAXROWS ? n : PMLP_MAXROWS;
-    if (n <= 0) { if (lane == 0) { actions[env] = 0; logprobs[env] = 0.f; } continue; }
-    const int32_t* ob = obs + (size_t)env * obs_rows * cols;
-    for (int r0 = 0; r0 < n; r0 += 16) {
+  // A wave's tiles run one after the other, so with one environment per wave a launch lasts as long as its LARGEST pair set
+  // (B = 4096: the mean is 1.7 tiles, the maximum 5-7; measured 60 us per launch for 25 us of matrix-core time, the same with
+  // two or four waves per SIMD).  The wave therefore takes only the first two tiles of its environment itself; further tiles
+  // go to a queue of the workgroup and are shared out among its eight waves after a barrier (logits land in the owner's LDS
+  // buffer), and the owner samples after a second barrier.
+  float* lg_base = a2 + A2F + 2 * HP2;
+  int* s_env = (int*)(lg_base + (size_t)nw * lgcap);                          // [nw] environment of each wave this round
+  int* s_n = s_env + nw;                                                      // [nw] its row count
+  int* s_q = s_n + nw;                                                        // queue length
+  unsigned short* queue = (unsigned short*)(s_q + 1);                         // [nw * 64] (wave << 8) | tile
+  for (int base = (int)blockIdx.x * nw; base < B; base += (int)gridDim.x * nw) {
+    const int env = base + wave;
+    const bool valid = env < B;
+    int n = valid ? uni(rows[env]) : 0;
+    const float uu = valid ? u[env] : 0.f;
+    n = n < obs_rows ? n : obs_rows; n = n < PMLP_MAXROWS ? n : PMLP_MAXROWS; n = n > 0 ? n : 0;
+    const int T = (n + 15) >> 4;
+    __syncthreads();                                                          // (the previous round is over: logits, queue)
+    if (lane == 0) { s_env[wave] = env; s_n[wave] = n; }
+    if (threadIdx.x == 0) *s_q = 0;
+    __syncthreads();
+    if (lane < T - 2) queue[atomicAdd(s_q, 1)] = (unsigned short)((wave << 8) | (2 + lane));
+  for (int phase = 0; phase < 2; phase++) {
+    int cnt = T < 2 ? T : 2;
+    if (phase == 1) { __syncthreads(); cnt = uni(*s_q); }
+    for (int it = phase == 0 ? 0 : wave; it < cnt; it += (phase == 0 ? 1 : nw)) {
+      int w = wave, t = it;
+      if (phase == 1) { const int e = uni((int)queue[it]); w = e >> 8; t = e & 255; }
+      const int tn = uni(s_n[w]), r0 = 16 * t;
+      const int32_t* ob = obs + (size_t)uni(s_env[w]) * obs_rows * cols;
+      float* lgt = lg_base + (size_t)w * lgcap;
+    {
       int r = r0 + lr; r = r < obs_rows ? r : obs_rows - 1;                   // inside the block whatever the row count is
       const int32_t* xr = ob + (size_t)r * cols;
       float xa[KS];
@@ -149,10 +174,15 @@ __global__ __launch_bounds__(PMLP2_WAVES * WAVE, 2) void bbx_pmlp2_act_kernel(co
       }
       part += __shfl_xor(part, 16, WAVE);                                     // the other lane groups hold the row's other units
       part += __shfl_xor(part, 32, WAVE);
-      if (lg4 == 0 && r0 + lr < n) lg[r0 + lr] = part + b3;
+      if (lg4 == 0 && r0 + lr < tn) lgt[r0 + lr] = part + b3;
     }
-    pmlp_sample(lg, n, env, uu, actions, logprobs);
-    wave_sync();                                                              // (the logits are rewritten for the next environment)
+    }
+  }
+    __syncthreads();                                                          // (every tile of the workgroup's environments is in)
+    if (valid) {
+      if (n <= 0) { if (lane == 0) { actions[env] = 0; logprobs[env] = 0.f; } }
+      else pmlp_sample(lg, n, env, uu, actions, logprobs);
+    }
   }
 }
 
@@ -169,7 +199,7 @@ extern "C" int bbx_launch_pmlp2_act(const int32_t* obs, const int32_t* rows, int
   const int waves = PMLP2_WAVES, hp1 = pmlp2_hp_for(h1), hp2 = pmlp2_hp_for(h2), ks = pmlp2_ks_for(cols);
   int lgcap = obs_rows < PMLP_MAXROWS ? obs_rows : PMLP_MAXROWS;              // logits per wave: what the block can hold
   lgcap = (lgcap + 63) / 64 * 64;
-  const size_t ml = ((size_t)hp1 * hp2 + 2 * hp2) * sizeof(float) + (size_t)waves * lgcap * sizeof(float);
+  const size_t ml = ((size_t)hp1 * hp2 + 2 * hp2) * sizeof(float) + (size_t)waves * lgcap * sizeof(float) + (size_t)(2 * waves + 1) * sizeof(int) + (size_t)waves * 64 * sizeof(unsigned short);
   int blocks = (B + waves - 1) / waves;
   blocks = blocks < max_blocks ? blocks : max_blocks;
 #define BBX_P2(N1, N2, K) do { \
