@@ -56,6 +56,7 @@ bbx_batch::~bbx_batch() {
   void* dev[] = {d_recs, d_q, d_tail, d_out, d_actions, d_mask, d_seeds, d_obs, d_trace, d_hdr,
                  d_vrecs, d_vhdr, d_vsrc, d_vseeds, d_vvals, d_stage, d_obs_off, d_obs_packed};
   for (void* q : dev) if (q) (void)hipFree(q);
+  for (void* q : retired) if (q) (void)hipFree(q);
   void* pinned[] = {h_io, h_act, h_stage, h_zobs, h_obs};
   for (void* q : pinned) if (q) (void)hipHostFree(q);
   bbx_host::pool_synced(false);
@@ -387,7 +388,12 @@ int grow_records(bbx_batch* b, unsigned need, int env, hipStream_t stream) {
   int lrc = bbx_launch_relayout(b->d_recs, nrecs, &b->L, &NL, b->B, stream);
   if (lrc) { (void)hipFree(nrecs); return fail(BBX_E_DEVICE, "relayout launch failed: %s", hipGetErrorString((hipError_t)lrc)); }
   HIPCHK(hipStreamSynchronize(stream));
-  HIPCHK(hipFree(b->d_recs));
+  if (b->cap_valid) {
+    // a recorded graph (bbx_graph_replayed) holds the old array's address: replays of it must stay harmless — they step the
+    // retired copy, not memory that has meanwhile been handed to someone else — until the caller hears about it and records again
+    b->retired.push_back(b->d_recs);
+    b->cap_stale = true;
+  } else HIPCHK(hipFree(b->d_recs));
   b->d_recs = nrecs; b->L = NL;
   b->last.recs = nrecs; b->last.L = NL;
   b->grow_events++;
@@ -405,6 +411,8 @@ int session_kernel(bbx_batch* b, bool first, hipStream_t after, bool sliced);
 
 int finish(bbx_batch* b, hipStream_t stream) {
   int err = BBX_OK;
+  const int async_chain = b->async_chain;              // (asynchronous external-action steps behind this wait)
+  b->async_chain = 0;
   auto note = [&err](int code) { if (err == BBX_OK) err = code; };
   if (b->ps_active) {                                // a persistent session: stop it; its kernels run in slices until nothing is owed
     int rc = session_close(b, false, nullptr, true);
@@ -460,6 +468,15 @@ int finish(bbx_batch* b, hipStream_t stream) {
       if (b->policy_rollout) {                        // (its per-step arrays belonged to the caller's frame: cannot be resumed)
         note(fail(BBX_E_CAPACITY, "environment %d could not finish its policy rollout (%s); the records have been enlarged, later rollouts have room",
                   grow_env, status_name(__builtin_ctz(grow))));
+        break;
+      }
+      if (b->device_async && b->last.agent == BBX_AGENT_EXTERNAL && async_chain > 1) {
+        // several asynchronous steps with caller-supplied actions were queued behind each other (or replayed from a graph):
+        // the environment stopped at one of them and sat out the rest; the action buffer now holds a later step's actions,
+        // so the step it stopped at cannot be taken for it
+        note(fail(BBX_E_CAPACITY, "environment %d outgrew its records (%s) inside a chain of asynchronous steps with caller-supplied actions and took "
+                                  "none of the chain's later steps; the records have been enlarged, later calls have room", grow_env,
+                  status_name(__builtin_ctz(grow))));
         break;
       }
       again = true;
@@ -609,6 +626,7 @@ int launch(bbx_batch* b, BbxParams& p, hipStream_t stream, bool obs_external = f
     b->policy_rollout = false; b->last_stream = b->ps_stream; b->in_flight = true; b->obs_external = obs_external; b->device_async = true;
     return session_kernel(b, true, stream, true);
   }
+  if (device_async && p.agent == BBX_AGENT_EXTERNAL && p.nsteps >= 1) b->async_chain++;
   b->last = p; b->last.ctl = nullptr;
   b->policy_rollout = p.policy && p.policy->rollout;
   b->last.policy = nullptr;                 // (a host pointer of the caller's frame: never kept)
@@ -617,7 +635,7 @@ int launch(bbx_batch* b, BbxParams& p, hipStream_t stream, bool obs_external = f
   b->obs_external = obs_external;
   b->device_async = device_async;
   if (cap != hipStreamCaptureStatusNone) {  // what bbx_graph_replayed restores: the call the replays repeat
-    b->cap_last = b->last; b->cap_valid = true; b->cap_obs_external = obs_external; b->cap_policy_rollout = b->policy_rollout;
+    b->cap_last = b->last; b->cap_valid = true; b->cap_stale = false; b->cap_obs_external = obs_external; b->cap_policy_rollout = b->policy_rollout;
   }
   return enqueue(b, p, false, stream);
 }
@@ -1349,9 +1367,15 @@ int bbx_graph_replayed(bbx_batch* b, void* stream) {
   if (!b) return fail(BBX_E_ARG, "null argument");
   if (b->ps_active) return fail(BBX_E_UNSUPPORTED, "a persistent session is running on this handle");
   if (!b->cap_valid) return fail(BBX_E_ARG, "no asynchronous step or rollout of this handle has been recorded into a graph");
+  if (b->cap_stale) {
+    b->cap_valid = false; b->cap_stale = false;
+    return fail(BBX_E_CAPACITY, "the records of this batch were enlarged after the step was recorded: the graph steps the retired copy, "
+                                "the steps replayed since did not reach the batch — record the step again");
+  }
   if (b->in_flight) { int rc = finish(b, b->last_stream); if (rc) return rc; }
   b->last = b->cap_last; b->policy_rollout = b->cap_policy_rollout; b->obs_external = b->cap_obs_external; b->device_async = true;
   b->in_flight = true; b->last_stream = (hipStream_t)stream;
+  b->async_chain = 2;                                   // (any number of replays)
   return BBX_OK;
 }
 

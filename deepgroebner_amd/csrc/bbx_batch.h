@@ -88,6 +88,8 @@ struct bbx_batch {
   // the rollout in flight (so bbx_sync can finish environments that waited for ideals)
   BbxParams last{};
   BbxParams cap_last{}; bool cap_valid = false, cap_obs_external = false, cap_policy_rollout = false;   // the last call recorded into a HIP graph (bbx_graph_replayed)
+  int async_chain = 0;                // asynchronous steps with caller-supplied actions queued since the last wait (finish())
+  bool cap_stale = false; std::vector<void*> retired;   // the records were enlarged after the recording: the old arrays stay allocated (replays write there)
   hipStream_t last_stream = 0;
   bool in_flight = false;
   bool policy_rollout = false;           // the launch in flight is a policy rollout (bbx_policy_rollout_device)

@@ -418,7 +418,11 @@ def _run_rollout_graph(env, policy, nsteps, obs_rows, generator, sync_every):
         c["i"].zero_()
         for _ in range(n):
             c["graph"].replay()
-        env.graph_replayed(stream.cuda_stream)
+        try:
+            env.graph_replayed(stream.cuda_stream)
+        except _ffi.BbxError:
+            cache.pop(key, None)                       # (records enlarged since the recording: the next call records again)
+            raise
         env.sync()
     d = env.stats() - st0
     return torch.tensor(-d[:, 1].astype(np.float64), device=dev), torch.tensor(d[:, 2], device=dev)

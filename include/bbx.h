@@ -261,7 +261,9 @@ int bbx_session_stats(bbx_batch* b, int64_t* out4);
  * Replays bypass the library, so tell it before the next bbx_sync: bbx_graph_replayed(b, stream) marks the handle as
  * having work in flight on `stream` (the one the graph was replayed on); bbx_sync then waits for it, reports what the
  * replayed steps reported (BBX_E_ACTION, capacities, ...) and continues environments that had to stop, exactly as after
- * the same calls made directly. */
+ * the same calls made directly.  One thing invalidates a recording: records enlarged by bbx_sync (an environment outgrew a
+ * capacity) live at a new address; the old arrays are kept so that further replays stay harmless, and the next
+ * bbx_graph_replayed returns BBX_E_CAPACITY — the steps replayed since did not reach the batch; record the step again. */
 int bbx_graph_replayed(bbx_batch* b, void* stream);
 
 /* Algorithmic-byte accounting (stats column 6, the roofline numerator) is on by default; the hand-tuned kernel

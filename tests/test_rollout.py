@@ -227,6 +227,49 @@ def test_rollout_replayed_from_a_hip_graph_equals_the_eager_rollout(hidden):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("graph", [False, True])
+def test_records_outgrown_inside_a_chain_of_device_steps_are_reported(graph):
+    """Asynchronous steps with caller-supplied actions queued behind each other (run_rollout between two waits, eager or
+    replayed from a graph): an environment that outgrows its records stops at that step and sits out the rest of the chain;
+    the action buffer then holds a later step's actions, so the library cannot take the missed step for it — bbx_sync
+    enlarges the records and says so (BBX_E_CAPACITY, never a wrong or out-of-range action taken silently).  Under a
+    recorded graph the enlarged records live at a new address: the next bbx_graph_replayed reports the recording as stale
+    ('record the step again'), replays in between stepped the retired copy, run_rollout drops its recording.  Afterwards
+    the batch is intact and steps normally."""
+    import torch
+    from deepgroebner_amd import VecLeadMonomialsEnv
+    from deepgroebner_amd._ffi import BbxError
+    from deepgroebner_amd.rollout import PMLPPolicy, run_rollout
+    torch.manual_seed(5)
+    B = 64
+    env = VecLeadMonomialsEnv("3-20-10-weighted", batch=B, k=2, caps={"max_basis": 16, "max_pairs": 32})
+    env.seed(np.arange(B) + 300); env.reset()
+    policy = PMLPPolicy(env.cols, [32, 32, 32]).cuda()
+    g = torch.Generator(device="cuda"); g.manual_seed(3)
+    kinds = []
+    clean = 0
+    for attempt in range(40):
+        before = env.stats()[:, 0].copy()
+        try:
+            run_rollout(env, policy, 8, obs_rows=128, generator=g, sync_every=8, graph=graph)
+        except BbxError as e:
+            assert e.code == -3, str(e)                              # BBX_E_CAPACITY
+            kinds.append("stale" if "record the step again" in str(e) else "chain" if "chain of asynchronous steps" in str(e) else str(e))
+            assert kinds[-1] in ("stale", "chain"), kinds[-1]
+            if kinds[-1] == "stale":
+                assert graph and not env._step_graphs
+                assert (env.stats()[:, 0] == before).all()           # (replays of a stale recording never reach the batch)
+            continue
+        assert ((env.stats()[:, 0] - before) == 8).all()             # a call without an error: every environment took its 8 steps
+        clean += 1
+        if clean >= 3 and env.capacities()["grown"] >= 1:
+            break
+    assert "chain" in kinds and clean >= 3 and env.capacities()["grown"] >= 1
+    assert ("stale" in kinds) == graph
+    assert (env.stats()[:, 4] == 0).all()
+
+
+@pytest.mark.gpu
 def test_launches_that_need_the_host_refuse_graph_capture():
     """A launch that could not be replayed faithfully (here: a handle with persistent sessions enabled, whose calls talk to a
     running kernel through the host) is refused while the stream is capturing — BBX_E_UNSUPPORTED — and the handle works
