@@ -164,7 +164,11 @@ int bbx_values_seeded(bbx_batch* b, const char* strategy, double gamma, const in
  * (hipStream_t passed as void*; NULL = the default stream).  obs may be NULL.
  * obs_fill: 0 = rows beyond |P| are left alone; 1 = they are padded with -1 (pg.py:217-226); 2 = incremental padding:
  * the caller vouches that d_obs and d_rows still hold what the previous call on this handle wrote, so only the rows
- * that stopped being valid are re-padded (classes without the incremental path pad everything, like 1). */
+ * that stopped being valid are re-padded (classes without the incremental path pad everything, like 1).
+ * Any number of these calls may be queued before a bbx_sync.  An environment that outgrows a capacity stops at that step:
+ * with one step between two waits bbx_sync enlarges the records and takes the step (nothing to see); with several, the
+ * environment has sat out the later ones and d_actions meanwhile holds a later step's actions, so bbx_sync enlarges the
+ * records and returns BBX_E_CAPACITY naming the environment — its steps of that chain are missing, later calls proceed. */
 int bbx_step_device(bbx_batch* b, const int32_t* d_actions, double* d_rewards, uint8_t* d_dones, int32_t* d_rows,
                     int32_t* d_obs, int obs_rows, int obs_fill, void* stream);
 /* the same with the vectorised-environment convention of bbx_step_autoreset (finished episodes restart inside the call) */
