@@ -73,6 +73,9 @@ SIGNATURES = {
     "bbx_pmlp2_prepared_floats": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "bbx_pmlp2_prepare": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "bbx_pmlp2_act": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
+    "bbx_pmlp3_prepared_floats": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "bbx_pmlp3_prepare": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    "bbx_pmlp3_act": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
     "bbx_policy_step_device": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp]),
     "bbx_policy_rollout_device": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_longlong, _vp]),
     "bbx_rollout_device": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),

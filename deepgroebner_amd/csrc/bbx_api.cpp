@@ -1202,41 +1202,63 @@ int bbx_pmlp_act(const int32_t* d_obs, const int32_t* d_rows, int batch, int obs
   return BBX_OK;
 }
 
-// ---- two hidden layers (bbx_pmlp2.hip)
-extern "C" int bbx_pmlp2_floats(int cols, int h1, int h2);
-extern "C" int bbx_launch_pmlp2_prepare(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, const float* b3,
-                                        int cols, int h1, int h2, float* out, hipStream_t stream);
-extern "C" int bbx_launch_pmlp2_act(const int32_t* obs, const int32_t* rows, int B, int obs_rows, int cols, const float* wp, int h1, int h2,
-                                    const float* u, int32_t* actions, float* logprobs, int max_blocks, hipStream_t stream);
+// ---- two and three hidden layers (bbx_pmlp2.hip; hm = 0: no middle layer)
+extern "C" int bbx_pmlp2_floats(int cols, int h1, int hm, int h2);
+extern "C" int bbx_launch_pmlp2_prepare(const float* w1, const float* b1, const float* wm, const float* bm, const float* w2, const float* b2,
+                                        const float* wd, const float* bd, int cols, int h1, int hm, int h2, float* out, hipStream_t stream);
+extern "C" int bbx_launch_pmlp2_act(const int32_t* obs, const int32_t* rows, int B, int obs_rows, int cols, const float* wp, int h1, int hm, int h2,
+                                    const float* u, int32_t* actions, float* logprobs, int cus, hipStream_t stream);
 
-int bbx_pmlp2_prepared_floats(int cols, int hidden1, int hidden2) {
-  if (cols < 1 || cols > 64 || hidden1 < 1 || hidden1 > 128 || hidden2 < 1 || hidden2 > 128)
-    return fail(BBX_E_UNSUPPORTED, "policy shape %d x %d x %d is not built into the two-layer policy kernel", cols, hidden1, hidden2);
-  return bbx_pmlp2_floats(cols, hidden1, hidden2);
+static int pmlp_deep_floats(int cols, int h1, int hm, int h2, bool three) {
+  if (cols < 1 || cols > 64 || h1 < 1 || h1 > 128 || h2 < 1 || h2 > 128 || (three && (hm < 1 || hm > 128)))
+    return three ? fail(BBX_E_UNSUPPORTED, "policy shape %d x %d x %d x %d is not built into the three-layer policy kernel", cols, h1, hm, h2)
+                 : fail(BBX_E_UNSUPPORTED, "policy shape %d x %d x %d is not built into the two-layer policy kernel", cols, h1, h2);
+  return bbx_pmlp2_floats(cols, h1, three ? hm : 0, h2);
 }
+static int pmlp_deep_act(const int32_t* d_obs, const int32_t* d_rows, int batch, int obs_rows, int cols, const float* d_prepared, int h1, int hm, int h2,
+                         bool three, const float* d_u, int32_t* d_actions, float* d_logprobs, void* stream) {
+  if (!d_obs || !d_rows || !d_prepared || !d_u || !d_actions || !d_logprobs) return fail(BBX_E_ARG, "null argument");
+  if (batch < 1 || obs_rows < 1) return fail(BBX_E_ARG, "bad policy shape");
+  if (obs_rows > 1024) return fail(BBX_E_UNSUPPORTED, "the policy kernels score at most 1024 rows per environment (obs_rows = %d)", obs_rows);
+  if (pmlp_deep_floats(cols, h1, hm, h2, three) < 0) return BBX_E_UNSUPPORTED;
+  int dev = 0, cus = 0;
+  HIPCHK(hipGetDevice(&dev));
+  HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  int lrc = bbx_launch_pmlp2_act(d_obs, d_rows, batch, obs_rows, cols, d_prepared, h1, three ? hm : 0, h2, d_u, d_actions, d_logprobs, cus, (hipStream_t)stream);
+  if (lrc) return fail(BBX_E_DEVICE, "policy launch failed: %s", hipGetErrorString((hipError_t)lrc));
+  return BBX_OK;
+}
+
+int bbx_pmlp2_prepared_floats(int cols, int hidden1, int hidden2) { return pmlp_deep_floats(cols, hidden1, 0, hidden2, false); }
 
 int bbx_pmlp2_prepare(const float* d_w1, const float* d_b1, const float* d_w2, const float* d_b2, const float* d_w3, const float* d_b3,
                       int cols, int hidden1, int hidden2, float* d_prepared, void* stream) {
   if (!d_w1 || !d_b1 || !d_w2 || !d_b2 || !d_w3 || !d_b3 || !d_prepared) return fail(BBX_E_ARG, "null argument");
   if (bbx_pmlp2_prepared_floats(cols, hidden1, hidden2) < 0) return BBX_E_UNSUPPORTED;
-  int lrc = bbx_launch_pmlp2_prepare(d_w1, d_b1, d_w2, d_b2, d_w3, d_b3, cols, hidden1, hidden2, d_prepared, (hipStream_t)stream);
+  int lrc = bbx_launch_pmlp2_prepare(d_w1, d_b1, nullptr, nullptr, d_w2, d_b2, d_w3, d_b3, cols, hidden1, 0, hidden2, d_prepared, (hipStream_t)stream);
   if (lrc) return fail(BBX_E_DEVICE, "policy launch failed: %s", hipGetErrorString((hipError_t)lrc));
   return BBX_OK;
 }
 
 int bbx_pmlp2_act(const int32_t* d_obs, const int32_t* d_rows, int batch, int obs_rows, int cols, const float* d_prepared, int hidden1, int hidden2,
                   const float* d_u, int32_t* d_actions, float* d_logprobs, void* stream) {
-  if (!d_obs || !d_rows || !d_prepared || !d_u || !d_actions || !d_logprobs) return fail(BBX_E_ARG, "null argument");
-  if (batch < 1 || obs_rows < 1) return fail(BBX_E_ARG, "bad policy shape");
-  if (obs_rows > 1024) return fail(BBX_E_UNSUPPORTED, "the policy kernels score at most 1024 rows per environment (obs_rows = %d)", obs_rows);
-  if (bbx_pmlp2_prepared_floats(cols, hidden1, hidden2) < 0) return BBX_E_UNSUPPORTED;
-  int dev = 0, cus = 0;
-  HIPCHK(hipGetDevice(&dev));
-  HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-  int lrc = bbx_launch_pmlp2_act(d_obs, d_rows, batch, obs_rows, cols, d_prepared, hidden1, hidden2, d_u, d_actions, d_logprobs,
-                                 2 * (cus > 0 ? cus : 256), (hipStream_t)stream);
+  return pmlp_deep_act(d_obs, d_rows, batch, obs_rows, cols, d_prepared, hidden1, 0, hidden2, false, d_u, d_actions, d_logprobs, stream);
+}
+
+int bbx_pmlp3_prepared_floats(int cols, int hidden1, int hidden2, int hidden3) { return pmlp_deep_floats(cols, hidden1, hidden2, hidden3, true); }
+
+int bbx_pmlp3_prepare(const float* d_w1, const float* d_b1, const float* d_w2, const float* d_b2, const float* d_w3, const float* d_b3,
+                      const float* d_w4, const float* d_b4, int cols, int hidden1, int hidden2, int hidden3, float* d_prepared, void* stream) {
+  if (!d_w1 || !d_b1 || !d_w2 || !d_b2 || !d_w3 || !d_b3 || !d_w4 || !d_b4 || !d_prepared) return fail(BBX_E_ARG, "null argument");
+  if (bbx_pmlp3_prepared_floats(cols, hidden1, hidden2, hidden3) < 0) return BBX_E_UNSUPPORTED;
+  int lrc = bbx_launch_pmlp2_prepare(d_w1, d_b1, d_w2, d_b2, d_w3, d_b3, d_w4, d_b4, cols, hidden1, hidden2, hidden3, d_prepared, (hipStream_t)stream);
   if (lrc) return fail(BBX_E_DEVICE, "policy launch failed: %s", hipGetErrorString((hipError_t)lrc));
   return BBX_OK;
+}
+
+int bbx_pmlp3_act(const int32_t* d_obs, const int32_t* d_rows, int batch, int obs_rows, int cols, const float* d_prepared, int hidden1, int hidden2,
+                  int hidden3, const float* d_u, int32_t* d_actions, float* d_logprobs, void* stream) {
+  return pmlp_deep_act(d_obs, d_rows, batch, obs_rows, cols, d_prepared, hidden1, hidden2, hidden3, true, d_u, d_actions, d_logprobs, stream);
 }
 
 int bbx_policy_step_device(bbx_batch* b, const float* d_prepared, int hidden, const float* d_u, int32_t* d_actions, float* d_logprobs,

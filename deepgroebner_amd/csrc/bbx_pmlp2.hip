@@ -26,45 +26,101 @@
 #include "bbx_device.h"
 #include "bbx_pmlp.h"
 
-// prepared weights (floats): W1p [4 KS][HP1] | b1p [HP1] | A2 [HP2 / 16][HP1 / 16][64][4] | b2p [HP2] | w3p [HP2] | b3, pad
+// prepared weights (floats): W1p [4 KS][HP1] | b1p [HP1] | [AM [HPM / 16][HP1 / 16][64][4]] | A2 [HP2 / 16][HPI / 16][64][4] | [bMp [HPM]] |
+// b2p [HP2] | wdp [HP2] | bd, pad          (bracketed: the optional middle hidden layer; HPI = HPM if there is one, else HP1)
 // HP = the layer padded to 64 or 128 units, KS = k-steps of four columns built in
 __host__ __device__ constexpr int pmlp2_hp_for(int hidden) { return hidden <= 64 ? 64 : 128; }
 __host__ __device__ constexpr int pmlp2_ks_for(int cols) { const int ks = (cols + 3) / 4; return ks <= 3 ? 3 : ks <= 8 ? 8 : 16; }
-__host__ __device__ constexpr int pmlp2_prepared_floats(int cols, int h1, int h2) {
-  return (4 * pmlp2_ks_for(cols) + 1) * pmlp2_hp_for(h1) + pmlp2_hp_for(h1) * pmlp2_hp_for(h2) + 2 * pmlp2_hp_for(h2) + 4;
+__host__ __device__ constexpr int pmlp2_prepared_floats(int cols, int hp1, int hpm, int hp2) {   // (padded sizes; hpm = 0: two hidden layers)
+  return (4 * pmlp2_ks_for(cols) + 1) * hp1 + hp1 * hpm + (hpm ? hpm : hp1) * hp2 + hpm + 2 * hp2 + 4;
 }
 constexpr int PMLP2_WAVES = 8;
 
-__global__ void bbx_pmlp2_prepare_kernel(const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
-                                         const float* __restrict__ b2, const float* __restrict__ w3, const float* __restrict__ b3,
-                                         int cols, int h1, int h2, float* __restrict__ out) {
-  const int HP1 = pmlp2_hp_for(h1), HP2 = pmlp2_hp_for(h2), K1 = 4 * pmlp2_ks_for(cols), S4 = HP1 / 16;
-  const int o_b1 = K1 * HP1, o_a2 = o_b1 + HP1, o_b2 = o_a2 + HP1 * HP2, o_w3 = o_b2 + HP2, o_b3 = o_w3 + HP2, total = o_b3 + 4;
+// one permuted second-/third-layer matrix: element t of A[HPO / 16][HPI / 16][64][4]
+__device__ __forceinline__ float pmlp2_perm(const float* __restrict__ w, int hi, int ho, int HPI, int t) {
+  const int S4 = HPI / 16, j = t & 3, lane = (t >> 2) & 63, q = t >> 8, s4 = q % S4, blk = q / S4;
+  const int s = 4 * s4 + j;
+  const int k = 16 * (s >> 2) + 4 * (lane >> 4) + (s & 3), unit = 16 * blk + (lane & 15);
+  return (k < hi && unit < ho) ? w[(size_t)k * ho + unit] : 0.f;
+}
+// hm == 0: two hidden layers (wm / bm unused)
+__global__ void bbx_pmlp2_prepare_kernel(const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ wm,
+                                         const float* __restrict__ bm, const float* __restrict__ w2, const float* __restrict__ b2,
+                                         const float* __restrict__ wd, const float* __restrict__ bd, int cols, int h1, int hm, int h2,
+                                         int HP1, int HPM, int HP2, float* __restrict__ out) {
+  const int K1 = 4 * pmlp2_ks_for(cols), HPI = HPM ? HPM : HP1, hi = HPM ? hm : h1;
+  const int o_b1 = K1 * HP1, o_am = o_b1 + HP1, o_a2 = o_am + HP1 * HPM, o_bm = o_a2 + HPI * HP2, o_b2 = o_bm + HPM, o_wd = o_b2 + HP2,
+            o_bd = o_wd + HP2, total = o_bd + 4;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
     float v = 0.f;
     if (i < o_b1) { const int k = i / HP1, h = i - k * HP1; v = (k < cols && h < h1) ? w1[(size_t)k * h1 + h] : 0.f; }
-    else if (i < o_a2) { const int h = i - o_b1; v = h < h1 ? b1[h] : 0.f; }
-    else if (i < o_b2) {
-      const int t = i - o_a2, j = t & 3, lane = (t >> 2) & 63, q = t >> 8, s4 = q % S4, blk2 = q / S4;
-      const int s = 4 * s4 + j;
-      const int k = 16 * (s >> 2) + 4 * (lane >> 4) + (s & 3), unit = 16 * blk2 + (lane & 15);
-      v = (k < h1 && unit < h2) ? w2[(size_t)k * h2 + unit] : 0.f;
-    }
-    else if (i < o_w3) { const int h = i - o_b2; v = h < h2 ? b2[h] : 0.f; }
-    else if (i < o_b3) { const int h = i - o_w3; v = h < h2 ? w3[h] : 0.f; }
-    else v = i == o_b3 ? b3[0] : 0.f;
+    else if (i < o_am) { const int h = i - o_b1; v = h < h1 ? b1[h] : 0.f; }
+    else if (i < o_a2) v = pmlp2_perm(wm, h1, hm, HP1, i - o_am);
+    else if (i < o_bm) v = pmlp2_perm(w2, hi, h2, HPI, i - o_a2);
+    else if (i < o_b2) { const int h = i - o_bm; v = h < hm ? bm[h] : 0.f; }
+    else if (i < o_wd) { const int h = i - o_b2; v = h < h2 ? b2[h] : 0.f; }
+    else if (i < o_bd) { const int h = i - o_wd; v = h < h2 ? wd[h] : 0.f; }
+    else v = i == o_bd ? bd[0] : 0.f;
     out[i] = v;
   }
 }
 
-template <int HP1, int HP2, int KS>
-__global__ __launch_bounds__(PMLP2_WAVES * WAVE, 2) void bbx_pmlp2_act_kernel(const int32_t* __restrict__ obs, const int32_t* __restrict__ rows, int B,
+// one hidden layer behind the first: hout = relu(b + A hin) (LAST = false) or the deciding layer's dot over it (LAST = true:
+// returns this lane's share of the logit).  Two blocks of 16 units in flight, their A operands requested half a block pair ahead.
+template <int NKI, int NKO, bool LAST>
+__device__ __forceinline__ float pmlp2_hidden(const bbx_f32x4 (&hin)[NKI], bbx_f32x4* hout, const float* A, const float* bl, const float* wl,
+                                              int lane, int lg4) {
+  constexpr int HS = NKI / 2;
+  float part = 0.f;
+  auto pair = [&](int b2i) __attribute__((always_inline)) {
+    bbx_f32x4 acc0 = *(const bbx_f32x4*)(bl + 16 * b2i + 4 * lg4), acc1 = *(const bbx_f32x4*)(bl + 16 * b2i + 16 + 4 * lg4);
+    const bbx_f32x4* ap = (const bbx_f32x4*)A + (size_t)b2i * NKI * 64 + lane;
+#pragma unroll
+    for (int hf = 0; hf < 2; hf++) {
+      bbx_f32x4 av0[HS], av1[HS];
+#pragma unroll
+      for (int q = 0; q < HS; q++) { av0[q] = ap[(hf * HS + q) * 64]; av1[q] = ap[(NKI + hf * HS + q) * 64]; }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < HS; q++) {
+        const bbx_f32x4 hb = hin[hf * HS + q];
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[q].x, hb.x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[q].x, hb.x, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[q].y, hb.y, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[q].y, hb.y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[q].z, hb.z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[q].z, hb.z, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[q].w, hb.w, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[q].w, hb.w, acc1, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    acc0.x = acc0.x > 0.f ? acc0.x : 0.f; acc0.y = acc0.y > 0.f ? acc0.y : 0.f; acc0.z = acc0.z > 0.f ? acc0.z : 0.f; acc0.w = acc0.w > 0.f ? acc0.w : 0.f;
+    acc1.x = acc1.x > 0.f ? acc1.x : 0.f; acc1.y = acc1.y > 0.f ? acc1.y : 0.f; acc1.z = acc1.z > 0.f ? acc1.z : 0.f; acc1.w = acc1.w > 0.f ? acc1.w : 0.f;
+    if constexpr (LAST) {
+      const bbx_f32x4 w0 = *(const bbx_f32x4*)(wl + 16 * b2i + 4 * lg4), w1v = *(const bbx_f32x4*)(wl + 16 * b2i + 16 + 4 * lg4);
+      part = fmaf(acc0.x, w0.x, part); part = fmaf(acc0.y, w0.y, part); part = fmaf(acc0.z, w0.z, part); part = fmaf(acc0.w, w0.w, part);
+      part = fmaf(acc1.x, w1v.x, part); part = fmaf(acc1.y, w1v.y, part); part = fmaf(acc1.z, w1v.z, part); part = fmaf(acc1.w, w1v.w, part);
+    } else { hout[b2i] = acc0; hout[b2i + 1] = acc1; }
+  };
+  if constexpr (LAST) {
+#pragma clang loop unroll(disable)
+    for (int b2i = 0; b2i < NKO; b2i += 2) pair(b2i);
+  } else {
+#pragma unroll
+    for (int b2i = 0; b2i < NKO; b2i += 2) pair(b2i);
+  }
+  return part;
+}
+
+template <int HP1, int HPM, int HP2, int KS, int NWAVES>
+__global__ __launch_bounds__(NWAVES * WAVE, 16 / NWAVES) void bbx_pmlp2_act_kernel(const int32_t* __restrict__ obs, const int32_t* __restrict__ rows, int B,
                                                                              int obs_rows, int cols, const float* __restrict__ wp,
                                                                              const float* __restrict__ u, int32_t* __restrict__ actions,
                                                                              float* __restrict__ logprobs, int lgcap) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int NK1 = HP1 / 16, NK2 = HP2 / 16, A2F = HP1 * HP2;   // blocks of 16 units per layer
-  constexpr int HS = NK1 / 2;                                       // A operands are requested half a block pair at a time
+  constexpr int NK1 = HP1 / 16, NKM = HPM / 16, NK2 = HP2 / 16;    // blocks of 16 units per layer
+  constexpr int HPI = HPM ? HPM : HP1, AMF = HP1 * HPM, A2F = AMF + HPI * HP2 + HPM;   // (A2F: everything in LDS in front of b2)
   float* a2 = (float*)smem;
   const float* W1p = wp;
   const float* b1p = wp + 4 * KS * HP1;
@@ -73,6 +129,9 @@ __global__ __launch_bounds__(PMLP2_WAVES * WAVE, 2) void bbx_pmlp2_act_kernel(co
   // are then LDS reads next to its A operands, not trips to memory in front of every block's MFMAs)
   for (int i = (int)threadIdx.x; i < (A2F + 2 * HP2) / 4; i += (int)blockDim.x) ((bbx_f32x4*)a2)[i] = ((const bbx_f32x4*)a2g)[i];
   __syncthreads();
+  const float* aml = a2;                                                      // middle layer (if any)
+  const float* a2l = a2 + AMF;                                                // last hidden layer
+  const float* bml = a2l + HPI * HP2;
   const float* b2l = a2 + A2F;
   const float* w3l = b2l + HP2;
   const int lane = lane_id(), wave = uni((int)(threadIdx.x / WAVE)), nw = (int)blockDim.x / WAVE;
@@ -139,39 +198,13 @@ __global__ __launch_bounds__(PMLP2_WAVES * WAVE, 2) void bbx_pmlp2_act_kernel(co
         h[j].x = h[j].x > 0.f ? h[j].x : 0.f; h[j].y = h[j].y > 0.f ? h[j].y : 0.f;
         h[j].z = h[j].z > 0.f ? h[j].z : 0.f; h[j].w = h[j].w > 0.f ? h[j].w : 0.f;
       }
-      // ---- layer 2 + deciding layer, two blocks of 16 units at a time
-      float part = 0.f;
-#pragma clang loop unroll(disable)
-      for (int b2i = 0; b2i < NK2; b2i += 2) {
-        bbx_f32x4 acc0 = *(const bbx_f32x4*)(b2l + 16 * b2i + 4 * lg4), acc1 = *(const bbx_f32x4*)(b2l + 16 * b2i + 16 + 4 * lg4);
-        const bbx_f32x4 w0 = *(const bbx_f32x4*)(w3l + 16 * b2i + 4 * lg4), w1v = *(const bbx_f32x4*)(w3l + 16 * b2i + 16 + 4 * lg4);
-        const bbx_f32x4* ap = (const bbx_f32x4*)a2 + (size_t)b2i * NK1 * 64 + lane;
-#pragma unroll
-        for (int hf = 0; hf < 2; hf++) {
-          // the A operands of half of both blocks (2 HS reads of 16 bytes per lane) are requested before their MFMAs
-          bbx_f32x4 av0[HS], av1[HS];
-#pragma unroll
-          for (int q = 0; q < HS; q++) { av0[q] = ap[(hf * HS + q) * 64]; av1[q] = ap[(NK1 + hf * HS + q) * 64]; }
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int q = 0; q < HS; q++) {
-            const bbx_f32x4 hb = h[hf * HS + q];
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[q].x, hb.x, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[q].x, hb.x, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[q].y, hb.y, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[q].y, hb.y, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[q].z, hb.z, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[q].z, hb.z, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[q].w, hb.w, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[q].w, hb.w, acc1, 0, 0, 0);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        part = fmaf(acc0.x > 0.f ? acc0.x : 0.f, w0.x, part); part = fmaf(acc0.y > 0.f ? acc0.y : 0.f, w0.y, part);
-        part = fmaf(acc0.z > 0.f ? acc0.z : 0.f, w0.z, part); part = fmaf(acc0.w > 0.f ? acc0.w : 0.f, w0.w, part);
-        part = fmaf(acc1.x > 0.f ? acc1.x : 0.f, w1v.x, part); part = fmaf(acc1.y > 0.f ? acc1.y : 0.f, w1v.y, part);
-        part = fmaf(acc1.z > 0.f ? acc1.z : 0.f, w1v.z, part); part = fmaf(acc1.w > 0.f ? acc1.w : 0.f, w1v.w, part);
-      }
+      // ---- the hidden layers behind the first, then the deciding layer's dot
+      float part;
+      if constexpr (HPM != 0) {
+        bbx_f32x4 hm[NKM];
+        pmlp2_hidden<NK1, NKM, false>(h, hm, aml, bml, nullptr, lane, lg4);
+        part = pmlp2_hidden<NKM, NK2, true>(hm, nullptr, a2l, b2l, w3l, lane, lg4);
+      } else part = pmlp2_hidden<NK1, NK2, true>(h, nullptr, a2l, b2l, w3l, lane, lg4);
       part += __shfl_xor(part, 16, WAVE);                                     // the other lane groups hold the row's other units
       part += __shfl_xor(part, 32, WAVE);
       if (lg4 == 0 && r0 + lr < tn) lgt[r0 + lr] = part + b3;
@@ -186,31 +219,51 @@ __global__ __launch_bounds__(PMLP2_WAVES * WAVE, 2) void bbx_pmlp2_act_kernel(co
   }
 }
 
-extern "C" int bbx_pmlp2_floats(int cols, int h1, int h2) { return pmlp2_prepared_floats(cols, h1, h2); }
+// padded layer sizes: two hidden layers are padded one by one; with a middle layer all three take the size of the widest
+// (one kernel per size instead of eight)
+static void pmlp2_pads(int h1, int hm, int h2, int* hp1, int* hpm, int* hp2) {
+  if (hm == 0) { *hp1 = pmlp2_hp_for(h1); *hpm = 0; *hp2 = pmlp2_hp_for(h2); return; }
+  const int mx = h1 > hm ? (h1 > h2 ? h1 : h2) : (hm > h2 ? hm : h2);
+  *hp1 = *hpm = *hp2 = pmlp2_hp_for(mx);
+}
 
-extern "C" int bbx_launch_pmlp2_prepare(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, const float* b3,
-                                        int cols, int h1, int h2, float* out, hipStream_t stream) {
-  hipLaunchKernelGGL(bbx_pmlp2_prepare_kernel, dim3(64), dim3(256), 0, stream, w1, b1, w2, b2, w3, b3, cols, h1, h2, out);
+extern "C" int bbx_pmlp2_floats(int cols, int h1, int hm, int h2) {
+  int hp1, hpm, hp2; pmlp2_pads(h1, hm, h2, &hp1, &hpm, &hp2);
+  return pmlp2_prepared_floats(cols, hp1, hpm, hp2);
+}
+
+extern "C" int bbx_launch_pmlp2_prepare(const float* w1, const float* b1, const float* wm, const float* bm, const float* w2, const float* b2,
+                                        const float* wd, const float* bd, int cols, int h1, int hm, int h2, float* out, hipStream_t stream) {
+  int hp1, hpm, hp2; pmlp2_pads(h1, hm, h2, &hp1, &hpm, &hp2);
+  hipLaunchKernelGGL(bbx_pmlp2_prepare_kernel, dim3(64), dim3(256), 0, stream, w1, b1, wm, bm, w2, b2, wd, bd, cols, h1, hm, h2, hp1, hpm, hp2, out);
   return (int)hipGetLastError();
 }
 
-extern "C" int bbx_launch_pmlp2_act(const int32_t* obs, const int32_t* rows, int B, int obs_rows, int cols, const float* wp, int h1, int h2,
-                                    const float* u, int32_t* actions, float* logprobs, int max_blocks, hipStream_t stream) {
-  const int waves = PMLP2_WAVES, hp1 = pmlp2_hp_for(h1), hp2 = pmlp2_hp_for(h2), ks = pmlp2_ks_for(cols);
+extern "C" int bbx_launch_pmlp2_act(const int32_t* obs, const int32_t* rows, int B, int obs_rows, int cols, const float* wp, int h1, int hm, int h2,
+                                    const float* u, int32_t* actions, float* logprobs, int cus, hipStream_t stream) {
+  int hp1, hpm, hp2; pmlp2_pads(h1, hm, h2, &hp1, &hpm, &hp2);
+  const int ks = pmlp2_ks_for(cols);
+  // 64 KB of second-layer weights: two workgroups of 8 waves per CU; with a middle layer of that size (128 KB): one of 16
+  const int waves = (hpm == 128) ? 16 : PMLP2_WAVES;
   int lgcap = obs_rows < PMLP_MAXROWS ? obs_rows : PMLP_MAXROWS;              // logits per wave: what the block can hold
   lgcap = (lgcap + 63) / 64 * 64;
-  const size_t ml = ((size_t)hp1 * hp2 + 2 * hp2) * sizeof(float) + (size_t)waves * lgcap * sizeof(float) + (size_t)(2 * waves + 1) * sizeof(int) + (size_t)waves * 64 * sizeof(unsigned short);
+  const size_t ml = ((size_t)hp1 * hpm + (size_t)(hpm ? hpm : hp1) * hp2 + hpm + 2 * hp2) * sizeof(float) + (size_t)waves * lgcap * sizeof(float) +
+                    (size_t)(2 * waves + 1) * sizeof(int) + (size_t)waves * 64 * sizeof(unsigned short);
+  const int max_blocks = (waves == 16 ? 1 : 2) * (cus > 0 ? cus : 256);
   int blocks = (B + waves - 1) / waves;
   blocks = blocks < max_blocks ? blocks : max_blocks;
-#define BBX_P2(N1, N2, K) do { \
+#define BBX_P2(N1, NM, N2, K, NW) do { \
     static size_t set_ = 0;            /* (once per size: the call is not free) */ \
     if (set_ < ml) { \
-      hipError_t err_ = hipFuncSetAttribute((const void*)bbx_pmlp2_act_kernel<N1, N2, K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ml); \
+      hipError_t err_ = hipFuncSetAttribute((const void*)bbx_pmlp2_act_kernel<N1, NM, N2, K, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ml); \
       if (err_ != hipSuccess) return (int)err_; \
       set_ = ml; } \
-    hipLaunchKernelGGL((bbx_pmlp2_act_kernel<N1, N2, K>), dim3(blocks), dim3(waves * WAVE), ml, stream, obs, rows, B, obs_rows, cols, wp, u, actions, logprobs, lgcap); } while (0)
-#define BBX_P2_K(N1, N2) do { if (ks == 3) BBX_P2(N1, N2, 3); else if (ks == 8) BBX_P2(N1, N2, 8); else BBX_P2(N1, N2, 16); } while (0)
-  if (hp1 == 64 && hp2 == 64) BBX_P2_K(64, 64); else if (hp1 == 64) BBX_P2_K(64, 128); else if (hp2 == 64) BBX_P2_K(128, 64); else BBX_P2_K(128, 128);
+    hipLaunchKernelGGL((bbx_pmlp2_act_kernel<N1, NM, N2, K, NW>), dim3(blocks), dim3(NW * WAVE), ml, stream, obs, rows, B, obs_rows, cols, wp, u, actions, logprobs, lgcap); } while (0)
+#define BBX_P2_K(N1, NM, N2, NW) do { if (ks == 3) BBX_P2(N1, NM, N2, 3, NW); else if (ks == 8) BBX_P2(N1, NM, N2, 8, NW); else BBX_P2(N1, NM, N2, 16, NW); } while (0)
+  if (hpm == 128) BBX_P2_K(128, 128, 128, 16);
+  else if (hpm == 64) BBX_P2_K(64, 64, 64, 8);
+  else if (hp1 == 64 && hp2 == 64) BBX_P2_K(64, 0, 64, 8); else if (hp1 == 64) BBX_P2_K(64, 0, 128, 8);
+  else if (hp2 == 64) BBX_P2_K(128, 0, 64, 8); else BBX_P2_K(128, 0, 128, 8);
 #undef BBX_P2_K
 #undef BBX_P2
   return (int)hipGetLastError();

@@ -88,8 +88,8 @@ class PMLPPolicy(torch.nn.Module):
     @torch.no_grad()
     def act(self, obs, rows, u, actions=None, logprobs=None, stream=None):
         """Sample one action per environment by inverse CDF from the uniforms u [B] -> (actions int32 [B], logprobs
-        float32 [B]) on the device.  One hidden layer: the fused HIP kernel (bbx_pmlp_act); two hidden layers of at most 128
-        units: bbx_pmlp2_act; otherwise torch ops."""
+        float32 [B]) on the device.  One hidden layer: the fused HIP kernel (bbx_pmlp_act); two or three hidden layers of at
+        most 128 units: bbx_pmlp2_act / bbx_pmlp3_act; otherwise torch ops."""
         B, R, cols = obs.shape
         if actions is None:
             actions = torch.empty(B, dtype=torch.int32, device=obs.device)
@@ -101,38 +101,50 @@ class PMLPPolicy(torch.nn.Module):
             _ffi.check(_ffi.lib().bbx_pmlp_act(C.c_void_p(obs.data_ptr()), C.c_void_p(rows.data_ptr()), B, R, cols, w["prepared"], w["hidden"],
                                                C.c_void_p(u.data_ptr()), C.c_void_p(actions.data_ptr()), C.c_void_p(logprobs.data_ptr()), C.c_void_p(s)))
             return actions, logprobs
-        if len(self.embedding) == 2 and self.fused2_ok(cols, self.embedding[0].out_features, self.embedding[1].out_features) and R <= 1024:
-            w = self._fused2_weights()
+        if self.deep_ok(cols) and R <= 1024:
+            w = self._deep_weights()
             s = (stream if stream is not None else torch.cuda.current_stream()).cuda_stream
-            _ffi.check(_ffi.lib().bbx_pmlp2_act(C.c_void_p(obs.data_ptr()), C.c_void_p(rows.data_ptr()), B, R, cols, w["prepared"], w["hidden1"], w["hidden2"],
-                                                C.c_void_p(u.data_ptr()), C.c_void_p(actions.data_ptr()), C.c_void_p(logprobs.data_ptr()), C.c_void_p(s)))
+            fn = _ffi.lib().bbx_pmlp2_act if len(w["hidden"]) == 2 else _ffi.lib().bbx_pmlp3_act
+            _ffi.check(fn(C.c_void_p(obs.data_ptr()), C.c_void_p(rows.data_ptr()), B, R, cols, w["prepared"], *w["hidden"],
+                          C.c_void_p(u.data_ptr()), C.c_void_p(actions.data_ptr()), C.c_void_p(logprobs.data_ptr()), C.c_void_p(s)))
             return actions, logprobs
         return self.act_torch(obs, rows, u, actions, logprobs)
+
+    def deep_ok(self, cols):
+        """Two or three hidden layers of at most 128 units: the shapes bbx_pmlp2_act / bbx_pmlp3_act are built for."""
+        return len(self.embedding) in (2, 3) and all(1 <= l.out_features <= 128 for l in self.embedding) and 1 <= cols <= 64
 
     @staticmethod
     def fused2_ok(cols, hidden1, hidden2):
         """Shapes the two-layer policy kernel is built for (bbx_pmlp2_prepared_floats >= 0)."""
         return 1 <= hidden1 <= 128 and 1 <= hidden2 <= 128 and 1 <= cols <= 64
 
-    def _fused2_weights(self):
-        """The two-layer kernel's view of the weights (bbx_pmlp2_prepare), rebuilt only when a parameter changed."""
-        l1, l2 = self.embedding
+    def _deep_weights(self):
+        """The two- / three-layer kernel's view of the weights (bbx_pmlp2_prepare / bbx_pmlp3_prepare), rebuilt only when a
+        parameter changed, in the same buffer (a recorded graph keeps reading it)."""
         key = tuple(p._version for p in self.parameters()) + tuple(p.data_ptr() for p in self.parameters())
-        c = self.__dict__.get("_fused2_cache")
+        c = self.__dict__.get("_deep_cache")
         if c is None or c["key"] != key:
-            cols, h1, h2 = l1.in_features, l1.out_features, l2.out_features
-            t = [l1.weight.detach().t().contiguous().float(), l1.bias.detach().contiguous().float(),
-                 l2.weight.detach().t().contiguous().float(), l2.bias.detach().contiguous().float(),
-                 self.deciding.weight.detach().reshape(-1).contiguous().float(), self.deciding.bias.detach().reshape(-1).contiguous().float()]
-            nfl = _ffi.lib().bbx_pmlp2_prepared_floats(cols, h1, h2)
+            cols = self.embedding[0].in_features
+            hidden = [l.out_features for l in self.embedding]
+            t = []
+            for l in self.embedding:
+                t += [l.weight.detach().t().contiguous().float(), l.bias.detach().contiguous().float()]
+            t += [self.deciding.weight.detach().reshape(-1).contiguous().float(), self.deciding.bias.detach().reshape(-1).contiguous().float()]
+            lib = _ffi.lib()
+            nfl = lib.bbx_pmlp2_prepared_floats(cols, *hidden) if len(hidden) == 2 else lib.bbx_pmlp3_prepared_floats(cols, *hidden)
             _ffi.check(min(nfl, 0))
             prep = c["keep"][0] if c is not None and c["keep"][0].numel() == nfl and c["keep"][0].device == t[0].device else \
-                torch.empty(nfl, dtype=torch.float32, device=t[0].device)   # (refilled in place: a recorded graph keeps reading this buffer)
-            _ffi.check(_ffi.lib().bbx_pmlp2_prepare(*[C.c_void_p(x.data_ptr()) for x in t], cols, h1, h2, C.c_void_p(prep.data_ptr()),
-                                                    C.c_void_p(torch.cuda.current_stream().cuda_stream)))
-            c = {"key": key, "keep": (prep, t), "prepared": C.c_void_p(prep.data_ptr()), "hidden1": h1, "hidden2": h2}
-            self.__dict__["_fused2_cache"] = c
+                torch.empty(nfl, dtype=torch.float32, device=t[0].device)
+            prepare = lib.bbx_pmlp2_prepare if len(hidden) == 2 else lib.bbx_pmlp3_prepare
+            _ffi.check(prepare(*[C.c_void_p(x.data_ptr()) for x in t], cols, *hidden, C.c_void_p(prep.data_ptr()),
+                               C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+            c = {"key": key, "keep": (prep, t), "prepared": C.c_void_p(prep.data_ptr()), "hidden": hidden}
+            self.__dict__["_deep_cache"] = c
         return c
+
+    def _fused2_weights(self):
+        return self._deep_weights()
 
     @staticmethod
     def fused_ok(cols, hidden):
@@ -407,8 +419,8 @@ def _run_rollout_graph(env, policy, nsteps, obs_rows, generator, sync_every):
         c["graph"] = g
         cache[key] = c
     stream = torch.cuda.current_stream()
-    if len(policy.embedding) == 2 and policy.fused2_ok(cols, policy.embedding[0].out_features, policy.embedding[1].out_features) and obs_rows <= 1024:
-        policy._fused2_weights()                       # (weights changed since the recording: the prepared copy is refilled in place)
+    if policy.deep_ok(cols) and obs_rows <= 1024:
+        policy._deep_weights()                       # (weights changed since the recording: the prepared copy is refilled in place)
     st0 = env.stats()
     env.rollout_device("first", 0, False, stream.cuda_stream, c["rew"], c["done"], c["rows"], c["obs"], obs_rows, True, False)
     env.sync()

@@ -203,6 +203,14 @@ int bbx_pmlp2_prepare(const float* d_w1, const float* d_b1, const float* d_w2, c
                       int cols, int hidden1, int hidden2, float* d_prepared, void* stream);
 int bbx_pmlp2_act(const int32_t* d_obs, const int32_t* d_rows, int batch, int obs_rows, int cols, const float* d_prepared, int hidden1, int hidden2,
                   const float* d_u, int32_t* d_actions, float* d_logprobs, void* stream);
+/* ... and for three hidden layers (hidden_layers=[hidden1, hidden2, hidden3], each <= 128): the same kernel with a middle layer
+ * whose output stays in registers as the next layer's B operands; d_w3 [hidden2][hidden3], d_b3 [hidden3], d_w4 [hidden3],
+ * d_b4 [1].  All three layers are padded to the widest one's tile size (64 or 128 units). */
+int bbx_pmlp3_prepared_floats(int cols, int hidden1, int hidden2, int hidden3);   /* < 0: shape not supported */
+int bbx_pmlp3_prepare(const float* d_w1, const float* d_b1, const float* d_w2, const float* d_b2, const float* d_w3, const float* d_b3,
+                      const float* d_w4, const float* d_b4, int cols, int hidden1, int hidden2, int hidden3, float* d_prepared, void* stream);
+int bbx_pmlp3_act(const int32_t* d_obs, const int32_t* d_rows, int batch, int obs_rows, int cols, const float* d_prepared, int hidden1, int hidden2,
+                  int hidden3, const float* d_u, int32_t* d_actions, float* d_logprobs, void* stream);
 /* One vector step with the policy in the loop: bbx_pmlp_act on the block the previous call left in d_obs / d_rows, then
  * bbx_step_device_autoreset with the sampled rows as actions, which rewrites d_obs / d_rows (the inner loop of
  * pg.py:451-503 run_episode, batched).  Where the step kernel has the policy built in (the register/LDS-resident class

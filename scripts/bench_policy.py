@@ -21,8 +21,8 @@ ap.add_argument("--dist", default="3-20-10-weighted")
 ap.add_argument("--batch", type=int, default=4096)
 ap.add_argument("--steps", type=int, default=2000)
 ap.add_argument("--k", type=int, default=2)
-ap.add_argument("--hidden", default="128", help="hidden layer sizes, e.g. 128 or 128,128 (more than one layer: always --per-step; two layers of <= 128 "
-                                              "units: bbx_pmlp2_act in front of bbx_step_device_autoreset, deeper: torch ops)")
+ap.add_argument("--hidden", default="128", help="hidden layer sizes, e.g. 128 or 128,128 (more than one layer: always --per-step; two or three layers "
+                                              "of <= 128 units: bbx_pmlp2_act / bbx_pmlp3_act in front of bbx_step_device_autoreset, else: torch ops)")
 ap.add_argument("--graph", action="store_true", help="deeper policies: replay the vector step from a HIP graph (run_rollout(graph=True))")
 ap.add_argument("--obs-rows", type=int, default=256)
 ap.add_argument("--store", action="store_true", help="also record the trajectory (actions, rewards, log-probabilities, dones) on the device")
@@ -61,7 +61,7 @@ d = st - st0
 assert (d[:, 0] == a.steps).all() and (st[:, 4] == 0).all()
 assert int(episodes.sum()) == int(d[:, 2].sum()) and float(total.sum()) == -float(d[:, 1].sum())
 print(json.dumps({"dist": a.dist, "batch": B, "steps": a.steps, "policy": "PMLP(%s)" % hidden,
-                  "mode": ("policy kernel (bbx_pmlp2_act) + bbx_step_device_autoreset per step" if len(hidden) == 2 and policy.fused2_ok(env.cols, *hidden) else
+                  "mode": ("policy kernel (bbx_pmlp%d_act) + bbx_step_device_autoreset per step" % len(hidden) if policy.deep_ok(env.cols) else
                            "torch ops + bbx_step_device_autoreset per step" + (", replayed from a HIP graph" if a.graph else "")) if len(hidden) > 1 else ("one call per step (bbx_policy_step_device)" + (", calls joining persistent sessions" if a.per_step and not a.no_persistent and not a.store and not a.store_states else "")) if a.per_step else "policy rollout kernel, %d steps per launch" % a.chunk,
                   "store": "trajectory + states" if a.store_states else ("trajectory" if a.store else "nothing"),
                   "env_steps_per_s": B * a.steps / dt, "us_per_vector_step": dt / a.steps * 1e6,

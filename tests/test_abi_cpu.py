@@ -134,4 +134,8 @@ def test_policy_shapes_are_checked_on_the_host(ffi_):
     for bad in ((65, 128, 128), (12, 129, 128), (12, 128, 0)):
         assert dll.bbx_pmlp2_prepared_floats(*bad) == -5
         assert b"two-layer" in dll.bbx_last_error()
+    assert dll.bbx_pmlp3_prepared_floats(12, 128, 128, 128) == (4 * 3 + 1) * 128 + 2 * 128 * 128 + 3 * 128 + 4
+    assert dll.bbx_pmlp3_prepared_floats(12, 40, 64, 17) == (4 * 3 + 1) * 64 + 2 * 64 * 64 + 3 * 64 + 4
+    assert dll.bbx_pmlp3_prepared_floats(12, 40, 100, 17) == (4 * 3 + 1) * 128 + 2 * 128 * 128 + 3 * 128 + 4   # (all three padded to the widest)
+    assert dll.bbx_pmlp3_prepared_floats(12, 40, 129, 17) == -5 and b"three-layer" in dll.bbx_last_error()
     assert dll.bbx_graph_replayed(None, None) == -1                                                   # BBX_E_ARG

@@ -150,11 +150,13 @@ def test_fused_policy_kernel_matches_torch_module(dist, k, hidden):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dist,k,hidden", [("3-20-10-weighted", 2, (128, 128)), ("5-10-5-uniform", 1, (64, 128)), ("3-20-10-uniform", 3, (100, 40)),
-                                           ("4-5-4-uniform", 1, (32, 7)), ("5-10-5-uniform", 3, (128, 64)), ("6-3-4-uniform", 3, (128, 128))])
+                                           ("4-5-4-uniform", 1, (32, 7)), ("5-10-5-uniform", 3, (128, 64)), ("6-3-4-uniform", 3, (128, 128)),
+                                           ("3-20-10-weighted", 2, (128, 128, 128)), ("5-10-5-uniform", 3, (40, 100, 17)),
+                                           ("4-5-4-uniform", 1, (64, 33, 64)), ("6-3-4-uniform", 3, (128, 96, 128))])
 def test_fused_two_layer_policy_kernel_matches_torch_module(dist, k, hidden):
-    """bbx_pmlp2_act (two hidden layers on the matrix cores, the second layer's k-steps in the order the first layer's
-    accumulators lie) against the torch module: every unit-block combination, all three k-step counts, layer sizes that do
-    not fill a tile, environments with more than one tile of rows."""
+    """bbx_pmlp2_act / bbx_pmlp3_act (two / three hidden layers on the matrix cores, each layer's k-steps in the order the
+    previous layer's accumulators lie) against the torch module: every padded-size combination, all three k-step counts,
+    layer sizes that do not fill a tile, environments with more than two tiles of rows (shared among the workgroup)."""
     import torch
     from deepgroebner_amd import VecLeadMonomialsEnv
     from deepgroebner_amd.rollout import PMLPPolicy
@@ -170,7 +172,7 @@ def test_fused_two_layer_policy_kernel_matches_torch_module(dist, k, hidden):
     env.sync()
     assert int(rows.max()) <= R and int(rows.min()) >= 1
     policy = PMLPPolicy(env.cols, list(hidden)).cuda()
-    assert policy.fused2_ok(env.cols, *hidden)
+    assert policy.deep_ok(env.cols)
     with torch.no_grad():
         for lin in list(policy.embedding) + [policy.deciding]:
             lin.weight.mul_(0.3)
@@ -190,18 +192,18 @@ def test_fused_two_layer_policy_kernel_matches_torch_module(dist, k, hidden):
                 lo, hi = sorted((int(a_k[e]), int(a_t[e])))
                 assert hi - lo == 1 and abs(float(cdf[e, lo]) - float(u[e])) < 1e-4, e
         if trial == 0:                                            # an optimiser step: the prepared copy follows, in the same buffer
-            before = policy._fused2_weights()["prepared"].value
+            before = policy._deep_weights()["prepared"].value
             with torch.no_grad():
                 policy.embedding[1].weight.add_(0.01)
-            assert policy._fused2_weights()["prepared"].value == before
+            assert policy._deep_weights()["prepared"].value == before
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("hidden", [(64, 64), (32, 32, 32)])
+@pytest.mark.parametrize("hidden", [(64, 64), (32, 32, 32), (32, 32, 32, 32)])
 def test_rollout_replayed_from_a_hip_graph_equals_the_eager_rollout(hidden):
     """run_rollout(graph=True): the vector step (policy ops + bbx_step_device_autoreset) recorded once and replayed gives the
-    rollout of the same calls made one by one — two hidden layers (bbx_pmlp2_act in the graph) and three (torch ops in the
-    graph); a second call reuses the recording; bbx_graph_replayed makes bbx_sync see the replayed work."""
+    rollout of the same calls made one by one — two and three hidden layers (bbx_pmlp2_act / bbx_pmlp3_act in the graph)
+    and four (torch ops in the graph); a second call reuses the recording; bbx_graph_replayed makes bbx_sync see the replayed work."""
     import torch
     from deepgroebner_amd import VecLeadMonomialsEnv
     from deepgroebner_amd.rollout import PMLPPolicy, run_rollout
@@ -244,7 +246,7 @@ def test_records_outgrown_inside_a_chain_of_device_steps_are_reported(graph):
     B = 64
     env = VecLeadMonomialsEnv("3-20-10-weighted", batch=B, k=2, caps={"max_basis": 16, "max_pairs": 32})
     env.seed(np.arange(B) + 300); env.reset()
-    policy = PMLPPolicy(env.cols, [32, 32, 32]).cuda()
+    policy = PMLPPolicy(env.cols, [32, 32, 32, 32]).cuda()            # (torch ops: the path whose steps a graph is worth recording)
     g = torch.Generator(device="cuda"); g.manual_seed(3)
     kinds = []
     clean = 0
