@@ -1,4 +1,6 @@
-// PMLP policy with TWO hidden layers on the observation block (ParallelMultilayerPerceptron(hidden_layers=[h1, h2]),
+// PMLP policy with TWO or THREE hidden layers on the observation block (ParallelMultilayerPerceptron(hidden_layers=[h1, h2]) or
+// [h1, hm, h2]; the text below describes two: a middle layer is the second layer's code with its output kept in registers,
+// which is again the layout the next layer wants — pmlp2_hidden<.., LAST = false>),
 // networks.py:522-571: ParallelEmbeddingLayer :49-95 with two dense layers + ParallelDecidingLayer :414-460), evaluated and
 // sampled on the device like the one-layer kernel of bbx_pmlp.h:
 //     logit_r = w3 . relu(W2^T relu(W1^T x_r + b1) + b2) + b3,  log-softmax over the rows of an environment, inverse-CDF draw.
