@@ -142,14 +142,14 @@ __global__ __launch_bounds__(NWAVES * WAVE, 16 / NWAVES) void bbx_pmlp2_act_kern
   const float b3 = a2g[A2F + 2 * HP2];
   // A wave's tiles run one after the other, so with one environment per wave a launch lasts as long as its LARGEST pair set
   // (B = 4096: the mean is 1.7 tiles, the maximum 5-7; measured 60 us per launch for 25 us of matrix-core time, the same with
-  // two or four waves per SIMD).  The wave therefore takes only the first two tiles of its environment itself; further tiles
-  // go to a queue of the workgroup and are shared out among its eight waves after a barrier (logits land in the owner's LDS
-  // buffer), and the owner samples after a second barrier.
+  // two or four waves per SIMD).  The wave therefore takes only the first tile of its environment itself; further tiles go
+  // to a queue of the workgroup from which its waves help themselves (an LDS counter; logits land in the owner's LDS buffer),
+  // and the owner samples after a barrier.
   float* lg_base = a2 + A2F + 2 * HP2;
   int* s_env = (int*)(lg_base + (size_t)nw * lgcap);                          // [nw] environment of each wave this round
   int* s_n = s_env + nw;                                                      // [nw] its row count
-  int* s_q = s_n + nw;                                                        // queue length
-  unsigned short* queue = (unsigned short*)(s_q + 1);                         // [nw * 64] (wave << 8) | tile
+  int* s_q = s_n + nw;                                                        // queue length, and (s_q[1]) how much of it has been taken
+  unsigned short* queue = (unsigned short*)(s_q + 2);                         // [nw * 64] (wave << 8) | tile
   for (int base = (int)blockIdx.x * nw; base < B; base += (int)gridDim.x * nw) {
     const int env = base + wave;
     const bool valid = env < B;
@@ -159,15 +159,26 @@ __global__ __launch_bounds__(NWAVES * WAVE, 16 / NWAVES) void bbx_pmlp2_act_kern
     const int T = (n + 15) >> 4;
     __syncthreads();                                                          // (the previous round is over: logits, queue)
     if (lane == 0) { s_env[wave] = env; s_n[wave] = n; }
-    if (threadIdx.x == 0) *s_q = 0;
+    if (threadIdx.x == 0) { s_q[0] = 0; s_q[1] = 0; }
     __syncthreads();
-    if (lane < T - 2) queue[atomicAdd(s_q, 1)] = (unsigned short)((wave << 8) | (2 + lane));
-  for (int phase = 0; phase < 2; phase++) {
-    int cnt = T < 2 ? T : 2;
-    if (phase == 1) { __syncthreads(); cnt = uni(*s_q); }
-    for (int it = phase == 0 ? 0 : wave; it < cnt; it += (phase == 0 ? 1 : nw)) {
-      int w = wave, t = it;
-      if (phase == 1) { const int e = uni((int)queue[it]); w = e >> 8; t = e & 255; }
+    if (lane < T - 1) queue[atomicAdd(s_q, 1)] = (unsigned short)((wave << 8) | (1 + lane));
+    __syncthreads();
+    const int nq = uni(s_q[0]);
+  {
+    // the wave's own first tile, then tiles from the queue for as long as there are any: a wave whose environment has one tile
+    // helps with the others' second and third at once (a barrier between "own" and "shared" tiles had the one-tile waves wait
+    // 11 us per launch for the two-tile waves, with the matrix cores half idle)
+    bool own = T > 0;
+    for (;;) {
+      int w = wave, t = 0;
+      if (own) own = false;
+      else {
+        int idx = 0;
+        if (lane == 0) idx = atomicAdd(&s_q[1], 1);
+        idx = __builtin_amdgcn_readfirstlane(idx);
+        if (idx >= nq) break;
+        const int e = uni((int)queue[idx]); w = e >> 8; t = e & 255;
+      }
       const int tn = uni(s_n[w]), r0 = 16 * t;
       const int32_t* ob = obs + (size_t)uni(s_env[w]) * obs_rows * cols;
       float* lgt = lg_base + (size_t)w * lgcap;
@@ -250,7 +261,7 @@ extern "C" int bbx_launch_pmlp2_act(const int32_t* obs, const int32_t* rows, int
   int lgcap = obs_rows < PMLP_MAXROWS ? obs_rows : PMLP_MAXROWS;              // logits per wave: what the block can hold
   lgcap = (lgcap + 63) / 64 * 64;
   const size_t ml = ((size_t)hp1 * hpm + (size_t)(hpm ? hpm : hp1) * hp2 + hpm + 2 * hp2) * sizeof(float) + (size_t)waves * lgcap * sizeof(float) +
-                    (size_t)(2 * waves + 1) * sizeof(int) + (size_t)waves * 64 * sizeof(unsigned short);
+                    (size_t)(2 * waves + 2) * sizeof(int) + (size_t)waves * 64 * sizeof(unsigned short);
   const int max_blocks = (waves == 16 ? 1 : 2) * (cus > 0 ? cus : 256);
   int blocks = (B + waves - 1) / waves;
   blocks = blocks < max_blocks ? blocks : max_blocks;
