@@ -129,6 +129,23 @@ __global__ __launch_bounds__(NWAVES * WAVE, 16 / NWAVES) void bbx_pmlp2_act_kern
   const float* a2g = b1p + HP1;
   // (A2 | b2p | w3p are contiguous in the prepared buffer: one copy; the biases and the deciding weights of a block of units
   // are then LDS reads next to its A operands, not trips to memory in front of every block's MFMAs)
+  // what the wave's own first tile needs from memory — its environment's row count and uniform number, the tile's rows — is
+  // requested before the staging, not behind it (narrow rows only: the values wait in registers)
+  constexpr bool PRE = KS == 3;
+  float xa0[KS]; int n0 = 0; float uu0 = 0.f;
+  if (PRE) {
+    int e0 = (int)blockIdx.x * ((int)blockDim.x / WAVE) + (int)(threadIdx.x / WAVE);
+    e0 = e0 < B ? e0 : B - 1;
+    n0 = rows[e0]; uu0 = u[e0];
+    int r = (int)(threadIdx.x & 15); r = r < obs_rows ? r : obs_rows - 1;
+    const int32_t* xr = obs + ((size_t)e0 * obs_rows + r) * cols;
+#pragma unroll
+    for (int s = 0; s < KS; s++) {
+      const int k = 4 * s + (int)((threadIdx.x & 63) >> 4);
+      const int32_t xi = xr[k < cols ? k : 0];
+      xa0[s] = k < cols ? (float)xi : 0.f;
+    }
+  }
   for (int i = (int)threadIdx.x; i < (A2F + 2 * HP2) / 4; i += (int)blockDim.x) ((bbx_f32x4*)a2)[i] = ((const bbx_f32x4*)a2g)[i];
   __syncthreads();
   const float* aml = a2;                                                      // middle layer (if any)
@@ -153,8 +170,9 @@ __global__ __launch_bounds__(NWAVES * WAVE, 16 / NWAVES) void bbx_pmlp2_act_kern
   for (int base = (int)blockIdx.x * nw; base < B; base += (int)gridDim.x * nw) {
     const int env = base + wave;
     const bool valid = env < B;
-    int n = valid ? uni(rows[env]) : 0;
-    const float uu = valid ? u[env] : 0.f;
+    const bool round0 = PRE && base == (int)blockIdx.x * nw;
+    int n = valid ? uni(round0 ? n0 : rows[env]) : 0;
+    const float uu = valid ? (round0 ? uu0 : u[env]) : 0.f;
     n = n < obs_rows ? n : obs_rows; n = n < PMLP_MAXROWS ? n : PMLP_MAXROWS; n = n > 0 ? n : 0;
     const int T = (n + 15) >> 4;
     __syncthreads();                                                          // (the previous round is over: logits, queue)
@@ -171,7 +189,8 @@ __global__ __launch_bounds__(NWAVES * WAVE, 16 / NWAVES) void bbx_pmlp2_act_kern
     bool own = T > 0;
     for (;;) {
       int w = wave, t = 0;
-      if (own) own = false;
+      bool pre = false;
+      if (own) { own = false; pre = round0; }
       else {
         int idx = 0;
         if (lane == 0) idx = atomicAdd(&s_q[1], 1);
@@ -186,11 +205,16 @@ __global__ __launch_bounds__(NWAVES * WAVE, 16 / NWAVES) void bbx_pmlp2_act_kern
       int r = r0 + lr; r = r < obs_rows ? r : obs_rows - 1;                   // inside the block whatever the row count is
       const int32_t* xr = ob + (size_t)r * cols;
       float xa[KS];
+      if (pre) {
 #pragma unroll
-      for (int s = 0; s < KS; s++) {
-        const int k = 4 * s + lg4;
-        const int32_t xi = xr[k < cols ? k : 0];
-        xa[s] = k < cols ? (float)xi : 0.f;
+        for (int s = 0; s < KS; s++) xa[s] = xa0[s];
+      } else {
+#pragma unroll
+        for (int s = 0; s < KS; s++) {
+          const int k = 4 * s + lg4;
+          const int32_t xi = xr[k < cols ? k : 0];
+          xa[s] = k < cols ? (float)xi : 0.f;
+        }
       }
       // ---- layer 1: h[blk][v] = relu(b1 + sum_k W1[k][unit] x[row][k]), unit = 16 blk + 4 (lane >> 4) + v
       // (the first-layer weights stay in memory: L1 hits; the base pointer is opaque per tile so that the optimiser does not
