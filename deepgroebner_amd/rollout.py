@@ -114,11 +114,6 @@ class PMLPPolicy(torch.nn.Module):
         """Two or three hidden layers of at most 128 units: the shapes bbx_pmlp2_act / bbx_pmlp3_act are built for."""
         return len(self.embedding) in (2, 3) and all(1 <= l.out_features <= 128 for l in self.embedding) and 1 <= cols <= 64
 
-    @staticmethod
-    def fused2_ok(cols, hidden1, hidden2):
-        """Shapes the two-layer policy kernel is built for (bbx_pmlp2_prepared_floats >= 0)."""
-        return 1 <= hidden1 <= 128 and 1 <= hidden2 <= 128 and 1 <= cols <= 64
-
     def _deep_weights(self):
         """The two- / three-layer kernel's view of the weights (bbx_pmlp2_prepare / bbx_pmlp3_prepare), rebuilt only when a
         parameter changed, in the same buffer (a recorded graph keeps reading it)."""
@@ -142,9 +137,6 @@ class PMLPPolicy(torch.nn.Module):
             c = {"key": key, "keep": (prep, t), "prepared": C.c_void_p(prep.data_ptr()), "hidden": hidden}
             self.__dict__["_deep_cache"] = c
         return c
-
-    def _fused2_weights(self):
-        return self._deep_weights()
 
     @staticmethod
     def fused_ok(cols, hidden):
