@@ -1207,7 +1207,7 @@ extern "C" int bbx_pmlp2_floats(int cols, int h1, int hm, int h2);
 extern "C" int bbx_launch_pmlp2_prepare(const float* w1, const float* b1, const float* wm, const float* bm, const float* w2, const float* b2,
                                         const float* wd, const float* bd, int cols, int h1, int hm, int h2, float* out, hipStream_t stream);
 extern "C" int bbx_launch_pmlp2_act(const int32_t* obs, const int32_t* rows, int B, int obs_rows, int cols, const float* wp, int h1, int hm, int h2,
-                                    const float* u, int32_t* actions, float* logprobs, int cus, hipStream_t stream);
+                                    const float* u, int32_t* actions, float* logprobs, int cus, int max_lds, hipStream_t stream);
 
 static int pmlp_deep_floats(int cols, int h1, int hm, int h2, bool three) {
   if (cols < 1 || cols > 64 || h1 < 1 || h1 > 128 || h2 < 1 || h2 > 128 || (three && (hm < 1 || hm > 128)))
@@ -1224,7 +1224,10 @@ static int pmlp_deep_act(const int32_t* d_obs, const int32_t* d_rows, int batch,
   int dev = 0, cus = 0;
   HIPCHK(hipGetDevice(&dev));
   HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-  int lrc = bbx_launch_pmlp2_act(d_obs, d_rows, batch, obs_rows, cols, d_prepared, h1, three ? hm : 0, h2, d_u, d_actions, d_logprobs, cus, (hipStream_t)stream);
+  int max_lds = 0;
+  HIPCHK(hipDeviceGetAttribute(&max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev));
+  int lrc = bbx_launch_pmlp2_act(d_obs, d_rows, batch, obs_rows, cols, d_prepared, h1, three ? hm : 0, h2, d_u, d_actions, d_logprobs, cus,
+                                 max_lds > 0 ? max_lds : 65536, (hipStream_t)stream);
   if (lrc) return fail(BBX_E_DEVICE, "policy launch failed: %s", hipGetErrorString((hipError_t)lrc));
   return BBX_OK;
 }

@@ -277,16 +277,22 @@ extern "C" int bbx_launch_pmlp2_prepare(const float* w1, const float* b1, const 
 }
 
 extern "C" int bbx_launch_pmlp2_act(const int32_t* obs, const int32_t* rows, int B, int obs_rows, int cols, const float* wp, int h1, int hm, int h2,
-                                    const float* u, int32_t* actions, float* logprobs, int cus, hipStream_t stream) {
+                                    const float* u, int32_t* actions, float* logprobs, int cus, int max_lds, hipStream_t stream) {
   int hp1, hpm, hp2; pmlp2_pads(h1, hm, h2, &hp1, &hpm, &hp2);
   const int ks = pmlp2_ks_for(cols);
-  // 64 KB of second-layer weights: two workgroups of 8 waves per CU; with a middle layer of that size (128 KB): one of 16
-  const int waves = (hpm == 128) ? 16 : PMLP2_WAVES;
+  // 64 KB of second-layer weights: two workgroups of 8 waves per CU; with a middle layer of that size (128 KB): one workgroup
+  // of 16 waves — or of 8 or 4 where tall observation blocks (obs_rows up to 1024: 4 KB of logits per wave) leave less room
+  int waves = (hpm == 128) ? 16 : PMLP2_WAVES;
   int lgcap = obs_rows < PMLP_MAXROWS ? obs_rows : PMLP_MAXROWS;              // logits per wave: what the block can hold
   lgcap = (lgcap + 63) / 64 * 64;
-  const size_t ml = ((size_t)hp1 * hpm + (size_t)(hpm ? hpm : hp1) * hp2 + hpm + 2 * hp2) * sizeof(float) + (size_t)waves * lgcap * sizeof(float) +
-                    (size_t)(2 * waves + 2) * sizeof(int) + (size_t)waves * 64 * sizeof(unsigned short);
-  const int max_blocks = (waves == 16 ? 1 : 2) * (cus > 0 ? cus : 256);
+  size_t ml = 0;
+  for (;; waves /= 2) {
+    ml = ((size_t)hp1 * hpm + (size_t)(hpm ? hpm : hp1) * hp2 + hpm + 2 * hp2) * sizeof(float) + (size_t)waves * lgcap * sizeof(float) +
+         (size_t)(2 * waves + 2) * sizeof(int) + (size_t)waves * 64 * sizeof(unsigned short);
+    if (ml <= (size_t)max_lds || hpm != 128 || waves == 4) break;
+  }
+  if (ml > (size_t)max_lds) return (int)hipErrorInvalidValue;
+  const int max_blocks = (hpm == 128 ? 1 : 2) * (cus > 0 ? cus : 256);
   int blocks = (B + waves - 1) / waves;
   blocks = blocks < max_blocks ? blocks : max_blocks;
 #define BBX_P2(N1, NM, N2, K, NW) do { \
@@ -297,7 +303,9 @@ extern "C" int bbx_launch_pmlp2_act(const int32_t* obs, const int32_t* rows, int
       set_ = ml; } \
     hipLaunchKernelGGL((bbx_pmlp2_act_kernel<N1, NM, N2, K, NW>), dim3(blocks), dim3(NW * WAVE), ml, stream, obs, rows, B, obs_rows, cols, wp, u, actions, logprobs, lgcap); } while (0)
 #define BBX_P2_K(N1, NM, N2, NW) do { if (ks == 3) BBX_P2(N1, NM, N2, 3, NW); else if (ks == 8) BBX_P2(N1, NM, N2, 8, NW); else BBX_P2(N1, NM, N2, 16, NW); } while (0)
-  if (hpm == 128) BBX_P2_K(128, 128, 128, 16);
+  if (hpm == 128 && waves == 16) BBX_P2_K(128, 128, 128, 16);
+  else if (hpm == 128 && waves == 8) BBX_P2_K(128, 128, 128, 8);
+  else if (hpm == 128) BBX_P2_K(128, 128, 128, 4);
   else if (hpm == 64) BBX_P2_K(64, 64, 64, 8);
   else if (hp1 == 64 && hp2 == 64) BBX_P2_K(64, 0, 64, 8); else if (hp1 == 64) BBX_P2_K(64, 0, 128, 8);
   else if (hp2 == 64) BBX_P2_K(128, 0, 64, 8); else BBX_P2_K(128, 0, 128, 8);

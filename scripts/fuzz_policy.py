@@ -2,7 +2,8 @@
 observation widths, hidden sizes, batch sizes and kernel capacities, bbx_policy_rollout_device (policy inside the step
 kernels, T steps per launch, split at a random point) must reproduce T calls of bbx_policy_step_device on a copy of the batch
 — actions, log-probabilities, rewards, dones, row counts, observations — and the torch module must agree with the sampled
-log-probabilities.     python scripts/fuzz_policy.py [ROUNDS] [SEED]"""
+log-probabilities; the two- / three-layer policy kernels (random layer sizes) must agree with the torch module on the
+rollout's final block.     python scripts/fuzz_policy.py [ROUNDS] [SEED]"""
 import os, sys, random, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -76,6 +77,31 @@ for it in range(rounds):
             print("MISMATCH %s: step %d (cut %d)" % (tag, t, cut)); sys.exit(1)
     if not np.array_equal(env.stats()[:, :5], twin.stats()[:, :5]):
         print("MISMATCH %s: counters" % tag); sys.exit(1)
+    # the deeper kernels (bbx_pmlp2_act / bbx_pmlp3_act) on the final block of this rollout: random layer sizes against the
+    # torch module — log-probability of the drawn row, and the draw itself up to round-off ties
+    deep = [rng.randint(1, 128) for _ in range(rng.choice([2, 3]))]
+    pol2 = PMLPPolicy(env.cols, deep).cuda()
+    with torch.no_grad():
+        for lin in list(pol2.embedding) + [pol2.deciding]:
+            lin.weight.mul_(0.3)
+    live_rows = torch.clamp(rows, min=1)
+    uu = torch.rand(B, device="cuda")
+    a_k, l_k = pol2.act(obs, live_rows, uu)
+    a_t, _ = pol2.act_torch(obs, live_rows, uu)
+    torch.cuda.synchronize()
+    lp2 = pol2(obs)
+    n_eff = torch.clamp(live_rows, max=R)
+    if pol2.deep_ok(env.cols) and R <= 1024:
+        # (the reference masks by the -1 padding, the kernel by the row count: compare on the rows both see)
+        validm = torch.arange(R, device="cuda")[None, :] < n_eff[:, None]
+        lpm = torch.log_softmax(torch.where(validm, lp2, torch.full_like(lp2, -1e30)), dim=1)
+        if not ((a_k >= 0).all() and (a_k < n_eff).all()):
+            print("MISMATCH %s: deep policy %s drew outside the rows" % (tag, deep)); sys.exit(1)
+        if not torch.allclose(l_k, lpm.gather(1, a_k.long()[:, None]).squeeze(1), atol=5e-4, rtol=1e-4):
+            print("MISMATCH %s: deep policy %s log-probabilities vs the torch module" % (tag, deep)); sys.exit(1)
+        if (a_k == a_t).float().mean() < 0.98:
+            print("MISMATCH %s: deep policy %s draws" % (tag, deep)); sys.exit(1)
+        tag += " deep=%s" % deep
     print("ok " + tag)
     del env, twin, O
 print("fuzz_policy: %d rounds, %.0f s, no mismatch" % (rounds, time.time() - t0))

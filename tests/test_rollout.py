@@ -199,6 +199,45 @@ def test_fused_two_layer_policy_kernel_matches_torch_module(dist, k, hidden):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("R", [448, 512, 1024])
+@pytest.mark.parametrize("hidden", [(128, 128), (128, 128, 128)])
+def test_deep_policy_kernels_on_tall_observation_blocks(hidden, R):
+    """The logits of a wave's environment live in LDS next to the staged weights: with 128 KB of weights (three layers of 128
+    units) a tall block (up to 1024 rows = 4 KB of logits per wave) leaves room for fewer waves per workgroup — the launcher
+    picks 16, 8 or 4 (found by scripts/fuzz_policy.py: the 16-wave launch was refused by the runtime)."""
+    import torch
+    from deepgroebner_amd import VecLeadMonomialsEnv
+    from deepgroebner_amd.rollout import PMLPPolicy
+    torch.manual_seed(6)
+    B = 48
+    env = VecLeadMonomialsEnv("5-10-5-uniform", batch=B, k=1)
+    env.seed(np.arange(B) + 9); env.seed_agent(np.arange(B)); env.reset()
+    env.rollout("random", 300, auto_reset=True)
+    obs = torch.full((B, R, env.cols), -1, dtype=torch.int32, device="cuda")
+    rew = torch.zeros(B, dtype=torch.float64, device="cuda"); done = torch.zeros(B, dtype=torch.uint8, device="cuda")
+    rows = torch.zeros(B, dtype=torch.int32, device="cuda")
+    env.rollout_device("first", 0, False, torch.cuda.current_stream().cuda_stream, rew, done, rows, obs, R, True, False)
+    try:
+        env.sync()
+    except Exception:                                              # (rows beyond the block are an error of the block, not of this test)
+        pass
+    n = torch.clamp(rows, min=1, max=R)
+    assert int(n.max()) > 64                                       # several tiles per environment: the workgroup's shared queue is in use
+    policy = PMLPPolicy(env.cols, list(hidden)).cuda()
+    with torch.no_grad():
+        for lin in list(policy.embedding) + [policy.deciding]:
+            lin.weight.mul_(0.2)
+    u = torch.rand(B, device="cuda")
+    a_k, l_k = policy.act(obs, n, u)
+    torch.cuda.synchronize()
+    assert (a_k >= 0).all() and (a_k < n).all()
+    lp = policy(obs)
+    valid = torch.arange(R, device="cuda")[None, :] < n[:, None]
+    lpm = torch.log_softmax(torch.where(valid, lp, torch.full_like(lp, -1e30)), dim=1)
+    assert torch.allclose(l_k, lpm.gather(1, a_k.long()[:, None]).squeeze(1), atol=5e-4, rtol=1e-4)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("hidden", [(64, 64), (32, 32, 32), (32, 32, 32, 32)])
 def test_rollout_replayed_from_a_hip_graph_equals_the_eager_rollout(hidden):
     """run_rollout(graph=True): the vector step (policy ops + bbx_step_device_autoreset) recorded once and replayed gives the
