@@ -1227,7 +1227,8 @@ static int pmlp_deep_act(const int32_t* d_obs, const int32_t* d_rows, int batch,
   int max_lds = 0;
   HIPCHK(hipDeviceGetAttribute(&max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev));
   int lrc = bbx_launch_pmlp2_act(d_obs, d_rows, batch, obs_rows, cols, d_prepared, h1, three ? hm : 0, h2, d_u, d_actions, d_logprobs, cus,
-                                 max_lds > 0 ? max_lds : 65536, (hipStream_t)stream);
+                                 max_lds > 163840 ? max_lds : 163840,   /* (gfx950: 160 KB per workgroup, whatever the attribute says) */
+                                 (hipStream_t)stream);
   if (lrc) return fail(BBX_E_DEVICE, "policy launch failed: %s", hipGetErrorString((hipError_t)lrc));
   return BBX_OK;
 }
