@@ -14,7 +14,7 @@ Measurement protocol (so that the line means the same at --steps 20 and at --ste
   * pre-roll: every environment runs `preroll_steps` (>= 256) untimed steps first, so that the batch is in its steady
     state (a mix of episode phases) rather than all environments in their first episode;
   * W warm-up steps (one launch), then eight chained calibration launches of K steps (untimed);
-  * timed region: R back-to-back launches of K steps each (`repeats`; R is chosen so that the region lasts >= 60 ms),
+  * timed region: R back-to-back launches of K steps each (`repeats`; R is chosen so that the region lasts >= 0.5 s),
     enqueued asynchronously, bracketed by barrier + synchronize on both sides; `ms_per_step` is the region's wall time /
     (R*K), `value` = batch * R * K / wall time (max over ranks).  The launches go through a persistent session
     (bbx_persistent, include/bbx.h): the first starts the step kernel, the others raise a device-visible step counter
@@ -44,8 +44,9 @@ BATCH = 4096          # environments per GPU
 K_LEADS = 2
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
 PREROLL = 256
-MIN_REGION_MS = 60.0
-PMC_PROFILE = os.path.join("profiles", "r03_pmc_fast_kernel.json")
+MIN_REGION_MS = 500.0  # a sustained figure: long enough to contain the rare environments whose bases grow large
+LONG_REGION_MS = 250.0
+PMC_PROFILES = [os.path.join("profiles", "r04_pmc_fast_kernel.json"), os.path.join("profiles", "r03_pmc_fast_kernel.json")]
 
 
 def parse_args():
@@ -55,13 +56,14 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=64)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--dist", default=DIST)
-    ap.add_argument("--repeats", type=int, default=0, help="launches of K steps in the timed region (0 = enough for >= 60 ms)")
+    ap.add_argument("--repeats", type=int, default=0, help="launches of K steps in the timed region (0 = enough for >= 0.5 s)")
     ap.add_argument("--preroll", type=int, default=PREROLL)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--generic-kernel", action="store_true",
                     help="diagnostic: pad the observation with -1 (obs_fill), which selects bbx_fast_kernel<false,false> "
                          "instead of the compile-time specialised headline variant")
     ap.add_argument("--cpu-sample-envs", type=int, default=0)
+    ap.add_argument("--no-cpu-all-cores", action="store_true", help="skip the one-environment-per-core leg of the CPU baseline")
     ap.add_argument("--no-long-launch", action="store_true",
                     help="skip the context figure after the timed region (the same workload in 8 launches of 1024 steps; skip it under "
                          "rocprofv3: it would mix two launch lengths into the kernel's average)")
@@ -138,7 +140,7 @@ def main():
 
     stream = torch.cuda.current_stream()
     cols = env.cols
-    obs_rows = 256                                    # the fast class holds |P| <= 256: no observation row is ever cut
+    obs_rows = 512                                    # the fast class holds |P| <= 512: no observation row is ever cut
     d_obs = torch.empty((B, obs_rows, cols), dtype=torch.int32, device="cuda")
     d_rew = torch.empty(B, dtype=torch.float64, device="cuda")
     d_done = torch.empty(B, dtype=torch.uint8, device="cuda")
@@ -164,7 +166,7 @@ def main():
         launch(K)
     env.sync(); torch.cuda.synchronize()
     t_launch = (time.perf_counter() - t0) / ncal
-    R = args.repeats if args.repeats > 0 else int(min(4096, max(3, MIN_REGION_MS * 1e-3 / max(t_launch, 1e-6) + 1)))
+    R = args.repeats if args.repeats > 0 else int(min(1 << 16, max(3, MIN_REGION_MS * 1e-3 / max(t_launch, 1e-6) + 1)))
     if world > 1:
         r_all = [None] * world
         dist.all_gather_object(r_all, R)
@@ -198,17 +200,20 @@ def main():
     if not args.no_long_launch and world == 1:
         launch(64)                                  # (the statistics call above closed the session: a new one gets going)
         env.join(stream.cuda_stream)
+        n_long = int(max(8, LONG_REGION_MS / max(1024 * region_ms / (R * K), 1e-6) + 1))
         ev2, ev3 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev2.record(stream)
-        for _ in range(8):
+        for _ in range(n_long):
             launch(1024)
         env.join(stream.cuda_stream)
         ev3.record(stream)
         env.sync(); torch.cuda.synchronize()
-        long_launch = {"steps_per_launch": 1024, "launches": 8, "value": 8 * 1024 * B / (ev2.elapsed_time(ev3) * 1e-3), "unit": "env-steps/s",
-                       "timing": "HIP events on the launch stream around the 8 launches (and the join behind them)",
-                       "note": "context only: 8192 steps of the same trajectories later on; an environment that is on the HBM-resident "
-                               "class in that window (basis beyond 128 elements) is waited for at the join"}
+        long_ms = ev2.elapsed_time(ev3)
+        long_launch = {"steps_per_launch": 1024, "launches": n_long, "value": n_long * 1024 * B / (long_ms * 1e-3), "unit": "env-steps/s",
+                       "region_ms": long_ms,
+                       "timing": "HIP events on the launch stream around the launches (and the join behind them)",
+                       "note": "context only: the same trajectories later on, issued 1024 steps per launch, >= 0.25 s"}
+    sess_end = env.session_stats()
     d = st1 - st0
     steps_done = int(d[:, 0].sum())
     assert steps_done == R * K * B, "every environment must have executed exactly R*K steps (%d != %d)" % (steps_done, R * K * B)
@@ -236,9 +241,11 @@ def main():
         dist.all_reduce(s, op=dist.ReduceOp.SUM)
         steps_done, additions, alg_bytes = int(s[0]), int(s[1]), int(s[2])
 
-    cpu = None
+    cpu = cpu_all = None
     if rank == 0 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args, st1, int(st1[0, 0]), B)
+        if not args.no_cpu_all_cores:
+            cpu_all = cpu_baseline_all_cores(args, st1, int(st1[0, 0]), B, cpu)
 
     if rank == 0:
         value = steps_done / elapsed
@@ -257,19 +264,26 @@ def main():
                 "kernels_in_timed_region": (sess["kernels"] - sess0["kernels"]) if persistent else R,
                 # every batch step this process pushed through that kernel (pre-roll, warm-up, calibration, timed region): a
                 # rocprofv3 --stats run of the same command shows the kernel's total time, total / this = time per batch step
-                "batch_steps_through_kernel": (max(args.preroll, 0) or 1) + Wm + ncal * K + R * K + ((64 + 8 * 1024) if long_launch else 0),
+                "batch_steps_through_kernel": (max(args.preroll, 0) or 1) + Wm + ncal * K + R * K + ((64 + long_launch["launches"] * 1024) if long_launch else 0),
                 "launch_note": ("the R launches of the timed region are served by the kernels of one persistent session (time slices of 10 ms); "
                                 "kernel_ms_per_launch = HIP-event time of the region / R") if persistent else "one kernel per launch"}
-        pf = os.path.join(ROOT, PMC_PROFILE)
-        if os.path.exists(pf) and args.dist == DIST and B == BATCH and not args.generic_kernel:
-            prof = json.load(open(pf))
+        PMC_PROFILE = next((q for q in PMC_PROFILES if os.path.exists(os.path.join(ROOT, q))), None)
+        if PMC_PROFILE and args.dist == DIST and B == BATCH and not args.generic_kernel:
+            prof = json.load(open(os.path.join(ROOT, PMC_PROFILE)))
             tr = prof.get("hbm_traffic")
             if tr:   # PMC passes at two launch lengths: traffic = fixed part (records in/out, observation block) + per-step part
                 roof["traffic"] = tr["fixed_bytes_per_launch"] + tr["bytes_per_batch_step"] * K
                 roof["traffic_source"] = PMC_PROFILE + " (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, separate passes, FETCH doubled)"
+                # counter collection serialises kernels, so the counters are those of the one-kernel-per-launch form of the same
+                # step body (fast_body): say which kernel was profiled when it is not the one that is timed
+                roof["traffic_kernel"] = prof.get("kernel")
+                roof["traffic_kernel_is_timed_kernel"] = prof.get("kernel") == kernel
             ib = prof.get("issue_bound")
-            if ib:   # second bound: scalar-pipe instructions per cycle per CU against the one scalar unit of a CU
-                roof["issue_bound"] = dict(ib, source=PMC_PROFILE)
+            if ib:   # the binding resource: scalar-pipe instructions per cycle per CU against the one scalar unit of a CU
+                roof["issue_bound"] = dict(ib, source=PMC_PROFILE, kernel=prof.get("kernel"))
+                roof["binding"] = "issue"
+                roof["binding_note"] = ("`bound`/`frac` are the HBM figure SURVEY 8d prescribes (algorithmic bytes against 8 TB/s); what limits "
+                                        "this kernel is instruction issue (`issue_bound`): the state never leaves registers / LDS / L2")
         out = {
             "metric": "env steps/sec (polynomial additions) on 3-20-10-weighted, batch=4096, 1/2/4/8 GPU",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": Wm,
@@ -284,8 +298,13 @@ def main():
             "additions": additions,
             "additions_per_s": additions / elapsed,
             "long_launch": long_launch,
+            "session_stats": ({"timed_region": {k_: sess[k_] - sess0[k_] for k_ in sess}, "whole_run": sess_end,
+                               "note": "spills = environments that left the register/LDS class (basis beyond 256 elements or 512 pairs) and "
+                                       "were continued by the HBM-resident pass; later_kernel_steps = env-steps taken by closing kernels"}
+                              if persistent else None),
             "roofline": roof,
             "cpu_baseline": cpu,
+            "cpu_baseline_all_cores": cpu_all,
         }
         sys.stdout.flush()
         os.write(out_fd, (json.dumps(out) + "\n").encode())
@@ -308,6 +327,38 @@ def cpu_baseline(args, st_final, steps_per_env, B):
     return {"value": res["steps"] / res["seconds"], "unit": "env-steps/s", "cores": 1, "kind": kind,
             "sample": "envs 0..%d of the same batch x %d steps each (pre-roll + warm-up + timed), %d steps, %.1f s" % (n - 1, steps_per_env, res["steps"], res["seconds"]),
             "additions_match_device": bool(res["additions"] == dev_adds)}
+
+
+def cpu_baseline_all_cores(args, st_final, steps_per_env, B, single):
+    """SURVEY 8d-ii / BASELINE.md 3.3: the same CPU code with one environment stream per host core — `nproc` threads, each
+    running its own slice of the same batch (thread i: environments i*n .. (i+1)*n - 1, same seeds as the device's) for a
+    bounded number of steps.  The library call releases the GIL; environments share nothing."""
+    import threading
+    from oracle import ffi
+    kind = "reference" if ffi.available("ref") else "port"
+    lib = ffi.load("ref" if kind == "reference" else "bo")
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    per_thread_steps = max(1, int(single["value"] * 8.0))          # ~8 s per thread at the single-thread rate
+    n = max(1, min(B // cores, per_thread_steps // max(1, steps_per_env)))
+    T = steps_per_env if n * steps_per_env <= per_thread_steps * 2 else max(1, per_thread_steps // n)
+    res = [None] * cores
+
+    def work(i):
+        res[i] = lib.bench_random(args.dist, K_LEADS, n, T, 1000 + i * n, i * n)
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
+    t0 = time.perf_counter()
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    wall = time.perf_counter() - t0
+    steps = sum(r["steps"] for r in res)
+    match = None
+    if T == steps_per_env:                                          # whole trajectories: the addition totals must equal the device's
+        match = all(res[i]["additions"] == int(st_final[i * n:(i + 1) * n, 1].sum()) for i in range(cores))
+    return {"value": steps / wall, "unit": "env-steps/s", "cores": cores, "nproc": os.cpu_count(), "kind": kind, "threads": cores,
+            "sample": "%d threads x envs [i*%d, (i+1)*%d) of the same batch x %d steps each, %d steps, %.1f s wall" % (cores, n, n, T, steps, wall),
+            "additions_match_device": match, "speedup_over_one_core": steps / wall / single["value"]}
 
 
 if __name__ == "__main__":

@@ -304,9 +304,9 @@ class VecLeadMonomialsEnv:
         _ffi.check(_ffi.lib().bbx_persistent(self._h, int(enable)))
 
     def session_stats(self):
-        out = np.zeros(4, dtype=np.int64)
+        out = np.zeros(5, dtype=np.int64)
         _ffi.check(_ffi.lib().bbx_session_stats(self._h, _ffi.ptr(out)))
-        return dict(zip(("sessions", "joined", "later_kernel_steps", "kernels"), (int(v) for v in out)))
+        return dict(zip(("sessions", "joined", "later_kernel_steps", "kernels", "spills"), (int(v) for v in out)))
 
     def join(self, stream=0):
         """Device-side end of the persistent session in flight: `stream` waits for it (the host does not)."""

@@ -200,7 +200,7 @@ const char* status_name(int s) {
 
 void fill_params(bbx_batch* b, BbxParams* p) {
   memset(p, 0, sizeof *p);
-  p->recs = b->d_recs; p->L = b->L; p->LL = b->LL; p->B = b->B;
+  p->recs = b->d_recs; p->L = b->L; p->LL = b->LL; p->B = b->B; p->fast_G = b->fast_G; p->fast_P = b->fast_P;
   p->q.words = b->d_q; p->q.env_stride = b->fixed ? 0 : b->nslots * b->slot_words; p->q.slot_words = b->slot_words;
   p->q.nslots = b->nslots; p->q.fixed = b->fixed ? 1 : 0; p->q.no_redraw = b->listed ? 1 : 0; p->q.tail = b->d_tail;
   p->elim = b->elim; p->rewards_mode = b->rewards; p->sort_reducers = b->sort_reducers; p->k = b->k; p->nvars = b->nvars;
@@ -724,8 +724,11 @@ int create_common(std::unique_ptr<bbx::IdealGen> proto, int nvars_obs, int elimi
     b->LL = b->binom ? make_layout_binom(b->W, lg, std::min(2 * lg, c.max_pairs))
                      : make_layout(b->W, lg, std::min(2 * lg, c.max_pairs), std::min(2 * lg + 16, c.arena_terms), c.max_poly_terms);
     b->staged = 1;
-    // the hand-tuned kernel covers exactly the reference C++ class's fixed options
-    b->fast = b->binom && elimination == BBX_GEBAUERMOELLER && sort_reducers && lg <= 128;
+    // the hand-tuned kernel covers exactly the reference C++ class's fixed options; its registers and LDS hold bases of
+    // 256 elements (bbx_fast.h FLay), independently of the staged class's working copy above
+    b->fast = b->binom && elimination == BBX_GEBAUERMOELLER && sort_reducers && lg <= 256;
+    b->fast_G = std::min(c.lds_max_basis ? lg : 256, c.max_basis);
+    b->fast_P = std::min(2 * b->fast_G, c.max_pairs);
   }
   // non-binomial random ideals in <= 7 variables: wave-per-environment kernel, long-polynomial environments continue one
   // workgroup each (bbx_wide.h) behind it
@@ -876,6 +879,7 @@ int bbx_copy(const bbx_batch* s, bbx_batch** out) {
   b->h_q = s->h_q; b->h_tail = s->h_tail; b->h_head = s->h_head; b->q_dirty = true;
   b->no_growth = s->no_growth; b->value_rng = s->value_rng; b->gen_to_wide = s->gen_to_wide;
   b->wide = s->wide; b->wide_terms = s->wide_terms; b->accounting = s->accounting; b->staged = s->staged; b->fast = s->fast; b->envs_per_block = s->envs_per_block;
+  b->fast_G = s->fast_G; b->fast_P = s->fast_P;
   if (s->device_gen) {
     b->gen_owner = s->gen_owner; b->d_gen = s->d_gen;      // (immutable: shared)
     b->device_gen = true; b->gen_words = s->gen_words;
@@ -1369,15 +1373,15 @@ int bbx_persistent(bbx_batch* b, int enable) {
   return BBX_OK;
 }
 
-int bbx_session_stats(bbx_batch* b, int64_t* out3) {   // out: 4 values
-  if (!b || !out3) return fail(BBX_E_ARG, "null argument");
+int bbx_session_stats(bbx_batch* b, int64_t* out5) {   // out: 5 values
+  if (!b || !out5) return fail(BBX_E_ARG, "null argument");
   HIPCHK(hipSetDevice(b->device));
-  out3[0] = b->ps_sessions; out3[1] = b->ps_joined; out3[2] = 0; out3[3] = b->ps_kernels;
+  out5[0] = b->ps_sessions; out5[1] = b->ps_joined; out5[2] = 0; out5[3] = b->ps_kernels; out5[4] = 0;
   if (b->d_ctl) {
     if (b->in_flight) { int rc = finish(b, b->last_stream); if (rc) return rc; }
-    unsigned long long v = 0;
-    HIPCHK(hipMemcpy(&v, b->d_ctl + 8, sizeof v, hipMemcpyDeviceToHost));
-    out3[2] = (int64_t)v;
+    unsigned long long v[2] = {0, 0};
+    HIPCHK(hipMemcpy(v, b->d_ctl + 8, sizeof v, hipMemcpyDeviceToHost));
+    out5[2] = (int64_t)v[0]; out5[4] = (int64_t)v[1];
   }
   return BBX_OK;
 }

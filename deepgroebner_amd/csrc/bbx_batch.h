@@ -94,6 +94,7 @@ struct bbx_batch {
   bool in_flight = false;
   bool policy_rollout = false;           // the launch in flight is a policy rollout (bbx_policy_rollout_device)
   int staged = 0, fast = 0, envs_per_block = 4;
+  int fast_G = 0, fast_P = 0;          // capacities of the register/LDS-resident class (BbxParams::fast_G)
   int wide = 0;                       // > 0: waves per environment of the wide (one workgroup per environment) class
   int wide_terms = 0;                 // forced LDS capacity of the wide class (caps.wide_lds_terms), 0 = automatic
   bool device_async = false;          // the launch in flight came through a *_device entry point (no host poll per step)

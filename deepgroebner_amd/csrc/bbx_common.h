@@ -143,6 +143,7 @@ struct BbxParams {
   char* recs;
   BbxLayout L;              // layout of the records in HBM
   BbxLayout LL;             // layout of the LDS-resident working copy (staged kernel only)
+  int32_t fast_G, fast_P;   // capacities of the register/LDS-resident class (bbx_fast.h; its kernels clamp them to what they hold)
   BbxQueue q;
   int32_t B;
   int32_t nsteps;

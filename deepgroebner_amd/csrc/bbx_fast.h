@@ -26,8 +26,18 @@
 #pragma once
 
 typedef Mono<2> M2;
-constexpr int FG = 128, FP = 256;                      // LDS-class capacities
-constexpr int FOFF_LM = 0, FOFF_TM = 1024, FOFF_GI = 2048, FOFF_PR = 3072, FLDS_BYTES = 4096;
+// LDS-class capacities and the per-wave LDS layout: |G| <= 64 NBK, |P| <= 128 NBK.  The first 128 reducers live in
+// registers (two banks of 64, FastState); with NBK = 4 reducers 128..255 exist as an ORDER only — their basis indices in
+// reducer order, u16 sx[] in LDS — and everything about them is read through the basis-order arrays when it is needed
+// (the overflow paths of the reduction and of the sorted insert: cold code, no register state of its own).  NBK = 2
+// (4 KB per environment) is what the policy kernels run — their registers and LDS also hold the policy —, NBK = 4 (8.25 KB,
+// 16 environments per CU = 132 KB of the CU's 160) everything else: on 3-20-10-weighted a basis passes 128 elements about
+// once per 10^5 episodes, and an environment that leaves the class is waited for by every join.
+template <int NBK> struct FLay {
+  static constexpr int G = 64 * NBK, P = 2 * G, OVF = G > 128 ? G - 128 : 0;
+  static constexpr int OFF_LM = 0, OFF_TM = 8 * G, OFF_GI = 16 * G, OFF_PR = 24 * G, OFF_SX = 24 * G + 4 * P, BYTES = OFF_SX + 2 * OVF;
+};
+constexpr int FNBK_WIDE = 4, FNBK_POL = 2;
 constexpr uint32_t FSENT = 0xFFFFFFFFu;               // sentinel monomial word: divides nothing, greater than everything
 
 struct BbxFastParams {
@@ -78,10 +88,12 @@ __device__ __forceinline__ uint32_t f_insert(uint32_t& arr, uint32_t nv, int p, 
   arr = lane > p ? sh : (lane == p ? nv : arr);
   return out;
 }
-// shift the whole array up by one, `carry` enters lane 0
-__device__ __forceinline__ void f_shift_in(uint32_t& arr, uint32_t carry, int lane) {
+// shift the whole array up by one, `carry` enters lane 0; returns the element shifted out of lane 63
+__device__ __forceinline__ uint32_t f_shift_in(uint32_t& arr, uint32_t carry, int lane) {
+  uint32_t out = f_readlane(arr, 63);
   uint32_t sh = f_wave_shr(arr);
   arr = lane == 0 ? carry : sh;
+  return out;
 }
 
 // Kernel arguments that only cold code needs (reset, the write-back behind the step loop, error paths) are re-read from
@@ -104,9 +116,15 @@ __device__ __forceinline__ FColdPolicy f_cold_policy() {
   return &q->pol;
 }
 
-struct FastState {                 // reducer-order arrays, lane l <-> reducers l (A) and l + 64 (B)
-  M2 slmA, slmB, stmA, stmB;
-  uint2 sinA, sinB;                // .x = tc | (-tc/lc) << 16 ; .y = sugar | basis index << 16
+// compile-time loop over reducer banks: f(std::integral_constant<int, b>) for b = 0 .. N-1 (every index a constant, so the
+// bank arrays below stay registers)
+template <class F, int... I> __device__ __forceinline__ void f_banks_(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F> __device__ __forceinline__ void f_banks(F&& f) { f_banks_(f, std::make_integer_sequence<int, N>{}); }
+
+constexpr int FRB = 2;             // reducer banks held in registers
+struct FastState {                 // reducer-order arrays of the first 128 reducers, lane l <-> reducers l + 64 b of bank b
+  M2 slm[FRB], stm[FRB];
+  uint2 sin[FRB];                  // .x = tc | (-tc/lc) << 16 ; .y = sugar | basis index << 16
 };
 
 // TRACE: per-step parity hashes (tests).  ACCT: count the algorithmic bytes of every step (roofline numerator;
@@ -134,8 +152,13 @@ struct FastState {                 // reducer-order arrays, lane l <-> reducers 
 // counts at 100 MHz whatever the shader clock does).  What is owed when it leaves is taken by the session's next kernel.
 // VAL: value() rollouts (buchberger.cpp:248-252, 332-351): the discounted return of the steps taken is accumulated in
 // double, without fusing multiply and add, and written to values[] when the wave leaves.
-template <bool TRACE, bool ACCT, bool PROF = false, bool HL = false, int POL = 0, bool PERSIST = false, bool VAL = false>
+// NBK: capacity in units of 64 basis elements (FLay): 2 = registers only, 4 = with the overflow order in LDS.
+template <bool TRACE, bool ACCT, bool PROF = false, bool HL = false, int POL = 0, bool PERSIST = false, bool VAL = false, int NBK = (POL > 0 ? FNBK_POL : FNBK_WIDE)>
 __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem, int ext_action = -1) {
+  typedef FLay<NBK> LY;
+  constexpr int FG = LY::G, FP = LY::P, FLDS_BYTES = LY::BYTES;
+  constexpr int FOFF_LM = LY::OFF_LM, FOFF_TM = LY::OFF_TM, FOFF_GI = LY::OFF_GI, FOFF_PR = LY::OFF_PR;
+  constexpr bool OVF = LY::OVF > 0;                        // reducers beyond the register banks (their order in LDS)
   unsigned long long prof_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long prof_last = PROF ? __builtin_amdgcn_s_memtime() : 0;
   const int lane = lane_id();
@@ -188,17 +211,25 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem, in
   uint2* gi = (uint2*)(lbase + FOFF_GI); uint32_t* pairs = (uint32_t*)(lbase + FOFF_PR);
   const int limG = p.lim_G < FG ? p.lim_G : FG, limP = p.lim_P < FP ? p.lim_P : FP;
 
+  uint16_t* sx = (uint16_t*)(lbase + LY::OFF_SX);         // OVF: basis indices of reducers 128.. in reducer order
   FastState S;
-  S.slmA.w[0] = S.slmA.w[1] = S.slmB.w[0] = S.slmB.w[1] = FSENT;
-  S.stmA = S.stmB = m_zero<2>(); S.sinA = S.sinB = make_uint2(0, 0);
+  auto clear_reducers = [&]() { f_banks<FRB>([&](auto b_) { constexpr int b = decltype(b_)::value; S.slm[b].w[0] = S.slm[b].w[1] = FSENT; }); };
+  clear_reducers();
+  f_banks<FRB>([&](auto b_) { constexpr int b = decltype(b_)::value; S.stm[b] = m_zero<2>(); S.sin[b] = make_uint2(0, 0); });
   bool staged_in = false;
   if (status == BBX_ST_OK) {
     if (nG > limG || nP > limP) status = BBX_ST_SPILL;
     else {
       F_HBM_PTRS(&p)
-      if (lane < nG) { S.slmA = g_slm[lane]; S.stmA = g_stm[lane]; S.sinA = g_si[lane]; lm[lane] = g_lm[lane]; tm[lane] = g_tm[lane]; gi[lane] = g_gi[lane]; }
-      if (lane + 64 < nG) { S.slmB = g_slm[lane + 64]; S.stmB = g_stm[lane + 64]; S.sinB = g_si[lane + 64];
-                            lm[lane + 64] = g_lm[lane + 64]; tm[lane + 64] = g_tm[lane + 64]; gi[lane + 64] = g_gi[lane + 64]; }
+      f_banks<NBK>([&](auto b_) {
+        constexpr int b = decltype(b_)::value;
+        const int i = lane + 64 * b;
+        if (i < nG) {
+          if constexpr (b < FRB) { S.slm[b] = g_slm[i]; S.stm[b] = g_stm[i]; S.sin[b] = g_si[i]; }
+          else sx[i - 64 * FRB] = (uint16_t)(g_si[i].y >> 16);
+          lm[i] = g_lm[i]; tm[i] = g_tm[i]; gi[i] = g_gi[i];
+        }
+      });
       for (int i = lane; i < nP; i += WAVE) pairs[i] = g_pr[i];
       staged_in = true;
       wave_sync();
@@ -250,13 +281,13 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem, in
     // The rows go out through a buffer descriptor whose size is exactly the live part of the block: the hardware drops the
     // stores of lanes beyond it, so no lane is ever masked — the exec-mask bookkeeping of predicated gathers and stores
     // was ~16 scalar instructions per 32 rows, on the unit that binds this kernel.  The gathers run for all lanes: a pair
-    // index beyond |P| stays inside the pair array (|P| <= 256 = its capacity, and a trip covers rows r0 .. r0 + 31 with
-    // r0 <= 224), what it reads is a stale pair, and the basis index taken from it is clamped to the arrays' 128 entries.
+    // index beyond |P| stays inside the pair array (|P| <= FP = its capacity, and a trip covers rows r0 .. r0 + 31 with
+    // r0 <= FP - 32), what it reads is a stale pair, and the basis index taken from it is clamped to the arrays' FG entries.
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(o3_base + o3_toff), 0, rows * 48, 0x00020000);
     for (int r0 = 0; r0 < rows; r0 += 32) {
       const int ra = r0 + o3_row, rb = ra + 16;
       const uint32_t pa = pairs[ra], pb = pairs[rb];
-      const uint32_t ga = (o3_hi ? pa >> 16 : pa) & 127u, gb = (o3_hi ? pb >> 16 : pb) & 127u;
+      const uint32_t ga = (o3_hi ? pa >> 16 : pa) & (uint32_t)(FG - 1), gb = (o3_hi ? pb >> 16 : pb) & (uint32_t)(FG - 1);
       const M2 ma = *(const M2*)(o3_mono + ga * 8), mb = *(const M2*)(o3_mono + gb * 8);
       const ObsV3 va = {(int32_t)(ma.w[0] & 0xffffu), (int32_t)(ma.w[0] >> 16), (int32_t)(ma.w[1] & 0xffffu)};
       const ObsV3 vb = {(int32_t)(mb.w[0] & 0xffffu), (int32_t)(mb.w[0] >> 16), (int32_t)(mb.w[1] & 0xffffu)};
@@ -329,10 +360,12 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem, in
   // (buchberger.cpp:52-99 + 321-326).  The caller has checked the capacities.
   // `skip` >= 0: the pair at that index has just been selected and is removed by the same compaction pass
   // (P.erase(remove(action)), buchberger.cpp:319) instead of a separate shift of the list
-  // `small` (a std::integral_constant): the caller guarantees |G| < 64 (resets of ideals with at most 64 generators), so
-  // everything about the second half of the reducer / basis registers compiles away
-  auto add_poly = [&](const BTerm<2>& t0, const BTerm<2>& t1, int sugar, int skip, auto small) {
-    constexpr bool SMALL = decltype(small)::value;
+  // `banks` (a std::integral_constant<int, BK>): the caller guarantees |G| < 64 BK.  BK = 1 (the common case: resets of
+  // ideals with at most 64 generators, bases below 64 elements): everything about the other banks of the reducer / basis
+  // registers compiles away; BK = 2, 4: banks beyond the first are guarded by wave-uniform tests on |G|; BK = 4 (|G| >= 128:
+  // cold) additionally maintains the overflow order sx[].
+  auto add_poly = [&](const BTerm<2>& t0, const BTerm<2>& t1, int sugar, int skip, auto banks) {
+    constexpr int BK = decltype(banks)::value;
     const int g = nG;                                     // == m of update()
     // 1/LC comes from a table in HBM/L2: issue the load now, consume it at the very end (the pair update below
     // does not need it), so its latency overlaps the Gebauer-Moeller work
@@ -348,31 +381,52 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem, in
     const uint32_t pr_first = lane < nP_old ? PA : 0u;
     const M2 li_first = lm[pr_first & 0xffffu], lj_first = lm[pr_first >> 16];
     // (78-91) new pairs (i, g): minimal lcms by degree peeling
-    uint64_t emitA = 0, emitB = 0;
+    uint64_t emit[BK];
     {
-      const M2 lA = lm[lane], lB = lm[lane + 64];          // basis order; lanes >= g hold garbage (masked by valid)
-      const uint64_t validA = f_lowmask((SMALL || g < 64) ? g : 64), validB = (!SMALL && g > 64) ? f_lowmask(g - 64) : 0ull;
-      const M2 LA = m_lcm(lA, f), LB = m_lcm(lB, f);
-      const uint64_t cpA = ballot64(m_coprime(lA, f)) & validA, cpB = validB ? (ballot64(m_coprime(lB, f)) & validB) : 0ull;
-      const uint32_t dA = LA.w[1] >> 16, dB = LB.w[1] >> 16;
-      uint64_t candA = validA, candB = validB;
-      while (candA | candB) {
-        const bool inA = f_lane_in(candA), inB = f_lane_in(candB);
-        uint32_t dm = inA ? dA : 0xFFFFFFFFu;
-        if (candB) { const uint32_t t = inB ? dB : 0xFFFFFFFFu; dm = t < dm ? t : dm; }
+      M2 L[BK]; uint64_t valid[BK], cp[BK], cand[BK]; uint32_t d[BK];
+      f_banks<BK>([&](auto b_) {
+        constexpr int b = decltype(b_)::value;
+        const M2 l = lm[lane + 64 * b];                    // basis order; lanes >= g hold garbage (masked by valid)
+        if constexpr (b == 0) valid[0] = f_lowmask((BK == 1 || g < 64) ? g : 64);
+        else valid[b] = g > 64 * b ? f_lowmask(g - 64 * b) : 0ull;
+        L[b] = m_lcm(l, f);
+        if constexpr (b == 0) cp[0] = ballot64(m_coprime(l, f)) & valid[0];
+        else cp[b] = valid[b] ? (ballot64(m_coprime(l, f)) & valid[b]) : 0ull;
+        d[b] = L[b].w[1] >> 16; cand[b] = valid[b]; emit[b] = 0;
+      });
+      auto any = [&](const uint64_t (&m)[BK]) { uint64_t o = 0; f_banks<BK>([&](auto b_) { o |= m[decltype(b_)::value]; }); return o; };
+      while (any(cand)) {
+        uint32_t dm = f_lane_in(cand[0]) ? d[0] : 0xFFFFFFFFu;
+        f_banks<BK>([&](auto b_) {
+          constexpr int b = decltype(b_)::value;
+          if constexpr (b > 0) if (cand[b]) { const uint32_t t = f_lane_in(cand[b]) ? d[b] : 0xFFFFFFFFu; dm = t < dm ? t : dm; }
+        });
         const uint32_t dmin = f_wave_min(dm);
-        uint64_t survA = ballot64(inA && dA == dmin), survB = candB ? ballot64(inB && dB == dmin) : 0ull;
-        while (survA | survB) {
-          M2 Ls; int s;
-          if (survA) { s = __builtin_ctzll(survA); Ls = f_readlane(LA, s); }
-          else { s = __builtin_ctzll(survB); Ls = f_readlane(LB, s); s += 64; }
+        uint64_t surv[BK];
+        f_banks<BK>([&](auto b_) {
+          constexpr int b = decltype(b_)::value;
+          if constexpr (b == 0) surv[0] = ballot64(f_lane_in(cand[0]) && d[0] == dmin);
+          else surv[b] = cand[b] ? ballot64(f_lane_in(cand[b]) && d[b] == dmin) : 0ull;
+        });
+        while (any(surv)) {
+          M2 Ls; int s = 0, sb = 0; bool got = false;      // the first survivor: lane s of bank sb
+          f_banks<BK>([&](auto b_) {
+            constexpr int b = decltype(b_)::value;
+            if (!got && (b == BK - 1 || surv[b])) { s = __builtin_ctzll(surv[b]); Ls = f_readlane(L[b], s); sb = b; got = true; }
+          });
           const uint64_t ls = f_u64(Ls);
-          const uint64_t eqA = ballot64(f_u64(LA) == ls), divA = ballot64(m_divides(Ls, LA));
-          uint64_t eqB = 0, divB = 0;
-          if (validB) { eqB = ballot64(f_u64(LB) == ls) & validB; divB = ballot64(m_divides(Ls, LB)); }
-          if (((eqA & validA & cpA) | (eqB & cpB)) == 0) { if (s < 64) emitA |= 1ull << s; else emitB |= 1ull << (s - 64); }
-          survA &= ~eqA; survB &= ~eqB;
-          candA &= ~divA; candB &= ~divB;
+          uint64_t eq[BK], dv[BK], bad = 0;
+          f_banks<BK>([&](auto b_) {
+            constexpr int b = decltype(b_)::value;
+            if constexpr (b == 0) { eq[0] = ballot64(f_u64(L[0]) == ls); dv[0] = ballot64(m_divides(Ls, L[0])); bad |= eq[0] & valid[0] & cp[0]; }
+            else {
+              eq[b] = 0; dv[b] = 0;
+              if (valid[b]) { eq[b] = ballot64(f_u64(L[b]) == ls) & valid[b]; dv[b] = ballot64(m_divides(Ls, L[b])); }
+              bad |= eq[b] & cp[b];
+            }
+          });
+          if (bad == 0) f_banks<BK>([&](auto b_) { constexpr int b = decltype(b_)::value; if (BK == 1 || sb == b) emit[b] |= 1ull << s; });
+          f_banks<BK>([&](auto b_) { constexpr int b = decltype(b_)::value; surv[b] &= ~eq[b]; cand[b] &= ~dv[b]; });
         }
       }
     }
@@ -395,36 +449,64 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem, in
       w += __popcll(mask);
     }
     nP = w;
-    {
-      // (92) ascending i, appended behind the surviving old pairs (98)
-      if (f_lane_in(emitA)) pairs[nP + f_prefix(emitA)] = (uint32_t)lane | ((uint32_t)g << 16);
-      nP += __popcll(emitA);
-      if (emitB) {
-        if (f_lane_in(emitB)) pairs[nP + f_prefix(emitB)] = (uint32_t)(lane + 64) | ((uint32_t)g << 16);
-        nP += __popcll(emitB);
+    // (92) ascending i, appended behind the surviving old pairs (98)
+    f_banks<BK>([&](auto b_) {
+      constexpr int b = decltype(b_)::value;
+      if (b == 0 || emit[b]) {
+        if (f_lane_in(emit[b])) pairs[nP + f_prefix(emit[b])] = (uint32_t)(lane + 64 * b) | ((uint32_t)g << 16);
+        nP += __popcll(emit[b]);
       }
-    }
+    });
     // sorted reducer insert: std::upper_bound by lead monomial (buchberger.cpp:323-324); sentinels compare greater
     {
-      int pos = __popcll(ballot64(!m_gt(S.slmA, f)));
-      if (!SMALL && g >= 64) pos += __popcll(ballot64(!m_gt(S.slmB, f)));
+      constexpr int RB = BK < FRB ? BK : FRB;              // register banks this call can reach
+      int pos = __popcll(ballot64(!m_gt(S.slm[0], f)));
+      f_banks<RB>([&](auto b_) {
+        constexpr int b = decltype(b_)::value;
+        if constexpr (b > 0) if (g >= 64 * b) pos += __popcll(ballot64(!m_gt(S.slm[b], f)));
+      });
+      const int novf = (OVF && BK > FRB && g > 64 * FRB) ? g - 64 * FRB : 0;   // reducers beyond the registers (cold)
+      if (OVF && BK > FRB) for (int k0 = 0; k0 < novf; k0 += WAVE) {
+        const int k = k0 + lane;
+        const bool le = k < novf && !m_gt(lm[sx[k < novf ? k : 0]], f);
+        pos += __popcll(ballot64(le));
+      }
       const uint32_t inv = inv_raw;
       if (lane == 0) gi[g] = make_uint2(t0.c | (t1.c << 16), inv | ((uint32_t)sugar << 16));
       const uint2 ns = make_uint2(t1.c | (negmod(mulmod(t1.c, inv)) << 16), (uint32_t)sugar | ((uint32_t)g << 16));   // .x = tc | (-tc / lc) << 16
-      if (SMALL || pos < 64) {
-        const uint32_t c0 = f_insert(S.slmA.w[0], f.w[0], pos, lane), c1 = f_insert(S.slmA.w[1], f.w[1], pos, lane);
-        const uint32_t c2 = f_insert(S.stmA.w[0], tail.w[0], pos, lane), c3 = f_insert(S.stmA.w[1], tail.w[1], pos, lane);
-        const uint32_t c4 = f_insert(S.sinA.x, ns.x, pos, lane), c5 = f_insert(S.sinA.y, ns.y, pos, lane);
-        if (!SMALL && g >= 64) {
-          f_shift_in(S.slmB.w[0], c0, lane); f_shift_in(S.slmB.w[1], c1, lane);
-          f_shift_in(S.stmB.w[0], c2, lane); f_shift_in(S.stmB.w[1], c3, lane);
-          f_shift_in(S.sinB.x, c4, lane); f_shift_in(S.sinB.y, c5, lane);
+      // the overflow order takes the new element (pos beyond the registers) or the reducer that falls out of the last bank
+      int ovq = -1; uint32_t ovg = 0;
+      if (OVF && BK > FRB && g >= 64 * FRB) {
+        if (pos >= 64 * FRB) { ovq = pos - 64 * FRB; ovg = (uint32_t)g; }
+        else { ovq = 0; ovg = f_readlane(S.sin[FRB - 1].y, 63) >> 16; }
+      }
+      // bank pos / 64 takes the new element at lane pos % 64; what falls out of a bank's lane 63 enters the next one's lane 0
+      if (!(OVF && BK > FRB) || pos < 64 * FRB) {
+        const int pb = RB == 1 ? 0 : pos >> 6, q = RB == 1 ? pos : pos & 63;
+        uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0;
+        f_banks<RB>([&](auto b_) {
+          constexpr int b = decltype(b_)::value;
+          if (RB == 1 || pb == b) {
+            c0 = f_insert(S.slm[b].w[0], f.w[0], q, lane); c1 = f_insert(S.slm[b].w[1], f.w[1], q, lane);
+            c2 = f_insert(S.stm[b].w[0], tail.w[0], q, lane); c3 = f_insert(S.stm[b].w[1], tail.w[1], q, lane);
+            c4 = f_insert(S.sin[b].x, ns.x, q, lane); c5 = f_insert(S.sin[b].y, ns.y, q, lane);
+          } else if (b > 0 && pb < b && g >= 64 * b) {
+            c0 = f_shift_in(S.slm[b].w[0], c0, lane); c1 = f_shift_in(S.slm[b].w[1], c1, lane);
+            c2 = f_shift_in(S.stm[b].w[0], c2, lane); c3 = f_shift_in(S.stm[b].w[1], c3, lane);
+            c4 = f_shift_in(S.sin[b].x, c4, lane); c5 = f_shift_in(S.sin[b].y, c5, lane);
+          }
+        });
+      }
+      if (OVF && BK > FRB && ovq >= 0) {                   // sx[ovq ..] moves up by one, ovg enters at ovq
+        for (int k0 = ((novf - 1 - ovq) / WAVE) * WAVE; k0 >= 0; k0 -= WAVE) {   // highest chunk first: no element is overwritten before it moved
+          const int k = ovq + k0 + lane;
+          uint16_t v = 0;
+          if (k < novf) v = sx[k];
+          wave_sync();
+          if (k < novf) sx[k + 1] = v;
+          wave_sync();
         }
-      } else {
-        const int q = pos - 64;
-        f_insert(S.slmB.w[0], f.w[0], q, lane); f_insert(S.slmB.w[1], f.w[1], q, lane);
-        f_insert(S.stmB.w[0], tail.w[0], q, lane); f_insert(S.stmB.w[1], tail.w[1], q, lane);
-        f_insert(S.sinB.x, ns.x, q, lane); f_insert(S.sinB.y, ns.y, q, lane);
+        if (lane == 0) sx[ovq] = (uint16_t)ovg;
       }
     }
     nG = g + 1;
@@ -450,7 +532,7 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem, in
         for (;;) {
           const uint32_t x_start = x;
           nG = 0; nP = 0;
-          S.slmA.w[0] = S.slmA.w[1] = S.slmB.w[0] = S.slmB.w[1] = FSENT;
+          clear_reducers();
           // sort_input: all generators are drawn first (lane f keeps generator f), then enter in sorted order
           const bool sorted = cq->sort_input != 0;
           M2 tabL = m_zero<2>(), tabT = m_zero<2>(); uint32_t tabC = 0; int rank = 0;
@@ -470,8 +552,8 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem, in
               const int src = __builtin_ctzll(ballot64(lane < npoly && rank == fidx));
               t0.m = f_readlane(tabL, src); t1.m = f_readlane(tabT, src); t1.c = f_readlane(tabC, src);
             } else if (!gen_binomial<2>(x, gtab, GL, gflags, ncp, t0.m, t1.m, t1.c)) { status = BBX_ST_GEN_FAIL; ok = false; break; }
-            if (npoly <= 64) add_poly(t0, t1, (int)m_deg(t0.m), -1, std::true_type{});
-            else add_poly(t0, t1, (int)m_deg(t0.m), -1, std::false_type{});
+            if (__builtin_expect(npoly <= 64, 1)) add_poly(t0, t1, (int)m_deg(t0.m), -1, std::integral_constant<int, 1>{});
+            else add_poly(t0, t1, (int)m_deg(t0.m), -1, std::integral_constant<int, NBK>{});
           }
           if (!ok || nP != 0) break;                       // buchberger.cpp:313-314: redraw while the pair set is empty
         }
@@ -487,7 +569,7 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem, in
           slot = cq->qwords + (size_t)env * cq->q_env_stride + (size_t)(q_head % (int)cq->q_nslots) * q_slot_words;
         }
         nG = 0; nP = 0;
-        S.slmA.w[0] = S.slmA.w[1] = S.slmB.w[0] = S.slmB.w[1] = FSENT;
+        clear_reducers();
         // the whole ideal (<= 128 words for up to 15 binomials) comes in with two coalesced loads, one word per
         // lane; fields are then picked with v_readlane instead of a chain of dependent scalar-address loads
         const bool small_slot = q_slot_words <= 128;
@@ -509,7 +591,7 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem, in
           t0.c = qword(at + 2); t0.m.w[0] = qword(at + 3); t0.m.w[1] = qword(at + 4);
           t1.c = 0; t1.m = m_zero<2>();
           if (nt == 2) { t1.c = qword(at + 5); t1.m.w[0] = qword(at + 6); t1.m.w[1] = qword(at + 7); }
-          add_poly(t0, t1, sugar, -1, std::false_type{});
+          add_poly(t0, t1, sugar, -1, std::integral_constant<int, NBK>{});
           at += 2 + nt * 3;
         }
         if (!ok) break;
@@ -639,159 +721,57 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem, in
     uint32_t h1c = (uint32_t)uni((int)h1.c), h1a = (uint32_t)uni((int)h1.m.w[0]), h1b = (uint32_t)uni((int)h1.m.w[1]);
     uint32_t r0c = 0, r0a = 0, r0b = 0, r1c = 0, r1a = 0, r1b = 0;
     int nred = 0, rsug = 0;
-    if constexpr (!ACCT) {
-      // The lean variants run this loop as hand-scheduled assembly.  Written in C++ (the loop below, which the accounting
-      // variants keep: it is the specification) the compiler carries the joins of its paths as 64-bit flag words and
-      // scalar moves — about 58 scalar-pipe instructions per reduction round, on the unit that binds this kernel
-      // (DESIGN.md section 4.1); here a round in which the first 64 reducers hold the divisor takes 22.
-      // Register roles: h0 = (h0c; h0a, h0b) lead term of h, h1 its tail term (coefficient 0: none), r0 / r1 the remainder,
-      // (its monomials are outputs only: whoever reads them looks at the coefficient first), nred / rsug / hsug as in the C++ loop.  Lane l holds reducers l (A) and l + 64 (B): lead monomial (lm0, lm1), tail
-      // monomial (tm0, tm1), inx = tail coefficient | (-tc / lc) << 16, sug = sugar.  gfx950 wait states observed: a packed
-      // (VOP3P) result needs one state before a VALU reads it (s_nop 0); everything else here is interlocked.
-      const uint32_t sugA = S.sinA.y & 0xffffu, sugB = S.sinB.y & 0xffffu;
-      const int ng_s = uni(nG);
-      uint32_t nred_u = 0, rsug_u = 0, hsug_u = (uint32_t)hsug;
-      uint32_t sl, sf, sx_, sxx, sq;
-      uint32_t t0, t1, t2;
-      asm volatile(
-        "L_top_%=:\n\t"
-        "s_cmp_eq_u32 %[h0c], 0\n\t"
-        "s_cbranch_scc1 L_done_%=\n\t"
-        "v_pk_sub_u16 %[t0], %[alm0], %[h0a] clamp\n\t"
-        "v_pk_sub_u16 %[t1], %[alm1], %[h0b] clamp\n\t"
-        "s_nop 0\n\t"
-        "v_or_b32 %[t0], %[t0], %[t1]\n\t"
-        "v_cmp_eq_u32 vcc, 0, %[t0]\n\t"
-        "v_sub_u32 %[t1], %[h0b], %[alm1]\n\t"
-        "v_sub_u32 %[t0], %[h0a], %[alm0]\n\t"
-        "v_add_u32 %[t2], %[t1], %[atm1]\n\t"
-        "v_add_u32 %[t0], %[t0], %[atm0]\n\t"
-        "v_lshrrev_b32 %[t1], 16, %[t1]\n\t"
-        "v_add_u32 %[t1], %[t1], %[asug]\n\t"
-        "s_cbranch_vccz L_tryB_%=\n\t"
-        "s_ff1_i32_b64 %[sl], vcc\n\t"
-        "v_readlane_b32 %[sf], %[t1], %[sl]\n\t"
-        "v_readlane_b32 %[sx], %[ainx], %[sl]\n\t"
-        "s_max_i32 %[hsug], %[hsug], %[sf]\n\t"
-        "s_cmp_gt_i32 %[hsug], 0xffff\n\t"
-        "s_cbranch_scc1 L_done_%=\n\t"
-        "v_readlane_b32 %[h0a], %[t0], %[sl]\n\t"
-        "v_readlane_b32 %[h0b], %[t2], %[sl]\n\t"
-        "L_red_%=:\n\t"                                   // h <- h - (LT h / LT f) f: the new term takes the lead term's place
-        "s_lshr_b32 %[sq], %[sx], 16\n\t"
-        "s_mul_i32 %[sxx], %[h0c], %[sq]\n\t"
-        "s_mul_hi_u32 %[sq], %[sxx], 0x4187a4af\n\t"
-        "s_lshr_b32 %[sq], %[sq], 13\n\t"
-        "s_mul_i32 %[sq], %[sq], 0x7d03\n\t"
-        "s_sub_u32 %[h0c], %[sxx], %[sq]\n\t"
-        "s_add_u32 %[nred], %[nred], 1\n\t"
-        "s_cmp_eq_u32 %[h0c], 0\n\t"
-        "s_cbranch_scc1 L_shift_%=\n\t"
-        "s_cmp_eq_u32 %[h1c], 0\n\t"
-        "s_cbranch_scc1 L_top_%=\n\t"
-        "s_xor_b32 %[sxx], %[h1b], 0xffff\n\t"           // grevlex keys: high word ^ 0xffff, low word complemented
-        "s_xor_b32 %[sq], %[h0b], 0xffff\n\t"
-        "s_cmp_lt_u32 %[sxx], %[sq]\n\t"
-        "s_cbranch_scc1 L_top_%=\n\t"                     // the new term leads: nothing moves
-        "s_cmp_eq_u32 %[sxx], %[sq]\n\t"
-        "s_cbranch_scc0 L_swap_%=\n\t"
-        "s_cmp_lt_u32 %[h1a], %[h0a]\n\t"
-        "s_cbranch_scc1 L_swap_%=\n\t"
-        "s_cmp_eq_u32 %[h1a], %[h0a]\n\t"
-        "s_cbranch_scc0 L_top_%=\n\t"
-        "s_add_u32 %[sxx], %[h0c], %[h1c]\n\t"            // equal monomials: one term, coefficients added mod p
-        "s_add_u32 %[sq], %[sxx], 0xffff82fd\n\t"
-        "s_min_u32 %[h0c], %[sxx], %[sq]\n\t"
-        "s_mov_b32 %[h1c], 0\n\t"
-        "s_branch L_top_%=\n\t"
-        "L_swap_%=:\n\t"                                  // the old tail leads
-        "s_mov_b32 %[sxx], %[h0c]\n\t" "s_mov_b32 %[h0c], %[h1c]\n\t" "s_mov_b32 %[h1c], %[sxx]\n\t"
-        "s_mov_b32 %[sxx], %[h0a]\n\t" "s_mov_b32 %[h0a], %[h1a]\n\t" "s_mov_b32 %[h1a], %[sxx]\n\t"
-        "s_mov_b32 %[sxx], %[h0b]\n\t" "s_mov_b32 %[h0b], %[h1b]\n\t" "s_mov_b32 %[h1b], %[sxx]\n\t"
-        "s_branch L_top_%=\n\t"
-        "L_shift_%=:\n\t"                                 // the new term vanished (a reducer without tail): h <- its tail term
-        "s_mov_b32 %[h0c], %[h1c]\n\t" "s_mov_b32 %[h0a], %[h1a]\n\t" "s_mov_b32 %[h0b], %[h1b]\n\t" "s_mov_b32 %[h1c], 0\n\t"
-        "s_branch L_top_%=\n\t"
-        "L_tryB_%=:\n\t"                                  // no divisor among reducers 0..63
-        "s_cmp_lt_i32 %[ng], 65\n\t"
-        "s_cbranch_scc1 L_tm_%=\n\t"
-        "v_pk_sub_u16 %[t0], %[blm0], %[h0a] clamp\n\t"
-        "v_pk_sub_u16 %[t1], %[blm1], %[h0b] clamp\n\t"
-        "s_nop 0\n\t"
-        "v_or_b32 %[t0], %[t0], %[t1]\n\t"
-        "v_cmp_eq_u32 vcc, 0, %[t0]\n\t"
-        "v_sub_u32 %[t1], %[h0b], %[blm1]\n\t"
-        "v_sub_u32 %[t0], %[h0a], %[blm0]\n\t"
-        "v_add_u32 %[t2], %[t1], %[btm1]\n\t"
-        "v_add_u32 %[t0], %[t0], %[btm0]\n\t"
-        "v_lshrrev_b32 %[t1], 16, %[t1]\n\t"
-        "v_add_u32 %[t1], %[t1], %[bsug]\n\t"
-        "s_cbranch_vccz L_tm_%=\n\t"
-        "s_ff1_i32_b64 %[sl], vcc\n\t"
-        "v_readlane_b32 %[sf], %[t1], %[sl]\n\t"
-        "v_readlane_b32 %[sx], %[binx], %[sl]\n\t"
-        "s_max_i32 %[hsug], %[hsug], %[sf]\n\t"
-        "s_cmp_gt_i32 %[hsug], 0xffff\n\t"
-        "s_cbranch_scc1 L_done_%=\n\t"
-        "v_readlane_b32 %[h0a], %[t0], %[sl]\n\t"
-        "v_readlane_b32 %[h0b], %[t2], %[sl]\n\t"
-        "s_branch L_red_%=\n\t"
-        "L_tm_%=:\n\t"                                    // r <- r + LT h ; h <- h - LT h
-        "s_cmp_eq_u32 %[r0c], 0\n\t"
-        "s_cbranch_scc0 L_tm1_%=\n\t"
-        "s_mov_b32 %[r0c], %[h0c]\n\t" "s_mov_b32 %[r0a], %[h0a]\n\t" "s_mov_b32 %[r0b], %[h0b]\n\t"
-        "s_branch L_tm2_%=\n\t"
-        "L_tm1_%=:\n\t"
-        "s_mov_b32 %[r1c], %[h0c]\n\t" "s_mov_b32 %[r1a], %[h0a]\n\t" "s_mov_b32 %[r1b], %[h0b]\n\t"
-        "L_tm2_%=:\n\t"
-        "s_lshr_b32 %[sxx], %[h0b], 16\n\t"
-        "s_max_i32 %[rsug], %[rsug], %[sxx]\n\t"
-        "s_mov_b32 %[h0c], %[h1c]\n\t" "s_mov_b32 %[h0a], %[h1a]\n\t" "s_mov_b32 %[h0b], %[h1b]\n\t" "s_mov_b32 %[h1c], 0\n\t"
-        "s_branch L_top_%=\n\t"
-        "L_done_%=:"
-        : [h0c] "+s"(h0c), [h0a] "+s"(h0a), [h0b] "+s"(h0b), [h1c] "+s"(h1c), [h1a] "+s"(h1a), [h1b] "+s"(h1b),
-          [r0c] "+s"(r0c), [r0a] "=&s"(r0a), [r0b] "=&s"(r0b), [r1c] "+s"(r1c), [r1a] "=&s"(r1a), [r1b] "=&s"(r1b),
-          [nred] "+s"(nred_u), [rsug] "+s"(rsug_u), [hsug] "+s"(hsug_u),
-          [sl] "=&s"(sl), [sf] "=&s"(sf), [sx] "=&s"(sx_), [sxx] "=&s"(sxx), [sq] "=&s"(sq),
-          [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2)
-        : [alm0] "v"(S.slmA.w[0]), [alm1] "v"(S.slmA.w[1]), [atm0] "v"(S.stmA.w[0]), [atm1] "v"(S.stmA.w[1]), [ainx] "v"(S.sinA.x), [asug] "v"(sugA),
-          [blm0] "v"(S.slmB.w[0]), [blm1] "v"(S.slmB.w[1]), [btm0] "v"(S.stmB.w[0]), [btm1] "v"(S.stmB.w[1]), [binx] "v"(S.sinB.x), [bsug] "v"(sugB),
-          [ng] "s"(ng_s)
-        : "vcc", "scc");
-      nred = (int)nred_u; rsug = (int)rsug_u; hsug = (int)hsug_u;
-    } else
-    while (h0c != 0) {
+    // One round of the reduction loop in C++ — the specification of the assembly below, the accounting variants' loop, and
+    // what serves the rounds whose divisor may lie beyond the reducer registers.  `regs`: scan the register banks (the
+    // assembly has done that already when it hands a round over).
+    const int ngu = uni(nG);                               // (|G| is wave-uniform; pinned, so that what depends on it stays scalar)
+    auto round_cpp = [&](auto regs) {
       const int hn = h1c ? 2 : 1;
       M2 hm; hm.w[0] = h0a; hm.w[1] = h0b;
       int found = -1;
-      uint32_t nb0 = 0, nb1 = 0, sx = 0;
+      uint32_t nb0 = 0, nb1 = 0, sxw = 0;
       int fs = 0;
       // Every lane prepares what the round needs from ITS reducer, should it be the divisor — the quotient LT h / LT f,
       // the monomial of the new term tail(f) * quotient, the sugar candidate: vector work the SIMDs have room for — and
       // the chosen lane's results travel by v_readlane: 4 words instead of 6 plus their arithmetic on the scalar unit,
       // which is the unit this kernel is bound by.  (Garbage in lanes that do not divide: unused.)
-      const uint32_t qA1 = h0b - S.slmA.w[1];
-      const uint32_t bA0 = S.stmA.w[0] + (h0a - S.slmA.w[0]), bA1 = S.stmA.w[1] + qA1;
-      const uint32_t fA = (S.sinA.y & 0xffffu) + (qA1 >> 16);
-      const uint64_t mA = ballot64(m_divides(S.slmA, hm));          // sentinels never divide
-      if (mA) {
-        found = __builtin_ctzll(mA);
-        nb0 = f_readlane(bA0, found); nb1 = f_readlane(bA1, found);
-        sx = f_readlane(S.sinA.x, found); fs = (int)f_readlane(fA, found);
-      } else if (nG > 64) {
-        const uint64_t mB = ballot64(m_divides(S.slmB, hm));
-        if (mB) {
-          const int l = __builtin_ctzll(mB);
-          found = 64 + l;
-          const uint32_t qB1 = h0b - S.slmB.w[1];
-          nb0 = f_readlane(S.stmB.w[0] + (h0a - S.slmB.w[0]), l); nb1 = f_readlane(S.stmB.w[1] + qB1, l);
-          sx = f_readlane(S.sinB.x, l); fs = (int)f_readlane((S.sinB.y & 0xffffu) + (qB1 >> 16), l);
+      if constexpr (decltype(regs)::value) f_banks<FRB>([&](auto b_) {    // banks in reducer order; the first divisor wins
+        constexpr int b = decltype(b_)::value;
+        if (found < 0 && (b == 0 || ngu > 64 * b)) {
+          const uint64_t mb = ballot64(m_divides(S.slm[b], hm));        // sentinels never divide
+          if (mb) {
+            const int l = __builtin_ctzll(mb);
+            found = 64 * b + l;
+            const uint32_t q1 = h0b - S.slm[b].w[1];
+            nb0 = f_readlane(S.stm[b].w[0] + (h0a - S.slm[b].w[0]), l); nb1 = f_readlane(S.stm[b].w[1] + q1, l);
+            sxw = f_readlane(S.sin[b].x, l); fs = (int)f_readlane((S.sin[b].y & 0xffffu) + (q1 >> 16), l);
+          }
+        }
+      });
+      if (OVF && found < 0 && ngu > 64 * FRB) {                      // reducers 128..: their order is sx[], their data the basis-order arrays
+        const int novf = ngu - 64 * FRB;
+        for (int k0 = 0; k0 < novf && found < 0; k0 += WAVE) {
+          const int k = k0 + lane;
+          const int gk = k < novf ? (int)sx[k] : 0;
+          const M2 fl = lm[gk];
+          const uint64_t mb = ballot64(k < novf && m_divides(fl, hm));
+          if (mb) {
+            const int l = __builtin_ctzll(mb);
+            found = 64 * FRB + k0 + l;
+            const int gs = (int)f_readlane((uint32_t)gk, l);
+            const M2 fm = f_readlane(fl, l), ft = tm[gs];
+            const uint2 info = gi[gs];
+            const uint32_t tc = info.x >> 16, q1 = h0b - fm.w[1];
+            nb0 = (uint32_t)uni((int)(ft.w[0] + (h0a - fm.w[0]))); nb1 = (uint32_t)uni((int)(ft.w[1] + q1));
+            sxw = (uint32_t)uni((int)(tc | (negmod(mulmod(tc, info.y & 0xffffu)) << 16)));
+            fs = uni((int)((info.y >> 16) + (q1 >> 16)));
+          }
         }
       }
       if (found >= 0) {                                              // h <- h - (LT h / LT f) f
-        const uint32_t tcg = sx & 0xffffu, kg = sx >> 16;            // kg = -tc / lc mod p, formed once when f entered the basis
+        const uint32_t tcg = sxw & 0xffffu, kg = sxw >> 16;          // kg = -tc / lc mod p, formed once when f entered the basis
         hsug = fs > hsug ? fs : hsug;
-        if (hsug > 65535) break;                                     // reported below; nothing has been modified
+        if (hsug > 65535) return;                                    // reported by the caller; nothing has been modified
         // the new term b = -(c tc) (tail f * q) takes the place of the cancelled lead term; then (b, h1) are put in
         // order (polynomials.cpp:148-177 on single optional terms) — in the common case nothing moves
         h0c = mulmod(h0c, kg);                                       // -(c_h / lc) tc; 0 when f has no tail
@@ -809,13 +789,154 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem, in
         if (ACCT) bytes += 12 * ((h0c ? 1 : 0) + (h1c ? 1 : 0));
         nred++;                                        // (terminates: the lead monomial strictly decreases)
       } else {                                                       // r <- r + LT h ; h <- h - LT h
-        if (ACCT) bytes += 8 * nG + 12 * (2 * hn - 1);
+        if (ACCT) bytes += 8 * ngu + 12 * (2 * hn - 1);
         if (r0c == 0) { r0c = h0c; r0a = h0a; r0b = h0b; } else { r1c = h0c; r1a = h0a; r1b = h0b; }
         const int d = (int)(h0b >> 16);
         rsug = d > rsug ? d : rsug;
         h0c = h1c; h0a = h1a; h0b = h1b; h1c = 0;
       }
-    }
+    };
+    if constexpr (!ACCT) {
+      // The lean variants run this loop as hand-scheduled assembly.  Written in C++ (the loop below, which the accounting
+      // variants keep: it is the specification) the compiler carries the joins of its paths as 64-bit flag words and
+      // scalar moves — about 58 scalar-pipe instructions per reduction round, on the unit that binds this kernel
+      // (DESIGN.md section 4.1); here a round in which the first 64 reducers hold the divisor takes 22.
+      // Register roles: h0 = (h0c; h0a, h0b) lead term of h, h1 its tail term (coefficient 0: none), r0 / r1 the remainder,
+      // (its monomials are outputs only: whoever reads them looks at the coefficient first), nred / rsug / hsug as in the C++ loop.  Lane l holds reducers l (A) and l + 64 (B): lead monomial (lm0, lm1), tail
+      // monomial (tm0, tm1), inx = tail coefficient | (-tc / lc) << 16, sug = sugar.  gfx950 wait states observed: a packed
+      // (VOP3P) result needs one state before a VALU reads it (s_nop 0); everything else here is interlocked.
+      const int ng_s = ngu;
+      uint32_t nred_u = 0, rsug_u = 0, hsug_u = (uint32_t)hsug;
+      uint32_t sl, sf, sx_, sxx, sq;
+      uint32_t t0, t1, t2;
+      // divisibility test of bank P's reducers against LT h; every lane also prepares the new term's monomial (t0, t2) and the
+      // sugar candidate (t1) should its reducer be the divisor
+#define FA_SCAN(P) \
+        "v_pk_sub_u16 %[t0], %[" #P "lm0], %[h0a] clamp\n\t" \
+        "v_pk_sub_u16 %[t1], %[" #P "lm1], %[h0b] clamp\n\t" \
+        "s_nop 0\n\t" \
+        "v_or_b32 %[t0], %[t0], %[t1]\n\t" \
+        "v_cmp_eq_u32 vcc, 0, %[t0]\n\t" \
+        "v_sub_u32 %[t1], %[h0b], %[" #P "lm1]\n\t" \
+        "v_sub_u32 %[t0], %[h0a], %[" #P "lm0]\n\t" \
+        "v_add_u32 %[t2], %[t1], %[" #P "tm1]\n\t" \
+        "v_add_u32 %[t0], %[t0], %[" #P "tm0]\n\t" \
+        "v_lshrrev_b32 %[t1], 16, %[t1]\n\t" \
+        "v_add_u32 %[t1], %[t1], %[" #P "sug]\n\t"
+      // the first divisor of bank P (vcc non-zero): its quotient data travel by v_readlane
+#define FA_PICK(P) \
+        "s_ff1_i32_b64 %[sl], vcc\n\t" \
+        "v_readlane_b32 %[sf], %[t1], %[sl]\n\t" \
+        "v_readlane_b32 %[sx], %[" #P "inx], %[sl]\n\t" \
+        "s_max_i32 %[hsug], %[hsug], %[sf]\n\t" \
+        "s_cmp_gt_i32 %[hsug], 0xffff\n\t" \
+        "s_cbranch_scc1 L_done_%=\n\t" \
+        "v_readlane_b32 %[h0a], %[t0], %[sl]\n\t" \
+        "v_readlane_b32 %[h0b], %[t2], %[sl]\n\t"
+      // a later bank P (reducers 64 b ..): only when the basis reaches into it (NGMIN = 64 b + 1), next bank or L_tm behind it
+#define FA_TRY(P, NGMIN, NEXT) \
+        "L_try" #P "_%=:\n\t" \
+        "s_cmp_lt_i32 %[ng], " #NGMIN "\n\t" \
+        "s_cbranch_scc1 L_tm_%=\n\t" \
+        FA_SCAN(P) \
+        "s_cbranch_vccz " NEXT "_%=\n\t" \
+        FA_PICK(P) \
+        "s_branch L_red_%=\n\t"
+#define FA_HEAD(NEXT) \
+        "L_top_%=:\n\t" \
+        "s_cmp_eq_u32 %[h0c], 0\n\t" \
+        "s_cbranch_scc1 L_done_%=\n\t" \
+        FA_SCAN(a) \
+        "s_cbranch_vccz " NEXT "_%=\n\t" \
+        FA_PICK(a) \
+        "L_red_%=:\n\t"                                   /* h <- h - (LT h / LT f) f: the new term takes the lead term's place */ \
+        "s_lshr_b32 %[sq], %[sx], 16\n\t" \
+        "s_mul_i32 %[sxx], %[h0c], %[sq]\n\t" \
+        "s_mul_hi_u32 %[sq], %[sxx], 0x4187a4af\n\t" \
+        "s_lshr_b32 %[sq], %[sq], 13\n\t" \
+        "s_mul_i32 %[sq], %[sq], 0x7d03\n\t" \
+        "s_sub_u32 %[h0c], %[sxx], %[sq]\n\t" \
+        "s_add_u32 %[nred], %[nred], 1\n\t" \
+        "s_cmp_eq_u32 %[h0c], 0\n\t" \
+        "s_cbranch_scc1 L_shift_%=\n\t" \
+        "s_cmp_eq_u32 %[h1c], 0\n\t" \
+        "s_cbranch_scc1 L_top_%=\n\t" \
+        "s_xor_b32 %[sxx], %[h1b], 0xffff\n\t"           /* grevlex keys: high word ^ 0xffff, low word complemented */ \
+        "s_xor_b32 %[sq], %[h0b], 0xffff\n\t" \
+        "s_cmp_lt_u32 %[sxx], %[sq]\n\t" \
+        "s_cbranch_scc1 L_top_%=\n\t"                     /* the new term leads: nothing moves */ \
+        "s_cmp_eq_u32 %[sxx], %[sq]\n\t" \
+        "s_cbranch_scc0 L_swap_%=\n\t" \
+        "s_cmp_lt_u32 %[h1a], %[h0a]\n\t" \
+        "s_cbranch_scc1 L_swap_%=\n\t" \
+        "s_cmp_eq_u32 %[h1a], %[h0a]\n\t" \
+        "s_cbranch_scc0 L_top_%=\n\t" \
+        "s_add_u32 %[sxx], %[h0c], %[h1c]\n\t"            /* equal monomials: one term, coefficients added mod p */ \
+        "s_add_u32 %[sq], %[sxx], 0xffff82fd\n\t" \
+        "s_min_u32 %[h0c], %[sxx], %[sq]\n\t" \
+        "s_mov_b32 %[h1c], 0\n\t" \
+        "s_branch L_top_%=\n\t" \
+        "L_swap_%=:\n\t"                                  /* the old tail leads */ \
+        "s_mov_b32 %[sxx], %[h0c]\n\t" "s_mov_b32 %[h0c], %[h1c]\n\t" "s_mov_b32 %[h1c], %[sxx]\n\t" \
+        "s_mov_b32 %[sxx], %[h0a]\n\t" "s_mov_b32 %[h0a], %[h1a]\n\t" "s_mov_b32 %[h1a], %[sxx]\n\t" \
+        "s_mov_b32 %[sxx], %[h0b]\n\t" "s_mov_b32 %[h0b], %[h1b]\n\t" "s_mov_b32 %[h1b], %[sxx]\n\t" \
+        "s_branch L_top_%=\n\t" \
+        "L_shift_%=:\n\t"                                 /* the new term vanished (a reducer without tail): h <- its tail term */ \
+        "s_mov_b32 %[h0c], %[h1c]\n\t" "s_mov_b32 %[h0a], %[h1a]\n\t" "s_mov_b32 %[h0b], %[h1b]\n\t" "s_mov_b32 %[h1c], 0\n\t" \
+        "s_branch L_top_%=\n\t"
+#define FA_TAIL \
+        "L_tm_%=:\n\t"                                    /* r <- r + LT h ; h <- h - LT h */ \
+        "s_cmp_eq_u32 %[r0c], 0\n\t" \
+        "s_cbranch_scc0 L_tm1_%=\n\t" \
+        "s_mov_b32 %[r0c], %[h0c]\n\t" "s_mov_b32 %[r0a], %[h0a]\n\t" "s_mov_b32 %[r0b], %[h0b]\n\t" \
+        "s_branch L_tm2_%=\n\t" \
+        "L_tm1_%=:\n\t" \
+        "s_mov_b32 %[r1c], %[h0c]\n\t" "s_mov_b32 %[r1a], %[h0a]\n\t" "s_mov_b32 %[r1b], %[h0b]\n\t" \
+        "L_tm2_%=:\n\t" \
+        "s_lshr_b32 %[sxx], %[h0b], 16\n\t" \
+        "s_max_i32 %[rsug], %[rsug], %[sxx]\n\t" \
+        "s_mov_b32 %[h0c], %[h1c]\n\t" "s_mov_b32 %[h0a], %[h1a]\n\t" "s_mov_b32 %[h0b], %[h1b]\n\t" "s_mov_b32 %[h1c], 0\n\t" \
+        "s_branch L_top_%=\n\t" \
+        "L_done_%=:"
+#define FA_OUTS \
+          [h0c] "+s"(h0c), [h0a] "+s"(h0a), [h0b] "+s"(h0b), [h1c] "+s"(h1c), [h1a] "+s"(h1a), [h1b] "+s"(h1b), \
+          [r0c] "+s"(r0c), [r0a] "=&s"(r0a), [r0b] "=&s"(r0b), [r1c] "+s"(r1c), [r1a] "=&s"(r1a), [r1b] "=&s"(r1b), \
+          [nred] "+s"(nred_u), [rsug] "+s"(rsug_u), [hsug] "+s"(hsug_u), \
+          [sl] "=&s"(sl), [sf] "=&s"(sf), [sx] "=&s"(sx_), [sxx] "=&s"(sxx), [sq] "=&s"(sq), \
+          [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2)
+#define FA_BANK(P, b) \
+          [P##lm0] "v"(S.slm[b].w[0]), [P##lm1] "v"(S.slm[b].w[1]), [P##tm0] "v"(S.stm[b].w[0]), [P##tm1] "v"(S.stm[b].w[1]), \
+          [P##inx] "v"(S.sin[b].x), [P##sug] "v"(S.sin[b].y & 0xffffu)
+      if constexpr (!OVF) {
+        asm volatile(FA_HEAD("L_tryb") FA_TRY(b, 65, "L_tm") FA_TAIL
+                     : FA_OUTS : FA_BANK(a, 0), FA_BANK(b, 1), [ng] "s"(ng_s) : "vcc", "scc");
+      } else {
+        // Reducers beyond the registers (|G| > 128: about once per 10^5 episodes of 3-20-10-weighted): at the first round whose
+        // lead term no register reducer divides the assembly leaves with bit 31 of the round counter set, and the rest of this
+        // reduction runs in round_cpp, which also looks through the overflow order.
+        asm volatile(FA_HEAD("L_tryb") FA_TRY(b, 65, "L_ovf")
+                     "L_ovf_%=:\n\t"
+                     "s_cmp_lt_i32 %[ng], 129\n\t"
+                     "s_cbranch_scc1 L_tm_%=\n\t"
+                     "s_bitset1_b32 %[nred], 31\n\t"
+                     "s_branch L_done_%=\n\t"
+                     FA_TAIL
+                     : FA_OUTS : FA_BANK(a, 0), FA_BANK(b, 1), [ng] "s"(ng_s) : "vcc", "scc");
+      }
+#undef FA_SCAN
+#undef FA_PICK
+#undef FA_TRY
+#undef FA_HEAD
+#undef FA_TAIL
+#undef FA_OUTS
+#undef FA_BANK
+      nred = (int)nred_u; rsug = (int)rsug_u; hsug = (int)hsug_u;
+      if (OVF && __builtin_expect(nred < 0, 0)) {
+        nred &= 0x7fffffff;
+        while (h0c != 0 && hsug <= 65535) round_cpp(std::true_type{});
+      }
+    } else
+    while (h0c != 0 && hsug <= 65535) round_cpp(std::true_type{});
     if (hsug > 65535) { status = BBX_ST_DEG_OVERFLOW; break; }
     rsug = rsug > hsug ? rsug : hsug;
     BTerm<2> r0, r1;
@@ -824,7 +945,7 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem, in
     FSTAMP(3);                                             // 3: reduce
     // ---- basis / pair-set update (buchberger.cpp:321-327) ------------------------------------------------------------
     const int nG_before = nG, nP_before = nP - 1;
-    if (r0.c == 0) {                                       // zero reduction: only P.erase(remove(action)), stable
+    if (uni((int)r0.c) == 0) {                             // zero reduction: only P.erase(remove(action)), stable
       if (nP <= 64) {                                      // all in the register copy: shift it, store the moved part
         const uint32_t sh = f_wave_shl(PA);
         const bool moved = lane >= action && lane < nP - 1;
@@ -844,8 +965,11 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem, in
       nP -= 1;
       zero_red++;
     } else {
-      if (nG < 64) add_poly(r0, r1, rsug, action, std::true_type{});   // (the common case; basis means are ~35)
-      else add_poly(r0, r1, rsug, action, std::false_type{});
+      // (the common case first: basis means are ~35; the four-bank form only beyond 128 elements, about once per 10^5
+      // episodes of 3-20-10-weighted, and said to be unlikely: the register allocator then keeps its copies out of the way)
+      if (__builtin_expect(nG < 64, 1)) add_poly(r0, r1, rsug, action, std::integral_constant<int, 1>{});
+      else if (NBK == 2 || __builtin_expect(nG < 128, 1)) add_poly(r0, r1, rsug, action, std::integral_constant<int, 2>{});
+      else add_poly(r0, r1, rsug, action, std::integral_constant<int, NBK>{});
       if (ACCT) bytes += 12 * (r1.c ? 2 : 1) + 8 * nG_before + 8 * (nP_before + nP);
     }
     FSTAMP(4);                                             // 4: add_poly (pair update, insert)
@@ -928,13 +1052,26 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem, in
   if (PROF && cz->prof && lane == 0) for (int i = 0; i < 8; i++) cz->prof[(size_t)env * 8 + i] = prof_sum[i];
 
   const bool handoff = status == BBX_ST_SPILL;
+  if (handoff && lane == 0 && cz->ctl_stats) atomicAdd((unsigned long long*)cz->ctl_stats + 1, 1ull);   // statistics: environments that left the class
   if (POL == 0 && p.obs && status == BBX_ST_OK) { if (obs32) write_obs32(); else write_obs(true, false); obs_trunc |= nP > p.obs_rows ? 1 : 0; }
   if (staged_in) {                                                   // write the live prefixes back to the HBM record
     wave_sync();
     F_HBM_PTRS(cz)
-    if (lane < nG) { g_slm[lane] = S.slmA; g_stm[lane] = S.stmA; g_si[lane] = S.sinA; g_lm[lane] = lm[lane]; g_tm[lane] = tm[lane]; g_gi[lane] = gi[lane]; }
-    if (lane + 64 < nG) { g_slm[lane + 64] = S.slmB; g_stm[lane + 64] = S.stmB; g_si[lane + 64] = S.sinB;
-                          g_lm[lane + 64] = lm[lane + 64]; g_tm[lane + 64] = tm[lane + 64]; g_gi[lane + 64] = gi[lane + 64]; }
+    f_banks<NBK>([&](auto b_) {
+      constexpr int b = decltype(b_)::value;
+      const int i = lane + 64 * b;
+      if (i < nG) {
+        if constexpr (b < FRB) { g_slm[i] = S.slm[b]; g_stm[i] = S.stm[b]; g_si[i] = S.sin[b]; }
+        else {                                                       // the record's reducer-order entry, rebuilt from the basis-order arrays
+          const int gk = sx[i - 64 * FRB];
+          const uint2 info = gi[gk];
+          const uint32_t tc = info.x >> 16;
+          g_slm[i] = lm[gk]; g_stm[i] = tm[gk];
+          g_si[i] = make_uint2(tc | (negmod(mulmod(tc, info.y & 0xffffu)) << 16), (info.y >> 16) | ((uint32_t)gk << 16));
+        }
+        g_lm[i] = lm[i]; g_tm[i] = tm[i]; g_gi[i] = gi[i];
+      }
+    });
     for (int i = lane; i < nP; i += WAVE) g_pr[i] = pairs[i];
   }
   if (lane == 0) {
@@ -980,16 +1117,16 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem, in
 }
 
 template <bool TRACE, bool ACCT>
-__global__ __launch_bounds__(256) void bbx_fast_kernel(BbxFastParams p) {
+__global__ __launch_bounds__(256, 4) void bbx_fast_kernel(BbxFastParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   fast_body<TRACE, ACCT>(p, smem);
 }
-__global__ __launch_bounds__(256) void bbx_fast_headline_kernel(BbxFastParams p) {
+__global__ __launch_bounds__(256, 4) void bbx_fast_headline_kernel(BbxFastParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   fast_body<false, false, false, true>(p, smem);
 }
 // value() rollouts of the register/LDS-resident class
-__global__ __launch_bounds__(256) void bbx_fast_value_kernel(BbxFastParams p) {
+__global__ __launch_bounds__(256, 4) void bbx_fast_value_kernel(BbxFastParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   fast_body<false, false, false, false, 0, false, true>(p, smem);
 }
@@ -1000,11 +1137,11 @@ __global__ __launch_bounds__(256, 4) void bbx_fast_policy_session_kernel(BbxFast
   fast_body<false, false, false, false, NB, true>(q.f, smem);
 }
 // the kernels of persistent sessions (fast_body PERSIST): the headline shape and the general lean one
-__global__ __launch_bounds__(256) void bbx_fast_headline_persistent_kernel(BbxFastParams p) {
+__global__ __launch_bounds__(256, 4) void bbx_fast_headline_persistent_kernel(BbxFastParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   fast_body<false, false, false, true, 0, true>(p, smem);
 }
-__global__ __launch_bounds__(256) void bbx_fast_persistent_kernel(BbxFastParams p) {
+__global__ __launch_bounds__(256, 4) void bbx_fast_persistent_kernel(BbxFastParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   fast_body<false, false, false, false, 0, true>(p, smem);
 }
@@ -1020,7 +1157,7 @@ __global__ __launch_bounds__(256, 4) void bbx_fast_policy_kernel(BbxFastPolicyPa
   const int action = pmlp_act_wave<NB, KS>(smem, env, env < q.f.B, q.f.obs, q.f.rows, q.f.obs_rows, 2 * q.f.k * q.f.nvars, q.pol.wp, q.pol.u,
                                            q.pol.actions, q.pol.logprobs);
   __syncthreads();                                     // the policy's LDS scratch becomes the step's state
-  fast_body<false, false>(q.f, smem, action);
+  fast_body<false, false, false, false, 0, false, false, FNBK_POL>(q.f, smem, action);   // (the policy's registers and LDS leave room for two banks)
 }
 // policy rollout: nsteps steps per launch with the policy inside the step loop (fast_body POL)
 template <int NB>
@@ -1030,7 +1167,7 @@ __global__ __launch_bounds__(256, 4) void bbx_fast_policy_rollout_kernel(BbxFast
 }
 #ifdef BBX_PROF_BUILD
 // diagnostic build with s_memtime stamps between the phases of a step (never timed, never shipped as a result)
-__global__ __launch_bounds__(256) void bbx_fast_prof_kernel(BbxFastParams p) {
+__global__ __launch_bounds__(256, 4) void bbx_fast_prof_kernel(BbxFastParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   fast_body<false, false, true>(p, smem);
 }

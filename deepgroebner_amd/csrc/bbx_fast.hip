@@ -12,7 +12,7 @@ extern "C" int bbx_launch_fast(const BbxParams* p, int blocks, int threads, int 
   f.rec_bytes = p->L.rec_bytes; f.hbmG = p->L.maxG;
   f.q_env_stride = p->q.env_stride; f.q_slot_words = p->q.slot_words; f.q_nslots = p->q.nslots; f.q_fixed = p->q.fixed;
   f.B = p->B; f.nsteps = p->nsteps; f.obs_rows = p->obs_rows; f.trace_stride = p->trace_stride; f.k = p->k; f.nvars = p->nvars;
-  f.lim_G = (int)p->LL.maxG; f.lim_P = (int)p->LL.maxP;
+  f.lim_G = p->fast_G; f.lim_P = p->fast_P;
   f.agent = p->agent; f.auto_reset = p->auto_reset; f.set_budget = p->set_budget; f.pass = p->pass;
   f.obs_every_step = p->obs_every_step; f.obs_fill = p->obs_fill; f.rewards_mode = p->rewards_mode;
   f.lite = p->lite; f.done_seq = p->done_seq;
@@ -20,7 +20,7 @@ extern "C" int bbx_launch_fast(const BbxParams* p, int blocks, int threads, int 
   f.sort_input = p->sort_input;
   f.ctl = p->ctl; f.sess_target = p->sess_target; f.ctl_stats = p->ctl_stats; f.slice_ticks = p->slice_ticks;
   f.gamma = p->gamma; f.values = p->values;
-  const size_t lds = (size_t)envs_per_block * FLDS_BYTES;
+  const size_t lds = (size_t)envs_per_block * FLay<FNBK_WIDE>::BYTES, lds_pol = (size_t)envs_per_block * FLay<FNBK_POL>::BYTES;
 #ifdef BBX_PROF_BUILD
   static unsigned long long* d_prof = nullptr;
   if (getenv("BBX_PROF") && !p->trace) {          // diagnostic: per-phase cycle sums, printed by bbx_prof_dump()
@@ -43,7 +43,7 @@ extern "C" int bbx_launch_fast(const BbxParams* p, int blocks, int threads, int 
     q.f.agent = BBX_AGENT_EXTERNAL; q.f.actions = q.pol.actions;
     if (q.pol.rollout) {                                   // nsteps steps, the policy inside the step loop (3 variables, k = 2)
       q.f.actions = nullptr; q.f.rewards = nullptr; q.f.dones = nullptr; q.f.rows = q.pol.post_obs ? q.pol.rows_t : nullptr; q.f.obs_every_step = 0; q.f.auto_reset = 1;
-      const size_t rl = (size_t)envs_per_block * (FLDS_BYTES + 4 * FP) + ((size_t)(2 * 6 + 2) * 32 * pmlp_nb_for(q.pol.hidden) + 4) * sizeof(float);
+      const size_t rl = (size_t)envs_per_block * (FLay<FNBK_POL>::BYTES + 4 * FLay<FNBK_POL>::P) + ((size_t)(2 * 6 + 2) * 32 * pmlp_nb_for(q.pol.hidden) + 4) * sizeof(float);
       if (p->ctl) {                                        // per-step calls served by a persistent session
         if (pmlp_nb_for(q.pol.hidden) == 2) hipLaunchKernelGGL((bbx_fast_policy_session_kernel<2>), dim3(blocks), dim3(threads), rl, stream, q);
         else hipLaunchKernelGGL((bbx_fast_policy_session_kernel<4>), dim3(blocks), dim3(threads), rl, stream, q);
@@ -54,7 +54,7 @@ extern "C" int bbx_launch_fast(const BbxParams* p, int blocks, int threads, int 
       return 0;
     }
     const int nb = pmlp_nb_for(q.pol.hidden), ks = pmlp_ks_for(2 * f.k * f.nvars);
-    const size_t pl = pmlp_lds_bytes(envs_per_block), ll = pl > lds ? pl : lds;
+    const size_t pl = pmlp_lds_bytes(envs_per_block), ll = pl > lds_pol ? pl : lds_pol;
     if (ks == 3) { if (nb == 2) hipLaunchKernelGGL((bbx_fast_policy_kernel<2, 3>), dim3(blocks), dim3(threads), ll, stream, q);
                    else hipLaunchKernelGGL((bbx_fast_policy_kernel<4, 3>), dim3(blocks), dim3(threads), ll, stream, q); }
     else { if (nb == 2) hipLaunchKernelGGL((bbx_fast_policy_kernel<2, 6>), dim3(blocks), dim3(threads), ll, stream, q);

@@ -259,8 +259,10 @@ int bbx_sync(bbx_batch* b);
  * A wave that sees no news for 20 ms leaves by itself (a session never outlives an idle host by more than that). */
 int bbx_persistent(bbx_batch* b, int enable);
 int bbx_join(bbx_batch* b, void* stream);
-/* out4 = {sessions begun, calls that joined a running session, env-steps taken by later kernels of sessions, kernels} */
-int bbx_session_stats(bbx_batch* b, int64_t* out4);
+/* out5 = {sessions begun, calls that joined a running session, env-steps taken by later kernels of sessions, kernels,
+ *         environments that left the register/LDS-resident class (basis beyond 256 elements / 512 pairs) and were continued
+ *         by the HBM-resident pass: counted while sessions are enabled} */
+int bbx_session_stats(bbx_batch* b, int64_t* out5);
 
 /* ---- HIP graphs ---------------------------------------------------------------------------------------------------------
  * The asynchronous device calls (bbx_step_device[_autoreset], bbx_rollout_device, bbx_policy_step_device,

@@ -249,21 +249,23 @@ def test_capacity_is_a_cliff_not_a_failure(dist, B, T, caps, cls):
 
 
 @pytest.mark.parametrize("persistent", [0, 1])
-def test_fast_class_second_reducer_bank_lean(persistent):
+@pytest.mark.parametrize("dist,B,T,reach", [("3-20-40-weighted", 96, 120, 64), ("3-20-140-weighted", 32, 160, 128),
+                                            ("3-20-200-weighted", 24, 120, 192), ("3-20-260-weighted", 16, 100, 256)])
+def test_fast_class_second_reducer_bank_lean(persistent, dist, B, T, reach):
     """3-20-40-weighted starts every episode with 40 generators, so bases pass 64 elements within a few steps: the lean fast
     kernels (the reduction loop written in assembly, bbx_fast.h) find divisors in the second bank of reducer registers
-    (reducers 64..127), environments that outgrow 128 continue in the HBM-resident class and come back — counters of every
+    (reducers 64..127); with 140 / 200 generators the third and fourth banks (reducers 128..255) are in use; with 260 every
+    environment outgrows the class's 256 elements, continues in the HBM-resident class and comes back — counters of every
     environment and sampled final states against the oracle, with one kernel per launch and through a persistent session."""
     import torch
     from deepgroebner_amd import VecLeadMonomialsEnv
     bo = ffi.load("bo")
-    dist, B, T = "3-20-40-weighted", 96, 120
     want = bo.run_random_many(dist, 2, range(700, 700 + B), range(B), T, True, 0)
-    assert max(r["nG"] for r in want) > 64
+    assert max(r["nG"] for r in want) > reach
     env = VecLeadMonomialsEnv(dist, batch=B, k=2)
     env.seed(np.arange(B) + 700); env.seed_agent(np.arange(B)); env.reset()
     env.accounting(False)
-    R = 512
+    R = 1024
     d_obs = torch.empty((B, R, env.cols), dtype=torch.int32, device="cuda")
     d_rew = torch.empty(B, dtype=torch.float64, device="cuda"); d_done = torch.empty(B, dtype=torch.uint8, device="cuda")
     d_rows = torch.empty(B, dtype=torch.int32, device="cuda")
