@@ -70,7 +70,45 @@ def parse_args():
     ap.add_argument("--no-persistent", action="store_true", help="one kernel per launch instead of a persistent session")
     ap.add_argument("--allow-oversubscribe", action="store_true",
                     help="rehearsal only: accept more ranks than visible GPUs (the line then says \"oversubscribed\": true)")
+    ap.add_argument("--rehearse-plumbing", action="store_true",
+                    help="no GPU is touched and nothing is measured: a stand-in that only counts the steps issued to it takes the device's "
+                         "place, so that the rank plumbing of an N-GPU run (rendezvous, build-once barrier, device-identity check, agreement "
+                         "on the repeat count, max-over-ranks time, ONE line from rank 0) can be rehearsed on a box without N GPUs; the "
+                         "line says \"rehearsal\": true and carries value null")
     return ap.parse_args()
+
+
+class _CountingStandIn:
+    """--rehearse-plumbing: the calls bench.py makes on a batch, answered by step counters alone (no device, no oracle, no
+    arithmetic: there is nothing to measure and nothing is reported as measured)."""
+
+    def __init__(self, batch, counters=None):
+        import numpy as np
+        self.B, self.cols = batch, 12
+        self.c = np.zeros((batch, 8), dtype=np.int64) if counters is None else counters.copy()
+
+    def seed(self, seeds): pass
+    def seed_agent(self, seeds): pass
+    def reset(self): pass
+    def accounting(self, on): pass
+    def persistent(self, on): pass
+    def sync(self): pass
+    def join(self, stream=0): pass
+    def stats(self): return self.c.copy()
+    def session_stats(self): return {"sessions": 0, "joined": 0, "later_kernel_steps": 0, "kernels": 0, "spills": 0}
+    def copy(self): return _CountingStandIn(self.B, self.c)
+
+    def rollout_device(self, agent, nsteps, *rest):
+        self.c[:, 0] += nsteps; self.c[:, 1] += 3 * nsteps; self.c[:, 6] += 1578 * nsteps
+
+    def rollout(self, agent, nsteps, auto_reset=True):
+        self.rollout_device(agent, nsteps)
+
+
+class _HostEvent:
+    def __init__(self, enable_timing=True): self.t = 0.0
+    def record(self, stream=None): self.t = time.perf_counter()
+    def elapsed_time(self, other): return (other.t - self.t) * 1e3
 
 
 def spawn_ranks(args):
@@ -109,11 +147,12 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo")
+    rehearsal = args.rehearse_plumbing
     if local_rank == 0:
-        graft.build()
+        graft.build()                                 # (one rank builds, the others wait at the barrier: the library is shared)
     if world > 1:
         dist.barrier()
-    ndev = torch.cuda.device_count()
+    ndev = int(os.environ.get("BBX_REHEARSE_DEVICES", world)) if rehearsal else torch.cuda.device_count()
     if ndev < 1:
         raise SystemExit("no GPU visible: libbbx has no CPU fallback")
     # one rank per distinct GPU, or the line must say otherwise: a scaling figure from ranks that share a device is not one
@@ -121,8 +160,11 @@ def main():
     if oversubscribed and not args.allow_oversubscribe:
         raise SystemExit("--gpus %d but only %d GPU(s) visible: refusing to oversubscribe (rehearsals: --allow-oversubscribe)" % (world, ndev))
     device = local_rank % ndev
-    torch.cuda.set_device(device)
-    uuid = str(torch.cuda.get_device_properties(device).uuid) if hasattr(torch.cuda.get_device_properties(device), "uuid") else "dev%d" % device
+    if rehearsal:
+        uuid = "rehearsal-device-%d" % device
+    else:
+        torch.cuda.set_device(device)
+        uuid = str(torch.cuda.get_device_properties(device).uuid) if hasattr(torch.cuda.get_device_properties(device), "uuid") else "dev%d" % device
     if world > 1:
         uuids = [None] * world
         dist.all_gather_object(uuids, uuid)
@@ -132,19 +174,26 @@ def main():
     from deepgroebner_amd.shard import plan
 
     K, Wm, B = args.steps, args.warmup, args.batch
-    env = VecLeadMonomialsEnv(args.dist, batch=B, k=K_LEADS, device=device)
+    if rehearsal:                                     # counters in place of the device; the product path below is otherwise unchanged
+        import types
+        env = _CountingStandIn(B)
+        tdev, gpu_sync, Event = "cpu", (lambda: None), _HostEvent
+        stream = types.SimpleNamespace(cuda_stream=0)
+    else:
+        env = VecLeadMonomialsEnv(args.dist, batch=B, k=K_LEADS, device=device)
+        tdev, gpu_sync, Event = "cuda", torch.cuda.synchronize, torch.cuda.Event
+        stream = torch.cuda.current_stream()
     pl = plan(rank, world, B)                         # contiguous block of global environment ids
     env.seed(pl["ideal_seeds"])
     env.seed_agent(pl["agent_seeds"])
     env.reset()
 
-    stream = torch.cuda.current_stream()
     cols = env.cols
     obs_rows = 512                                    # the fast class holds |P| <= 512: no observation row is ever cut
-    d_obs = torch.empty((B, obs_rows, cols), dtype=torch.int32, device="cuda")
-    d_rew = torch.empty(B, dtype=torch.float64, device="cuda")
-    d_done = torch.empty(B, dtype=torch.uint8, device="cuda")
-    d_rows = torch.empty(B, dtype=torch.int32, device="cuda")
+    d_obs = torch.empty((B, obs_rows, cols), dtype=torch.int32, device=tdev)
+    d_rew = torch.empty(B, dtype=torch.float64, device=tdev)
+    d_done = torch.empty(B, dtype=torch.uint8, device=tdev)
+    d_rows = torch.empty(B, dtype=torch.int32, device=tdev)
     chain = not os.environ.get("BBX_HOST_GEN")        # device-drawn ideals: launches need no host service in between
 
     def launch(nsteps):
@@ -159,12 +208,12 @@ def main():
     launch(max(args.preroll, 0) or 1); env.sync()     # steady state
     if Wm > 0:
         launch(Wm); env.sync()
-    torch.cuda.synchronize()
+    gpu_sync()
     t0 = time.perf_counter()
     ncal = (64 if persistent else 8) if chain else 1 # calibration (also the untimed warm-up of this launch shape): chained
     for _ in range(ncal):                             # launches, so that the synchronisation is not mistaken for launch time
         launch(K)
-    env.sync(); torch.cuda.synchronize()
+    env.sync(); gpu_sync()
     t_launch = (time.perf_counter() - t0) / ncal
     R = args.repeats if args.repeats > 0 else int(min(1 << 16, max(3, MIN_REGION_MS * 1e-3 / max(t_launch, 1e-6) + 1)))
     if world > 1:
@@ -175,10 +224,10 @@ def main():
     sess0 = env.session_stats()
     twin = env.copy()                               # same state, same generator state: replayed after the timed region
 
-    torch.cuda.synchronize()
+    gpu_sync()
     if world > 1:
         dist.barrier()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0, ev1 = Event(enable_timing=True), Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record(stream)
     for _ in range(R):
@@ -186,7 +235,7 @@ def main():
     env.join(stream.cuda_stream)                    # (persistent session: the caller's stream waits for its kernels, on the device)
     ev1.record(stream)
     env.sync()
-    torch.cuda.synchronize()
+    gpu_sync()
     t1 = time.perf_counter()
     if world > 1:
         dist.barrier()
@@ -201,13 +250,13 @@ def main():
         launch(64)                                  # (the statistics call above closed the session: a new one gets going)
         env.join(stream.cuda_stream)
         n_long = int(max(8, LONG_REGION_MS / max(1024 * region_ms / (R * K), 1e-6) + 1))
-        ev2, ev3 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev2, ev3 = Event(enable_timing=True), Event(enable_timing=True)
         ev2.record(stream)
         for _ in range(n_long):
             launch(1024)
         env.join(stream.cuda_stream)
         ev3.record(stream)
-        env.sync(); torch.cuda.synchronize()
+        env.sync(); gpu_sync()
         long_ms = ev2.elapsed_time(ev3)
         long_launch = {"steps_per_launch": 1024, "launches": n_long, "value": n_long * 1024 * B / (long_ms * 1e-3), "unit": "env-steps/s",
                        "region_ms": long_ms,
@@ -218,7 +267,7 @@ def main():
     steps_done = int(d[:, 0].sum())
     assert steps_done == R * K * B, "every environment must have executed exactly R*K steps (%d != %d)" % (steps_done, R * K * B)
     assert (st1[:, 4] == 0).all(), "an environment reported an error status"
-    assert int(d_rows.max().item()) <= obs_rows
+    assert rehearsal or int(d_rows.max().item()) <= obs_rows
     additions = int(d[:, 1].sum())
     # algorithmic bytes of exactly these steps: replay them on the twin with the accounting kernel (untimed)
     twin.accounting(True)
@@ -242,13 +291,13 @@ def main():
         steps_done, additions, alg_bytes = int(s[0]), int(s[1]), int(s[2])
 
     cpu = cpu_all = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline and not rehearsal:
         cpu = cpu_baseline(args, st1, int(st1[0, 0]), B)
         if not args.no_cpu_all_cores:
             cpu_all = cpu_baseline_all_cores(args, st1, int(st1[0, 0]), B, cpu)
 
     if rank == 0:
-        value = steps_done / elapsed
+        value = None if rehearsal else steps_done / elapsed
         kernel = ("bbx_fast_headline_persistent_kernel" if persistent else "bbx_fast_headline_kernel") if not args.generic_kernel else "bbx_fast_kernel<false,false>"
         # the dominant (only) kernel: per launch, algorithmic bytes of ONE GPU / its HIP-event duration
         per_launch_bytes = alg_bytes / world / R
@@ -287,22 +336,24 @@ def main():
         out = {
             "metric": "env steps/sec (polynomial additions) on 3-20-10-weighted, batch=4096, 1/2/4/8 GPU",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": Wm,
-            "ms_per_step": elapsed * 1e3 / (R * K), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": None if rehearsal else elapsed * 1e3 / (R * K), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u16 exponents / u32 GF(32003)",
-            "data": "synthetic (random binomial ideals drawn on the device from per-environment seeds, inside the timed region)",
+            "data": ("NONE: plumbing rehearsal, no device, nothing measured" if rehearsal else
+                     "synthetic (random binomial ideals drawn on the device from per-environment seeds, inside the timed region)"),
             "repeats": R, "preroll_steps": max(args.preroll, 0) or 1, "timed_steps": R * K, "elapsed_s": elapsed,
             "config": {"workload": "%s k=%d batch=%d/GPU random-hash agent auto-reset, observation written every step" % (args.dist, K_LEADS, B),
                        "global_batch": B * world, "steps_per_launch": K, "parallelism": "env-sharded x%d, no collectives" % world,
                        "devices_visible": ndev, "launch_path": "persistent session (bbx_persistent)" if persistent else "one kernel per launch"},
-            "oversubscribed": bool(oversubscribed), "per_rank_value": per_rank,
-            "additions": additions,
-            "additions_per_s": additions / elapsed,
+            "oversubscribed": bool(oversubscribed), "per_rank_value": [None] * world if rehearsal else per_rank,
+            "rehearsal": bool(rehearsal),
+            "additions": None if rehearsal else additions,
+            "additions_per_s": None if rehearsal else additions / elapsed,
             "long_launch": long_launch,
             "session_stats": ({"timed_region": {k_: sess[k_] - sess0[k_] for k_ in sess}, "whole_run": sess_end,
                                "note": "spills = environments that left the register/LDS class (basis beyond 256 elements or 512 pairs) and "
                                        "were continued by the HBM-resident pass; later_kernel_steps = env-steps taken by closing kernels"}
                               if persistent else None),
-            "roofline": roof,
+            "roofline": None if rehearsal else roof,
             "cpu_baseline": cpu,
             "cpu_baseline_all_cores": cpu_all,
         }
@@ -329,22 +380,44 @@ def cpu_baseline(args, st_final, steps_per_env, B):
             "additions_match_device": bool(res["additions"] == dev_adds)}
 
 
-def cpu_baseline_all_cores(args, st_final, steps_per_env, B, single):
-    """SURVEY 8d-ii / BASELINE.md 3.3: the same CPU code with one environment stream per host core — `nproc` threads, each
-    running its own slice of the same batch (thread i: environments i*n .. (i+1)*n - 1, same seeds as the device's) for a
-    bounded number of steps.  The library call releases the GIL; environments share nothing."""
+def _cpu_share():
+    """Host cores this process may use: the affinity mask, cut down by a cgroup CPU quota where one is set."""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            cores = min(cores, max(1, int(float(q) / float(per) + 0.5)))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                cores = min(cores, max(1, int(q / per + 0.5)))
+        except (OSError, ValueError):
+            pass
+    return cores
+
+
+def cpu_baseline_all_cores(args, st_final, steps_per_env, B, single, seconds=8.0):
+    """SURVEY 8d-ii / BASELINE.md 3.3: the same CPU code with one environment stream per host core — one thread per core
+    this process may use (`cores`; `nproc` = what the machine has), each running environments of its own slice of the same
+    batch (same seeds as the device's), chunk after chunk until `seconds` have passed: a bounded sample whatever share of
+    the machine the cores really are.  The library call releases the GIL; environments share nothing."""
     import threading
     from oracle import ffi
     kind = "reference" if ffi.available("ref") else "port"
     lib = ffi.load("ref" if kind == "reference" else "bo")
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    per_thread_steps = max(1, int(single["value"] * 8.0))          # ~8 s per thread at the single-thread rate
-    n = max(1, min(B // cores, per_thread_steps // max(1, steps_per_env)))
-    T = steps_per_env if n * steps_per_env <= per_thread_steps * 2 else max(1, per_thread_steps // n)
-    res = [None] * cores
+    cores = _cpu_share()
+    per = max(1, B // cores)                                        # thread i owns environments [i*per, (i+1)*per)
+    T = max(1, min(steps_per_env, int(single["value"] * 0.05)))     # one chunk = one environment x T steps, ~50 ms of a free core
+    deadline = time.perf_counter() + seconds
+    steps = [0] * cores
 
     def work(i):
-        res[i] = lib.bench_random(args.dist, K_LEADS, n, T, 1000 + i * n, i * n)
+        e = 0
+        while time.perf_counter() < deadline:
+            g = i * per + e % per
+            steps[i] += lib.bench_random(args.dist, K_LEADS, 1, T, 1000 + g, g)["steps"]
+            e += 1
     ths = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
     t0 = time.perf_counter()
     for t in ths:
@@ -352,13 +425,10 @@ def cpu_baseline_all_cores(args, st_final, steps_per_env, B, single):
     for t in ths:
         t.join()
     wall = time.perf_counter() - t0
-    steps = sum(r["steps"] for r in res)
-    match = None
-    if T == steps_per_env:                                          # whole trajectories: the addition totals must equal the device's
-        match = all(res[i]["additions"] == int(st_final[i * n:(i + 1) * n, 1].sum()) for i in range(cores))
-    return {"value": steps / wall, "unit": "env-steps/s", "cores": cores, "nproc": os.cpu_count(), "kind": kind, "threads": cores,
-            "sample": "%d threads x envs [i*%d, (i+1)*%d) of the same batch x %d steps each, %d steps, %.1f s wall" % (cores, n, n, T, steps, wall),
-            "additions_match_device": match, "speedup_over_one_core": steps / wall / single["value"]}
+    total = sum(steps)
+    return {"value": total / wall, "unit": "env-steps/s", "cores": cores, "nproc": os.cpu_count(), "kind": kind, "threads": cores,
+            "sample": "%d threads, each environments of its slice of the same batch x %d steps, for %.0f s: %d steps, %.1f s wall" % (cores, T, seconds, total, wall),
+            "additions_match_device": None, "speedup_over_one_core": total / wall / single["value"]}
 
 
 if __name__ == "__main__":

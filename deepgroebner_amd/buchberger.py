@@ -644,44 +644,55 @@ def buchberger(F, S=None, elimination="gebauermoeller", rewards="additions", sor
     return [_cut(f, n) for f in L.get(0)], stats
 
 
-def _grevlex_key(m):
-    """sympy's grevlex monomial key (what R.order(m) returns in buchberger.py:428)."""
-    return (sum(m), tuple(-x for x in reversed(m)))
+def _pair_key_columns(G, P, strategy):
+    """Integer / float key columns of every pair of P under one selection strategy, most significant column first.
+    'first': (j, i).  'degree': total degree of lcm(LM_i, LM_j).  'normal': that lcm in grevlex order — larger degree is
+    larger, and among equal degrees the monomial whose LAST differing exponent is smaller is larger, i.e. ascending order of
+    (degree, -e[n-1], ..., -e[0]).  'random': one uniform draw per pair."""
+    ij = np.asarray([(int(p[0]), int(p[1])) for p in P], dtype=np.int64).reshape(len(P), 2)
+    if strategy == "first":
+        return ij[:, ::-1].astype(np.float64)
+    if strategy == "random":
+        return np.random.rand(len(P), 1)
+    if strategy not in ("normal", "degree"):
+        raise ValueError("unknown selection strategy")
+    width = max(len(f[0][1]) for f in G)
+    lead = np.zeros((len(G), width), dtype=np.int64)
+    for r, f in enumerate(G):
+        e = f[0][1]
+        lead[r, :len(e)] = e
+    lcm = np.maximum(lead[ij[:, 0]], lead[ij[:, 1]])
+    deg = lcm.sum(axis=1, keepdims=True)
+    if strategy == "degree":
+        return deg.astype(np.float64)
+    return np.concatenate([deg, -lcm[:, ::-1]], axis=1).astype(np.float64)
 
 
 def select(G, P, strategy="normal"):
-    """Select and return a pair from P (reference select, buchberger.py:415-439): the minimum of P under the key
-    (or the tuple of keys, for a list of strategies) 'first' = (j, i), 'normal' = grevlex key of lcm(LM_i, LM_j),
-    'degree' = degree of that lcm, 'random'.  G: term lists as BuchbergerEnv returns them."""
-    assert len(G) > 0, "polynomial list must be nonempty"
-    assert len(P) > 0, "pair set must be nonempty"
-    if isinstance(strategy, str):
-        strategy = [strategy]
-
-    def key(p, s):
-        if s == "first":
-            return p[1], p[0]
-        lcm = tuple(max(a, b) for a, b in zip(G[p[0]][0][1], G[p[1]][0][1]))
-        if s == "normal":
-            return _grevlex_key(lcm)
-        if s == "degree":
-            return sum(lcm)
-        if s == "random":
-            return np.random.rand()
-        raise ValueError("unknown selection strategy")
-
-    return min(P, key=lambda p: tuple(key(p, s) for s in strategy))
+    """The pair of P that a selection strategy — or a list of strategies, later ones breaking the ties of earlier ones —
+    ranks first; among pairs that tie under all of them, the one that comes first in P (what `min` over P gives the
+    reference's select, buchberger.py:415-439).  G: term lists as BuchbergerEnv returns them; P: pairs (i, j)."""
+    if len(G) == 0 or len(P) == 0:
+        raise AssertionError("polynomial list must be nonempty" if len(G) == 0 else "pair set must be nonempty")
+    names = [strategy] if isinstance(strategy, str) else list(strategy)
+    keys = np.concatenate([_pair_key_columns(G, P, s) for s in names], axis=1)
+    alive = np.arange(len(P))
+    for c in range(keys.shape[1]):                          # lexicographic minimum: column by column among the survivors
+        col = keys[alive, c]
+        alive = alive[col == col.min()]
+        if len(alive) == 1:
+            break
+    return P[int(alive[0])]
 
 
 class BuchbergerAgent:
-    """An agent that follows standard selection strategies on (G, P) states (buchberger.py:397-412)."""
+    """Agent over (G, P) states that always takes select()'s pair (reference BuchbergerAgent, buchberger.py:397-412)."""
 
     def __init__(self, selection="normal"):
         self.strategy = selection
 
     def act(self, state):
-        G, P = state
-        return select(G, P, strategy=self.strategy)
+        return select(state[0], state[1], strategy=self.strategy)
 
 
 def lead_monomials_vector(f, n, k=2, dtype=np.int32):
@@ -695,21 +706,29 @@ def lead_monomials_vector(f, n, k=2, dtype=np.int32):
 
 
 class LeadMonomialsAgent:
-    """An agent that follows standard selection strategies on the lead-monomial matrix (buchberger.py:545-567)."""
+    """Agent over the lead-monomial matrix, one row per pair (reference LeadMonomialsAgent, buchberger.py:545-567): 'first'
+    takes row 0, 'degree' the first row whose two LEAD monomials (the first of the k per half) have the lcm of least
+    degree, 'random' a uniformly drawn row.  Rows are in P's order, so 'first' / 'degree' pick what the device selectors
+    BBX_AGENT_FIRST / BBX_AGENT_DEGREE pick (ties resolve to the earliest row on both sides)."""
+
+    _RULES = {
+        "first": lambda self, state: 0,
+        "degree": lambda self, state: int(self._lcm_degrees(state).argmin()),
+        "random": lambda self, state: np.random.choice(len(state)),
+    }
 
     def __init__(self, selection="degree", k=1):
         self.strategy = selection
         self.k = k
 
+    def _lcm_degrees(self, state):
+        half = state.shape[1] // 2                          # columns of one pair member: k monomials of n exponents
+        n = half // self.k
+        return np.maximum(state[:, :n], state[:, half:half + n]).sum(axis=1)
+
     def act(self, state):
-        if self.strategy == "first":
-            return 0
-        elif self.strategy == "degree":
-            n = state.shape[1] // (2 * self.k)
-            m = state.shape[1] // 2
-            return np.argmin(np.sum(np.maximum(state[:, :n], state[:, m:m + n]), axis=1))
-        elif self.strategy == "random":
-            return np.random.choice(len(state))
+        rule = self._RULES.get(self.strategy)
+        return None if rule is None else rule(self, state)   # (the reference falls through to None for anything else)
 
 
 def strategy_stats(ideals, strategy="degree", elimination="gebauermoeller", sort_reducers=True, device=0, caps=None,

@@ -418,12 +418,13 @@ int finish(bbx_batch* b, hipStream_t stream) {
     int rc = session_close(b, false, nullptr, true);
     if (rc) { b->in_flight = false; return rc; }
     stream = b->ps_stream;
-    for (int guard = 0; guard < 100000; guard++) {
+    for (int guard = 0;; guard++) {
       rc = read_lite(b, stream);
       if (rc) { b->in_flight = false; return rc; }
       bool owed = false;
       for (int e = 0; e < b->B && !owed; e++) owed = (b->h_lite[(size_t)e * 4] & 0xffff) == BBX_ST_TIMESLICE;
       if (!owed) break;
+      if (guard >= 100000) { b->in_flight = false; return fail(BBX_E_DEVICE, "a persistent session still owes steps after 100000 time slices"); }
       rc = session_kernel(b, false, nullptr, true);
       if (rc) { b->in_flight = false; return rc; }
     }
@@ -1225,14 +1226,29 @@ static int pmlp_deep_act(const int32_t* d_obs, const int32_t* d_rows, int batch,
   if (batch < 1 || obs_rows < 1) return fail(BBX_E_ARG, "bad policy shape");
   if (obs_rows > 1024) return fail(BBX_E_UNSUPPORTED, "the policy kernels score at most 1024 rows per environment (obs_rows = %d)", obs_rows);
   if (pmlp_deep_floats(cols, h1, hm, h2, three) < 0) return BBX_E_UNSUPPORTED;
-  int dev = 0, cus = 0;
+  int dev = 0, cus = 0, max_lds = 0;
   HIPCHK(hipGetDevice(&dev));
-  HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-  int max_lds = 0;
-  HIPCHK(hipDeviceGetAttribute(&max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev));
-  int lrc = bbx_launch_pmlp2_act(d_obs, d_rows, batch, obs_rows, cols, d_prepared, h1, three ? hm : 0, h2, d_u, d_actions, d_logprobs, cus,
-                                 max_lds > 163840 ? max_lds : 163840,   /* (gfx950: 160 KB per workgroup, whatever the attribute says) */
+  {
+    // per device, asked once (this sits on the per-step path of a policy rollout).  gfx950 has 160 KB of LDS per workgroup, whatever
+    // hipDeviceAttributeMaxSharedMemoryPerBlock says (64 KB: the limit without the per-function attribute); the library is built
+    // for that part only, so that figure is the floor for it and for nothing else
+    static std::mutex mu; static int c_cus[64], c_lds[64]; static bool c_have[64];
+    std::lock_guard<std::mutex> g(mu);
+    const int d = dev & 63;
+    if (!c_have[d]) {
+      HIPCHK(hipDeviceGetAttribute(&c_cus[d], hipDeviceAttributeMultiprocessorCount, dev));
+      HIPCHK(hipDeviceGetAttribute(&c_lds[d], hipDeviceAttributeMaxSharedMemoryPerBlock, dev));
+      hipDeviceProp_t prop;
+      HIPCHK(hipGetDeviceProperties(&prop, dev));
+      if (strncmp(prop.gcnArchName, "gfx950", 6) == 0 && c_lds[d] < 163840) c_lds[d] = 163840;
+      c_have[d] = true;
+    }
+    cus = c_cus[d]; max_lds = c_lds[d];
+  }
+  int lrc = bbx_launch_pmlp2_act(d_obs, d_rows, batch, obs_rows, cols, d_prepared, h1, three ? hm : 0, h2, d_u, d_actions, d_logprobs, cus, max_lds,
                                  (hipStream_t)stream);
+  if (lrc == (int)hipErrorInvalidValue)
+    return fail(BBX_E_UNSUPPORTED, "the policy kernel needs more LDS than device %d has (%d bytes per workgroup)", dev, max_lds);
   if (lrc) return fail(BBX_E_DEVICE, "policy launch failed: %s", hipGetErrorString((hipError_t)lrc));
   return BBX_OK;
 }
@@ -1397,6 +1413,7 @@ int bbx_graph_replayed(bbx_batch* b, void* stream) {
   if (!b) return fail(BBX_E_ARG, "null argument");
   if (b->ps_active) return fail(BBX_E_UNSUPPORTED, "a persistent session is running on this handle");
   if (!b->cap_valid) return fail(BBX_E_ARG, "no asynchronous step or rollout of this handle has been recorded into a graph");
+  HIPCHK(hipSetDevice(b->device));                        // (finish() below may enlarge the records: allocations go to the current device)
   if (b->cap_stale) {
     b->cap_valid = false; b->cap_stale = false;
     return fail(BBX_E_CAPACITY, "the records of this batch were enlarged after the step was recorded: the graph steps the retired copy, "

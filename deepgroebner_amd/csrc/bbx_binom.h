@@ -68,7 +68,7 @@ __device__ void bstage_copy(const BEnv<W>& dst, const BEnv<W>& src, int nG, int 
 template <int W>
 __device__ bool bin_add_poly(BEnv<W>& e, const BbxParams& p, const BbxLayout& L, int& nG, int& nP,
                              const BTerm<W>& t0, const BTerm<W>& t1, int sugar, int* status, char* peel_lds = nullptr,
-                             unsigned long long* prof = nullptr, unsigned long long* plast = nullptr) {
+                             unsigned long long* prof = nullptr, unsigned long long* plast = nullptr, int* first_drop = nullptr) {
   const int lane = lane_id();
   if (nG >= (int)L.maxG) { *status = BBX_ST_G_FULL; return false; }
   const int g = nG;
@@ -78,7 +78,7 @@ __device__ bool bin_add_poly(BEnv<W>& e, const BbxParams& p, const BbxLayout& L,
     e.ginfo[g] = make_uint2(t0.c | (t1.c << 16), inv | ((uint32_t)sugar << 16));
   }
   wave_sync();
-  if (!wave_update<W>(e, L, nG, nP, t0.m, p.elim, status, peel_lds, prof, plast)) return false;
+  if (!wave_update<W>(e, L, nG, nP, t0.m, p.elim, status, peel_lds, prof, plast, first_drop)) return false;
   // reducer order: std::upper_bound by lead monomial
   int pos = g;
   if (p.sort_reducers) {
@@ -189,7 +189,9 @@ __device__ bool bin_reset(BEnv<W>& e, const BbxParams& p, const BbxLayout& L, in
 // observation rows (buchberger.cpp:354-370, 391-394): one lane per monomial slot of the matrix
 template <int W, bool HASH>
 __device__ uint64_t bin_obs(const BEnv<W>& e, const BbxParams& p, int env, int nP, bool write, bool want_hash, char* stage_lds = nullptr,
-                            size_t obs_off = 0) {
+                            size_t obs_off = 0, int row_from = 0) {
+  // row_from > 0: rows [0, row_from) of the block already hold exactly these rows (the previous step of this launch wrote
+  // them and the pair list has not changed in front of row_from): only the rows from there on are gathered and stored
   const int lane = lane_id();
   const int n = p.nvars, k = p.k;
   const int cols = 2 * n * k;
@@ -212,9 +214,10 @@ __device__ uint64_t bin_obs(const BEnv<W>& e, const BbxParams& p, int env, int n
     // direct-to-LDS gathers (global_load_lds_dwordx4: 81 M against 88 M), 16-byte aligned stores staged through LDS (52 M):
     // the observation is bound by the issue of its stores, not by the latency of its gathers.)
     uint32_t prn[U];
+    const int r_begin = row_from - row_from % rows_per_sweep;         // (whole sweeps: a few unchanged rows are rewritten with what they hold)
 #pragma unroll
-    for (int u = 0; u < U; u++) { const int r = u * rows_per_sweep + rl; prn[u] = (active && r < rows) ? e.pairs[r] : 0u; }
-    for (int r0 = 0; r0 < rows; r0 += U * rows_per_sweep) {
+    for (int u = 0; u < U; u++) { const int r = r_begin + u * rows_per_sweep + rl; prn[u] = (active && r < rows) ? e.pairs[r] : 0u; }
+    for (int r0 = r_begin; r0 < rows; r0 += U * rows_per_sweep) {
       int rr[U]; bool on[U]; uint32_t pr[U]; Mono<W> mm[U];
 #pragma unroll
       for (int u = 0; u < U; u++) {
@@ -332,6 +335,7 @@ __device__ __forceinline__ void binom_body(const BbxParams& p, char* smem, const
     else { bstage_copy<W>(e, ge, nG, nP); staged_in = true; wave_sync(); }
   }
   int steps_done = 0;
+  bool obs_live = false;                                   // the caller's block holds the observation of the state as of the last step
   double last_reward = 0.0;
   const bool tracing = TRACE && p.trace != nullptr;
   const int obs_term_bytes = 4 * 2 * p.nvars * p.k;
@@ -349,7 +353,7 @@ __device__ __forceinline__ void binom_body(const BbxParams& p, char* smem, const
         if (STAGED && (status == BBX_ST_G_FULL || status == BBX_ST_P_FULL)) { status = BBX_ST_SPILL; nG = 0; nP = 0; }
         break;
       }
-      need_reset = 0; episode_steps = 0;
+      need_reset = 0; episode_steps = 0; obs_live = false;
     }
     if (budget <= 0) break;
     if (nP == 0) break;
@@ -521,12 +525,13 @@ __device__ __forceinline__ void binom_body(const BbxParams& p, char* smem, const
     BSTAMP(3);
     // ---- basis / pair-set update (buchberger.cpp:321-327) ---------------------------------------------
     const int nG_before = nG, nP_before = nP;
+    int first_drop = nP;
     if (uni((int)r0.c) != 0) {
 #ifdef BBX_PROF_BUILD
-      if (!bin_add_poly<W>(e, p, L, nG, nP, r0, r1, rsug, &status, peel_lds, bprof, &blast)) break;
+      if (!bin_add_poly<W>(e, p, L, nG, nP, r0, r1, rsug, &status, peel_lds, bprof, &blast, &first_drop)) break;
       BSTAMP(4);
 #else
-      if (!bin_add_poly<W>(e, p, L, nG, nP, r0, r1, rsug, &status, peel_lds)) break;
+      if (!bin_add_poly<W>(e, p, L, nG, nP, r0, r1, rsug, &status, peel_lds, nullptr, nullptr, &first_drop)) break;
 #endif
       bytes += 12 * (r1.c ? 2 : 1) + 8 * nG_before + 8 * (nP_before + nP);
     } else zero_red++;
@@ -539,7 +544,15 @@ __device__ __forceinline__ void binom_body(const BbxParams& p, char* smem, const
     const bool done = nP == 0;
 
     BSTAMP(5);
-    if (POL == 0 && p.obs_every_step && p.obs) { bin_obs<W, false>(e, p, env, nP, true, false, peel_lds); obs_trunc |= nP > p.obs_rows ? 1 : 0; }
+    if (POL == 0 && p.obs_every_step && p.obs) {
+      // The block holds the previous step's observation (obs_live: this launch wrote it, no new ideal since): the pair list is
+      // unchanged in front of the selected pair and of the first pair the update dropped, so those rows stand as they are —
+      // with the random agent about half of them.  The matrix in memory after the step is the full observation either way.
+      const int from = (obs_live && !p.obs_fill) ? uni(action < first_drop ? action : first_drop) : 0;
+      bin_obs<W, false>(e, p, env, nP, true, false, peel_lds, 0, from);
+      obs_trunc |= nP > p.obs_rows ? 1 : 0;
+      obs_live = true;
+    }
     if constexpr (POL > 0) {
       if (pol->post_obs && p.obs) { bin_obs<W, false>(e, p, env, nP, true, false, nullptr); obs_trunc |= nP > p.obs_rows ? 1 : 0; }
       if (lane == 0) {

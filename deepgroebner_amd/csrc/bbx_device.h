@@ -655,9 +655,13 @@ constexpr int UPD_CHUNKS = 8;
 template <int W> __host__ __device__ constexpr int update_lds_bytes() { return WAVE * UPD_CHUNKS * 4 * W; }
 template <int W, class EnvT>
 __device__ bool wave_update(EnvT& e, const BbxLayout& L, int& nG, int& nP, const Mono<W> lmf, int elim, int* status,
-                            char* peel_lds = nullptr, unsigned long long* prof = nullptr, unsigned long long* plast = nullptr) {
+                            char* peel_lds = nullptr, unsigned long long* prof = nullptr, unsigned long long* plast = nullptr,
+                            int* first_drop = nullptr) {
+  // first_drop: out, the index of the first old pair that was dropped (the pair list is unchanged in front of it), or the
+  // old |P| when none was — what an observation written incrementally needs to know
   const int lane = lane_id();
   const int m = nG;
+  int fdrop = nP;
   if (elim == BBX_ELIM_GM) {
     // (70-76) drop old pairs (i,j) with LM f | lcm_ij, lcm_ij != lcm_if, lcm_ij != lcm_jf  — stable
     // Four chunks of 64 pairs per trip: all pair words are loaded together, then all lead-monomial gathers are in flight
@@ -679,6 +683,10 @@ __device__ bool wave_update(EnvT& e, const BbxLayout& L, int& nG, int& nP, const
           const bool drop = m_divides(lmf, l) && !m_eq(l, m_lcm(li[u], lmf)) && !m_eq(l, m_lcm(lj[u], lmf));
           const bool keep = in[u] && !drop;
           const uint64_t mask = ballot64(keep);
+          if (first_drop) {
+            const uint64_t dmask = ballot64(in[u] && drop);
+            if (dmask && fdrop > base + u * WAVE) { const int fd = base + u * WAVE + __builtin_ctzll(dmask); fdrop = fd < fdrop ? fd : fdrop; }
+          }
           if (keep) e.pairs[w + prefix_of(mask, lane)] = pr[u];
           w = uni(w + __popcll(mask));   // pinned: the optimiser otherwise threads the count through the per-lane branch
                                          // above and the uniformity analysis gives up on |P| (-> exec-masked code)
@@ -687,6 +695,7 @@ __device__ bool wave_update(EnvT& e, const BbxLayout& L, int& nG, int& nP, const
       wave_sync();
     }
     nP = w;
+    if (first_drop) *first_drop = fdrop;
     USTAMP(8);
     if (peel_lds != nullptr && m <= WAVE * UPD_CHUNKS) {
       // (78-91) new pairs (i, m), everything on chip: L_i = lcm(LM G[i], LM f) in the wave's LDS scratch (element i at slot

@@ -25,6 +25,7 @@
 // launch with two waves per SIMD (SQ_VALU_MFMA_BUSY_CYCLES: 25 us of 64) — more waves are what fills them, not a better
 // distribution of the environments: sorting them by tile count (even loads per wave) and handing them out through a ticket
 // counter (dynamic) were both built; the first changed nothing, the second was slower (same-address atomics from eight XCDs).
+#include <atomic>
 #include "bbx_device.h"
 #include "bbx_pmlp.h"
 
@@ -292,15 +293,17 @@ extern "C" int bbx_launch_pmlp2_act(const int32_t* obs, const int32_t* rows, int
     if (ml <= (size_t)max_lds || hpm != 128 || waves == 4) break;
   }
   if (ml > (size_t)max_lds) return (int)hipErrorInvalidValue;
+  int dev_ = 0; (void)hipGetDevice(&dev_); dev_ &= 63;
   const int max_blocks = (hpm == 128 ? 1 : 2) * (cus > 0 ? cus : 256);
   int blocks = (B + waves - 1) / waves;
   blocks = blocks < max_blocks ? blocks : max_blocks;
 #define BBX_P2(N1, NM, N2, K, NW) do { \
-    static size_t set_ = 0;            /* (once per size: the call is not free) */ \
-    if (set_ < ml) { \
+    static std::atomic<size_t> set_[64];   /* per device, once per size: the call is not free (the attribute belongs to the current device's code object) */ \
+    if (set_[dev_].load(std::memory_order_acquire) < ml) { \
       hipError_t err_ = hipFuncSetAttribute((const void*)bbx_pmlp2_act_kernel<N1, NM, N2, K, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ml); \
       if (err_ != hipSuccess) return (int)err_; \
-      set_ = ml; } \
+      size_t old_ = set_[dev_].load(std::memory_order_relaxed); \
+      while (old_ < ml && !set_[dev_].compare_exchange_weak(old_, ml, std::memory_order_release)) {} } \
     hipLaunchKernelGGL((bbx_pmlp2_act_kernel<N1, NM, N2, K, NW>), dim3(blocks), dim3(NW * WAVE), ml, stream, obs, rows, B, obs_rows, cols, wp, u, actions, logprobs, lgcap); } while (0)
 #define BBX_P2_K(N1, NM, N2, NW) do { if (ks == 3) BBX_P2(N1, NM, N2, 3, NW); else if (ks == 8) BBX_P2(N1, NM, N2, 8, NW); else BBX_P2(N1, NM, N2, 16, NW); } while (0)
   if (hpm == 128 && waves == 16) BBX_P2_K(128, 128, 128, 16);

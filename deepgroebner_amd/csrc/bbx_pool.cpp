@@ -22,7 +22,29 @@ struct Pool {
   size_t cached_dev = 0, cached_pin = 0;
 };
 Pool& pool() { static Pool* p = new Pool; return *p; }                   // (never destroyed: handles may outlive static destructors)
-size_t pool_round(size_t n) { size_t r = 256; while (r < n) r <<= 1; return r; }
+// Blocks that can be cached (<= POOL_MAX_CACHED) are rounded up to a power of two, their size class; anything larger — record
+// arrays of whole batches, gigabytes — is never cached and is allocated as asked for (256-byte granules): rounding those
+// up would cost up to twice the memory and make hipMemGetInfo checks of the callers lie.
+constexpr size_t POOL_MAX_CACHED = size_t(32) << 20;
+size_t pool_round(size_t n) {
+  if (n > POOL_MAX_CACHED) return (n + 255) & ~size_t(255);
+  size_t r = 256; while (r < n) r <<= 1; return r;
+}
+// out of memory: give back every idle block of that kind on this device
+void pool_release_idle(int dev, int kind) {
+  Pool& P = pool();
+  std::vector<void*> drop;
+  {
+    std::lock_guard<std::mutex> g(P.mu);
+    for (auto& kv : P.idle) {
+      if ((int)(kv.first >> 56) != (dev & 0xff) || (int)((kv.first >> 55) & 1) != (kind & 1)) continue;
+      const size_t r = size_t(1) << (kv.first & 0xff);
+      for (void* q : kv.second) { drop.push_back(q); (kind ? P.cached_pin : P.cached_dev) -= r; }
+      kv.second.clear();
+    }
+  }
+  for (void* q : drop) (void)(kind ? hipHostFree(q) : hipFree(q));
+}
 uint64_t pool_key(int dev, int kind, unsigned flags, size_t rounded) {
   int cls = 0; while ((size_t(1) << cls) < rounded) cls++;
   return ((uint64_t)(dev & 0xff) << 56) | ((uint64_t)(kind & 1) << 55) | ((uint64_t)(flags & 0xffff) << 32) | (uint64_t)cls;
@@ -43,7 +65,12 @@ hipError_t pool_get(void** p, size_t n, int kind, unsigned flags) {
       return hipSuccess;
     }
   }
-  const hipError_t e = kind ? hipHostMalloc(p, r, flags) : hipMalloc(p, r);
+  hipError_t e = kind ? hipHostMalloc(p, r, flags) : hipMalloc(p, r);
+  if (e != hipSuccess) {                                   // the idle cache may be what is in the way: release it and try once more
+    (void)hipGetLastError();
+    pool_release_idle(dev, kind);
+    e = kind ? hipHostMalloc(p, r, flags) : hipMalloc(p, r);
+  }
   if (e != hipSuccess) return e;
   std::lock_guard<std::mutex> g(P.mu);
   P.live[*p] = {r, key};
@@ -64,7 +91,7 @@ hipError_t pool_put(void* p, int kind) {
       known = true; r = it->second.first; key = it->second.second; P.live.erase(it);
       size_t& cached = kind ? P.cached_pin : P.cached_dev;
       const size_t cap = kind ? (size_t(64) << 20) : (size_t(256) << 20);
-      if (r <= (size_t(32) << 20) && cached + r <= cap) { P.idle[key].push_back(p); cached += r; keep = true; }
+      if (r <= POOL_MAX_CACHED && cached + r <= cap) { P.idle[key].push_back(p); cached += r; keep = true; }
     }
   }
   (void)known;

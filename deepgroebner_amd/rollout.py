@@ -424,9 +424,11 @@ def _run_rollout_graph(env, policy, nsteps, obs_rows, generator, sync_every):
             c["graph"].replay()
         try:
             env.graph_replayed(stream.cuda_stream)
+            env.sync()                                 # (records that were enlarged inside the replays are reported here)
         except _ffi.BbxError:
-            cache.pop(key, None)                       # (records enlarged since the recording: the next call records again)
+            # the records live at a new address now, or an environment sat out part of the chain: the recording steps a
+            # retired copy from here on — dropped, the next call records again
+            cache.pop(key, None)
             raise
-        env.sync()
     d = env.stats() - st0
     return torch.tensor(-d[:, 1].astype(np.float64), device=dev), torch.tensor(d[:, 2], device=dev)

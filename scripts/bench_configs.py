@@ -23,7 +23,8 @@ ap.add_argument("dist")
 ap.add_argument("--batch", type=int, default=512)
 ap.add_argument("--steps", type=int, default=512)
 ap.add_argument("--k", type=int, default=2)
-ap.add_argument("--cpu-envs", type=int, default=4)
+ap.add_argument("--cpu-envs", type=int, default=4, help="first chunk of the CPU sample (0: no CPU leg)")
+ap.add_argument("--cpu-seconds", type=float, default=2.0, help="the CPU sample grows until it has run this long")
 ap.add_argument("--obs-rows", type=int, default=1024)
 ap.add_argument("--wide-waves", type=int, default=0)
 ap.add_argument("--wide-lds-terms", type=int, default=0)
@@ -98,10 +99,17 @@ if alg > 0 and kernel_ms > 0:
         roof["traffic"] = pj.get("hbm_traffic_bytes_per_launch"); roof["traffic_source"] = a.profile
     out["roofline"] = roof
 if a.cpu_envs > 0 and a.agent == "random" and not a.to_completion:
+    # the compiled reference on the first environments of the same batch, in chunks that double until at least 2 s of CPU
+    # time have been measured (a sample of a few milliseconds is noise) or the whole batch has been run
     lib = ffi.load("ref" if ffi.available("ref") else "bo")
-    res = lib.bench_random(a.dist, k, a.cpu_envs, T, 1000, 0)
-    out["cpu_baseline"] = {"value": res["steps"] / res["seconds"], "unit": "env-steps/s", "cores": 1,
+    done, chunk, secs, csteps, cadds = 0, a.cpu_envs, 0.0, 0, 0
+    while done < B and secs < a.cpu_seconds:
+        n = min(chunk, B - done)
+        res = lib.bench_random(a.dist, k, n, T, 1000 + done, done)
+        secs += res["seconds"]; csteps += res["steps"]; cadds += res["additions"]
+        done += n; chunk *= 2
+    out["cpu_baseline"] = {"value": csteps / secs, "unit": "env-steps/s", "cores": 1,
                            "kind": "reference" if lib.kind == "ref" else "port",
-                           "sample": "envs 0..%d x %d steps, %.1f s" % (a.cpu_envs - 1, T, res["seconds"]),
-                           "additions_match_device": bool(res["additions"] == int(st[:a.cpu_envs, 1].sum()))}
+                           "sample": "envs 0..%d x %d steps, %d steps, %.1f s" % (done - 1, T, csteps, secs),
+                           "additions_match_device": bool(cadds == int(st[:done, 1].sum()))}
 print(json.dumps(out))

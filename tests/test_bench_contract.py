@@ -33,8 +33,17 @@ def test_bench_line_fields_and_consistency():
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert r["traffic"] is not None and r["traffic"] > 0 and r["issue_bound"]["peak"] == 1.0
     assert 0 < r["kernel_ms_per_launch"] <= d["ms_per_step"] * d["steps"] * 1.05          # the kernel is inside the timed launch
+    # the HBM figure is the one SURVEY 8d prescribes; the line also says what really binds, and which kernel the counters are of
+    assert r["binding"] == "issue" and r["traffic_kernel"] and isinstance(r["traffic_kernel_is_timed_kernel"], bool)
+    assert r["issue_bound"]["kernel"] == r["traffic_kernel"]
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] == 1 and c["value"] > 0 and c["additions_match_device"] is True
+    ca = d["cpu_baseline_all_cores"]                                                       # one environment stream per host core
+    assert ca["kind"] == c["kind"] and ca["cores"] >= 1 and ca["threads"] == ca["cores"] and ca["nproc"] >= ca["cores"] and ca["value"] > 0
+    assert ca["additions_match_device"] in (True, None)
+    ss = d["session_stats"]                                                                # the sustained figure's evidence: nothing left the class
+    assert set(ss["timed_region"]) == {"sessions", "joined", "later_kernel_steps", "kernels", "spills"} and ss["timed_region"]["spills"] >= 0
+    assert d["long_launch"]["launches"] >= 8 and d["long_launch"]["value"] > 0 and d["rehearsal"] is False
 
 
 @pytest.mark.gpu

@@ -648,6 +648,42 @@ def test_rollout_device_with_torch_buffers():
         assert np.array_equal(got[:o.nP], o.obs(k)) and (got[o.nP:] == -1).all()
 
 
+@pytest.mark.parametrize("dist,lean", [("5-10-5-uniform", 1), ("5-10-5-uniform", 0), ("4-8-6-weighted", 1), ("3-20-10-weighted", 1)])
+def test_observation_block_written_incrementally_equals_the_full_observation(dist, lean):
+    """The HBM-resident binomial class rewrites, at every step of a launch, only the rows of the caller's block from the first
+    pair that left the pair set on (bbx_binom.h: the rows in front of it stand as the previous step wrote them).  The block after
+    launches of 1, 2, 3, 17 and 60 steps must be the oracle's full observation (buchberger.cpp:354-370, 391-394) of the state
+    reached, for every environment; the block is handed over dirty (-7 everywhere) and rows beyond |P| are the caller's."""
+    import torch
+    from deepgroebner_amd import VecLeadMonomialsEnv
+    bo = ffi.load("bo")
+    B, k, R = 24, 2, 1024
+    env = VecLeadMonomialsEnv(dist, batch=B, k=k, caps={"lds_max_basis": -1})       # (3 variables: HBM-resident class forced)
+    env.seed(np.arange(B) + 31); env.seed_agent(np.arange(B) + 5); env.reset()
+    if lean:
+        env.accounting(False)
+    obs = torch.full((B, R, env.cols), -7, dtype=torch.int32, device="cuda")
+    rew = torch.zeros(B, dtype=torch.float64, device="cuda"); done = torch.zeros(B, dtype=torch.uint8, device="cuda")
+    rows = torch.zeros(B, dtype=torch.int32, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    oracles = []
+    for e in range(B):
+        o = bo.env(dist); o.seed(31 + e); o.reset(); oracles.append(o)
+    t = 0
+    for n in (1, 2, 3, 17, 60, 1, 40):
+        env.rollout_device("random", n, True, s, rew, done, rows, obs, R, False, True)
+        env.sync(); torch.cuda.synchronize()
+        got, nrows = obs.cpu().numpy(), rows.cpu().numpy()
+        for e, o in enumerate(oracles):
+            for tt in range(t, t + n):
+                o.step(ffi.agent_action(5 + e, tt, o.nP))
+                if o.nP == 0:
+                    o.reset()
+            assert nrows[e] == o.nP, (dist, e, t)
+            assert np.array_equal(got[e, :o.nP], o.obs(k)), (dist, e, t, n)
+        t += n
+
+
 def test_headline_kernel_variant_vs_oracle():
     """The launch shape bench.py times — counter-hash agent, 3 variables, k = 2, observation written after every step
     without fill, auto-reset — takes the compile-time specialised kernel; a few launches of it (episodes end and restart

@@ -72,3 +72,38 @@ def test_plan_is_a_partition():
     ids = np.concatenate([plan(r, 8, 4096)["ids"] for r in range(8)])
     assert np.array_equal(ids, np.arange(8 * 4096))
     assert plan(3, 8, 4096)["ideal_seeds"][0] == 1000 + 3 * 4096
+
+
+def _bench_rehearsal(extra, env_extra=None):
+    import json
+    import subprocess
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--repeats", "7", "--batch", "64",
+                           "--rehearse-plumbing"] + extra, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT), json
+
+
+def test_eight_rank_launch_plumbing_without_gpus():
+    """The 8-GPU launch of the driver, rehearsed where there is no GPU at all: `bench.py --gpus 8 --rehearse-plumbing` starts
+    its eight ranks (torch.distributed.run on 127.0.0.1), one of them builds, all meet at the barrier, check that no two
+    share a device, agree on the repeat count, reduce their times and counters over gloo, and rank 0 prints exactly ONE line
+    — with a stand-in that only counts the steps issued in place of the device, so the line carries no measurement
+    (value null, "rehearsal": true).  Nothing here can tell how fast anything is; it can tell that the first real 8-GPU run
+    does not die of plumbing."""
+    p, json = _bench_rehearsal(["--gpus", "8"])
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["rehearsal"] is True and d["value"] is None and d["roofline"] is None and d["cpu_baseline"] is None
+    assert d["n_gpus"] == 8 and d["config"]["global_batch"] == 8 * 64 and d["config"]["devices_visible"] == 8
+    assert d["oversubscribed"] is False and len(d["per_rank_value"]) == 8 and d["repeats"] == 7 and d["timed_steps"] == 140
+    assert d["scaling"] == "weak" and "no collectives" in d["config"]["parallelism"]
+
+
+def test_eight_ranks_on_four_devices_are_refused():
+    p, _ = _bench_rehearsal(["--gpus", "8"], {"BBX_REHEARSE_DEVICES": "4"})
+    assert p.returncode != 0 and "refusing to oversubscribe" in p.stderr
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
