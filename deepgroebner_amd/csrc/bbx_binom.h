@@ -20,6 +20,7 @@ static __device__ unsigned long long bbx_bin_prof_acc[32];
 #endif
 
 template <int W> struct BEnv {
+  static constexpr bool kCached = false;
   BbxHdr* hdr;
   Mono<W>*lm, *tm, *slm, *stm, *lcm;
   uint2 *ginfo, *sinfo;
@@ -38,6 +39,126 @@ template <int W> __device__ __forceinline__ BEnv<W> benv_view(char* rec, const B
 
 // a term with c == 0 is "absent"
 template <int W> struct BTerm { Mono<W> m; uint32_t c; };
+
+// ---- HBM-resident environments with an LDS copy of what is gathered by index (16-byte monomials: 5-10-5-uniform) -------------
+// The arrays the step reads by per-lane index — the pair list, and lm[] / tm[] behind the pair indices: pair filter of the
+// update, Gebauer-Moeller lcms, observation rows — are what a wave waits for at 4 waves per SIMD: every such gather is a
+// trip to L2 / HBM of a microsecond or two.  BEnvC keeps a WRITE-THROUGH copy of their first BC_G / BC_P entries in the wave's
+// LDS: every write goes to the record as before (the record is complete at any moment: hand-over, growth and the end of the
+// launch need nothing), reads of entries below the caps come from LDS.  Monomials are held one byte per slot (8 bytes
+// instead of 16: two arrays of 480 fit beside 512 pairs in the 10 KB a wave can have at 16 environments per CU); a monomial
+// with a slot beyond 255 switches the copy of lm / tm off until the next ideal (cap = 0: everything is read from the
+// record again).  This replaces the peel scratch (wave_update forms the lcms from the copy where it reads them).
+// Measured on one box (5-10-5-uniform, B = 4096 x 2048 steps): 106.6 M env-steps/s without the copy, 109-110 M with it; lm
+// alone as plain 16-byte entries with the observation's gathers from the record: 100 M.
+#define BBX_LDS __attribute__((address_space(3)))
+constexpr int BC_G = 480, BC_P = 512;
+constexpr int BC_BYTES = 2 * BC_G * 8 + BC_P * 4;          // 9728
+typedef unsigned long long bc_u64;
+__device__ __forceinline__ bc_u64 bc_pack(const Mono<4>& m) {  // (slot <= 255 each: the caller has checked)
+  return (bc_u64)__builtin_amdgcn_perm(m.w[1], m.w[0], 0x06040200u) | ((bc_u64)__builtin_amdgcn_perm(m.w[3], m.w[2], 0x06040200u) << 32);
+}
+__device__ __forceinline__ Mono<4> bc_unpack(const bc_u64 p) {
+  const uint32_t x = (uint32_t)p, y = (uint32_t)(p >> 32);
+  Mono<4> m;
+  m.w[0] = __builtin_amdgcn_perm(0u, x, 0x0c010c00u); m.w[1] = __builtin_amdgcn_perm(0u, x, 0x0c030c02u);
+  m.w[2] = __builtin_amdgcn_perm(0u, y, 0x0c010c00u); m.w[3] = __builtin_amdgcn_perm(0u, y, 0x0c030c02u);
+  return m;
+}
+__device__ __forceinline__ bool bc_fits(const Mono<4>& m) { return ((m.w[0] | m.w[1] | m.w[2] | m.w[3]) & 0xff00ff00u) == 0u; }
+// N gathers at once — entry i[u] of array cs[u] / gs[u] (the copy and the record's array: the two views share the caps): all
+// reads of the copy are in flight together, and so are the record's for the lanes whose index lies beyond the copy (one trip
+// to memory for all of them instead of one per read, which is what N separate operator[] calls cost)
+template <int N>
+__device__ __forceinline__ void bc_gather(BBX_LDS bc_u64* const (&cs)[N], Mono<4>* const (&gs)[N], const int (&i)[N], int cap, Mono<4> (&o)[N]) {
+  bc_u64 v[N]; bool far[N]; bool any = false;
+#pragma unroll
+  for (int u = 0; u < N; u++) { far[u] = i[u] >= cap; any |= far[u]; v[u] = cs[u][far[u] ? 0 : i[u]]; }
+  if (ballot64(any)) {
+#pragma unroll
+    for (int u = 0; u < N; u++) { o[u] = m_zero<4>(); if (far[u]) o[u] = m_ld<4>(gs[u] + i[u]); }
+  }
+#pragma unroll
+  for (int u = 0; u < N; u++) if (!far[u]) o[u] = bc_unpack(v[u]);
+}
+struct BCMono {                                            // read view of lm[] / tm[]
+  Mono<4>* g; BBX_LDS bc_u64* c; int cap;
+  __device__ __forceinline__ Mono<4> operator[](int i) const {
+    if (i < cap) return bc_unpack(c[i]);
+    return g[i];
+  }
+  // both members of four pair words (wave_update's filter): eight gathers in flight
+  __device__ __forceinline__ void gather_pairs(const uint32_t (&pr)[4], Mono<4> (&li)[4], Mono<4> (&lj)[4]) const {
+    BBX_LDS bc_u64* const cs[8] = {c, c, c, c, c, c, c, c}; Mono<4>* const gs[8] = {g, g, g, g, g, g, g, g};
+    const int i[8] = {(int)(pr[0] & 0xffffu), (int)(pr[1] & 0xffffu), (int)(pr[2] & 0xffffu), (int)(pr[3] & 0xffffu),
+                      (int)(pr[0] >> 16), (int)(pr[1] >> 16), (int)(pr[2] >> 16), (int)(pr[3] >> 16)};
+    Mono<4> o[8];
+    bc_gather<8>(cs, gs, i, cap, o);
+#pragma unroll
+    for (int u = 0; u < 4; u++) { li[u] = o[u]; lj[u] = o[4 + u]; }
+  }
+};
+struct BCPairs {                                           // read / write view of the pair list
+  uint32_t* g; BBX_LDS uint32_t* c;
+  struct Ref {
+    uint32_t* g; BBX_LDS uint32_t* c; int k;
+    __device__ __forceinline__ operator uint32_t() const { return k < BC_P ? c[k] : g[k]; }
+    __device__ __forceinline__ void operator=(uint32_t v) const { g[k] = v; if (k < BC_P) c[k] = v; }
+  };
+  __device__ __forceinline__ Ref operator[](int k) const { return Ref{g, c, k}; }
+};
+struct BEnvC {
+  static constexpr bool kCached = true;
+  BbxHdr* hdr;
+  BCMono lm, tm;
+  Mono<4>*slm, *stm, *lcm;
+  uint2 *ginfo, *sinfo;
+  BCPairs pairs;
+  uint8_t* cp;
+};
+__device__ __forceinline__ BEnvC benvc_view(char* rec, const BbxLayout& L, char* lds) {
+  BEnvC e;
+  e.hdr = (BbxHdr*)rec;
+  e.lm.g = (Mono<4>*)(rec + L.off_lm); e.tm.g = (Mono<4>*)(rec + L.off_tm);
+  e.lm.c = (BBX_LDS bc_u64*)lds; e.tm.c = (BBX_LDS bc_u64*)(lds + BC_G * 8); e.lm.cap = e.tm.cap = 0;
+  e.slm = (Mono<4>*)(rec + L.off_slm); e.stm = (Mono<4>*)(rec + L.off_stm); e.lcm = (Mono<4>*)(rec + L.off_lcm);
+  e.ginfo = (uint2*)(rec + L.off_ginfo); e.sinfo = (uint2*)(rec + L.off_sinfo);
+  e.pairs.g = (uint32_t*)(rec + L.off_pairs); e.pairs.c = (BBX_LDS uint32_t*)(lds + 2 * BC_G * 8);
+  e.cp = (uint8_t*)(rec + L.off_cp);
+  return e;
+}
+// fill the copy from the record (kernel start)
+__device__ __forceinline__ void benv_load_cache(BEnvC& e, int nG, int nP) {
+  const int lane = lane_id();
+  bool fits = true;
+  const int ng = nG < BC_G ? nG : BC_G;
+  for (int i = lane; i < ng; i += WAVE) {
+    const Mono<4> a = m_ld<4>(e.lm.g + i), b = m_ld<4>(e.tm.g + i);
+    fits = fits && bc_fits(a) && bc_fits(b);
+    e.lm.c[i] = bc_pack(a); e.tm.c[i] = bc_pack(b);
+  }
+  const int np = nP < BC_P ? nP : BC_P;
+  for (int k = lane; k < np; k += WAVE) e.pairs.c[k] = e.pairs.g[k];
+  e.lm.cap = e.tm.cap = ballot64(!fits) ? 0 : BC_G;
+  wave_sync();
+}
+__device__ __forceinline__ void benv_load_cache(BEnv<2>&, int, int) {}
+__device__ __forceinline__ void benv_load_cache(BEnv<4>&, int, int) {}
+__device__ __forceinline__ void benv_load_cache(BEnv<8>&, int, int) {}
+// a new ideal: the copy is empty and valid again
+__device__ __forceinline__ void benv_new_ideal(BEnvC& e) { e.lm.cap = e.tm.cap = BC_G; }
+template <int W> __device__ __forceinline__ void benv_new_ideal(BEnv<W>&) {}
+// G[g] = (lead, tail): the basis-order arrays of the record, and the copy
+__device__ __forceinline__ void benv_put(BEnvC& e, int g, const Mono<4>& lead, const Mono<4>& tail) {
+  if (!(bc_fits(lead) && bc_fits(tail))) e.lm.cap = e.tm.cap = 0;            // (wave-uniform: the terms are)
+  if (lane_id() == 0) {
+    e.lm.g[g] = lead; e.tm.g[g] = tail;
+    if (g < e.lm.cap) { e.lm.c[g] = bc_pack(lead); e.tm.c[g] = bc_pack(tail); }
+  }
+}
+template <int W> __device__ __forceinline__ void benv_put(BEnv<W>& e, int g, const Mono<W>& lead, const Mono<W>& tail) {
+  if (lane_id() == 0) { e.lm[g] = lead; e.tm[g] = tail; }
+}
 
 // (x) + (y) for single optional terms: polynomials.cpp:148-177 restricted to one term per side
 template <int W>
@@ -65,18 +186,16 @@ __device__ void bstage_copy(const BEnv<W>& dst, const BEnv<W>& src, int nG, int 
 }
 
 // append the binomial (t0, t1) as G[nG]: metadata, update(), sorted reducer insert (buchberger.cpp:321-326)
-template <int W>
-__device__ bool bin_add_poly(BEnv<W>& e, const BbxParams& p, const BbxLayout& L, int& nG, int& nP,
+template <int W, class EnvB>
+__device__ __forceinline__ bool bin_add_poly(EnvB& e, const BbxParams& p, const BbxLayout& L, int& nG, int& nP,
                              const BTerm<W>& t0, const BTerm<W>& t1, int sugar, int* status, char* peel_lds = nullptr,
                              unsigned long long* prof = nullptr, unsigned long long* plast = nullptr, int* first_drop = nullptr) {
   const int lane = lane_id();
   if (nG >= (int)L.maxG) { *status = BBX_ST_G_FULL; return false; }
   const int g = nG;
   const uint32_t inv = t0.c == 1 ? 1u : (uint32_t)uni((int)p.inv_table[t0.c]);   // 1/LC (polynomials.cpp:11-23)
-  if (lane == 0) {
-    e.lm[g] = t0.m; e.tm[g] = t1.m;
-    e.ginfo[g] = make_uint2(t0.c | (t1.c << 16), inv | ((uint32_t)sugar << 16));
-  }
+  benv_put(e, g, t0.m, t1.m);
+  if (lane == 0) e.ginfo[g] = make_uint2(t0.c | (t1.c << 16), inv | ((uint32_t)sugar << 16));
   wave_sync();
   if (!wave_update<W>(e, L, nG, nP, t0.m, p.elim, status, peel_lds, prof, plast, first_drop)) return false;
   // reducer order: std::upper_bound by lead monomial
@@ -96,14 +215,14 @@ __device__ bool bin_add_poly(BEnv<W>& e, const BbxParams& p, const BbxLayout& L,
 #pragma unroll
       for (int u = 0; u < UI; u++) {
         const int k = hi - 1 - u * WAVE - lane;
-        si[u] = make_uint2(0, 0);
-        if (k >= pos) { a[u] = e.slm[k]; b[u] = e.stm[k]; si[u] = e.sinfo[k]; }
+        si[u] = make_uint2(0, 0); a[u] = m_zero<W>(); b[u] = m_zero<W>();
+        if (k >= pos) { a[u] = m_ld<W>(e.slm + k); b[u] = m_ld<W>(e.stm + k); si[u] = e.sinfo[k]; }
       }
       wave_sync();
 #pragma unroll
       for (int u = 0; u < UI; u++) {
         const int k = hi - 1 - u * WAVE - lane;
-        if (k >= pos) { e.slm[k + 1] = a[u]; e.stm[k + 1] = b[u]; e.sinfo[k + 1] = si[u]; }
+        if (k >= pos) { m_st<W>(e.slm + k + 1, a[u]); m_st<W>(e.stm + k + 1, b[u]); e.sinfo[k + 1] = si[u]; }
       }
       wave_sync();
     }
@@ -117,9 +236,9 @@ __device__ bool bin_add_poly(BEnv<W>& e, const BbxParams& p, const BbxLayout& L,
   return true;
 }
 
-template <int W>
-__device__ bool bin_reset(BEnv<W>& e, const BbxParams& p, const BbxLayout& L, int env, int& nG, int& nP, int& q_head, int* status,
-                          uint32_t& gen_state, char* peel_lds = nullptr) {
+template <int W, class EnvB>
+__device__ __forceinline__ bool bin_reset_inl(EnvB& e, const BbxParams& p, const BbxLayout& L, int env, int& nG, int& nP, int& q_head, int* status,
+                                              uint32_t& gen_state, char* peel_lds = nullptr) {
   if (p.gen) {                                       // the ideal is drawn here (gen_binomial): no queue, no host
     const int npoly = (int)ldc(p.gen + 2), ncp = (int)ldc(p.gen + 4);
     const uint32_t gflags = ldc(p.gen + 3);
@@ -129,6 +248,7 @@ __device__ bool bin_reset(BEnv<W>& e, const BbxParams& p, const BbxLayout& L, in
     for (;;) {
       const uint32_t x_start = x;
       nG = 0; nP = 0;
+      benv_new_ideal(e);
       // sort_input: all generators are drawn first (lane f keeps generator f), then enter in sorted order
       Mono<W> tabL = m_zero<W>(), tabT = m_zero<W>(); uint32_t tabC = 0; int rank = 0;
       if (p.sort_input) {
@@ -162,6 +282,7 @@ __device__ bool bin_reset(BEnv<W>& e, const BbxParams& p, const BbxLayout& L, in
       slot = p.q.words + (size_t)env * p.q.env_stride + (size_t)(q_head % (int)p.q.nslots) * p.q.slot_words;
     }
     nG = 0; nP = 0;
+    benv_new_ideal(e);
     const int npoly = (int)ldc(slot);               // queue words come in through scalar loads (see ldc)
     const uint32_t* w = slot + 1;
     for (int f = 0; f < npoly; f++) {
@@ -186,9 +307,17 @@ __device__ bool bin_reset(BEnv<W>& e, const BbxParams& p, const BbxLayout& L, in
   }
 }
 
+// out of line where nothing of the caller's has to live in memory for it (plain environments: read-only view); the cached view
+// carries state (its caps) and is inlined, or the view, the kernel parameters and the counters would sit in scratch memory
+template <int W, class EnvB>
+__device__ bool bin_reset(EnvB& e, const BbxParams& p, const BbxLayout& L, int env, int& nG, int& nP, int& q_head, int* status,
+                          uint32_t& gen_state, char* peel_lds = nullptr) {
+  return bin_reset_inl<W>(e, p, L, env, nG, nP, q_head, status, gen_state, peel_lds);
+}
+
 // observation rows (buchberger.cpp:354-370, 391-394): one lane per monomial slot of the matrix
-template <int W, bool HASH>
-__device__ uint64_t bin_obs(const BEnv<W>& e, const BbxParams& p, int env, int nP, bool write, bool want_hash, char* stage_lds = nullptr,
+template <int W, bool HASH, class EnvB>
+__device__ __forceinline__ uint64_t bin_obs(const EnvB& e, const BbxParams& p, int env, int nP, bool write, bool want_hash, char* stage_lds = nullptr,
                             size_t obs_off = 0, int row_from = 0) {
   // row_from > 0: rows [0, row_from) of the block already hold exactly these rows (the previous step of this launch wrote
   // them and the pair list has not changed in front of row_from): only the rows from there on are gathered and stored
@@ -227,11 +356,26 @@ __device__ uint64_t bin_obs(const BEnv<W>& e, const BbxParams& p, int env, int n
       }
 #pragma unroll
       for (int u = 0; u < U; u++) { const int r = rr[u] + U * rows_per_sweep; prn[u] = (active && r < rows) ? e.pairs[r] : 0u; }
+      if constexpr (EnvB::kCached) {
+        // lane -> (lm or tm) is fixed: one gather per sweep from the lane's array (rows beyond |P| and terms beyond the second
+        // read entry 0: never stored)
+        BBX_LDS bc_u64* const cs_ = t == 0 ? e.lm.c : e.tm.c; Mono<4>* const gs_ = t == 0 ? e.lm.g : e.tm.g;
+        BBX_LDS bc_u64* const cs[U] = {cs_, cs_, cs_, cs_}; Mono<4>* const gs[U] = {gs_, gs_, gs_, gs_};
+        int gi_[U];
 #pragma unroll
-      for (int u = 0; u < U; u++) {
-        const int g = half ? (int)(pr[u] >> 16) : (int)(pr[u] & 0xffffu);
-        mm[u] = m_zero<W>();
-        if (on[u]) { if (t == 0) mm[u] = e.lm[g]; else if (t == 1) mm[u] = e.tm[g]; }
+        for (int u = 0; u < U; u++) gi_[u] = (on[u] && t < 2) ? (half ? (int)(pr[u] >> 16) : (int)(pr[u] & 0xffffu)) : 0;
+        bc_gather<U>(cs, gs, gi_, e.lm.cap, mm);
+        if (t >= 2) {
+#pragma unroll
+          for (int u = 0; u < U; u++) mm[u] = m_zero<W>();
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          const int g = half ? (int)(pr[u] >> 16) : (int)(pr[u] & 0xffffu);
+          mm[u] = m_zero<W>();
+          if (on[u]) { if (t == 0) mm[u] = e.lm[g]; else if (t == 1) mm[u] = e.tm[g]; }
+        }
       }
 #pragma unroll
       for (int u = 0; u < U; u++) {
@@ -264,8 +408,8 @@ __device__ uint64_t bin_obs(const BEnv<W>& e, const BbxParams& p, int env, int n
 }
 
 // words of oracle/trace.py poly_words: [nterms, c0, e0[8], c1, e1[8]]
-template <int W>
-__device__ uint64_t bin_poly_hash(const BEnv<W>& e, int g) {
+template <int W, class EnvB>
+__device__ uint64_t bin_poly_hash(const EnvB& e, int g) {
   uint64_t h = 0;
   if (lane_id() == 0) {
     uint2 gi = e.ginfo[g];
@@ -287,7 +431,8 @@ __device__ uint64_t bin_poly_hash(const BEnv<W>& e, int g) {
 // fast_body POL (bbx_fast.h), rows gathered from the record — either as the continuation pass for environments that
 // outgrew the register/LDS-resident class or as the rollout kernel of a batch that is not in that class.  POL = unit
 // blocks of 32 of the hidden layer, PKS = the k-steps of the prepared weights (pmlp_ks_for(2 n k)).
-template <int W, bool STAGED, bool TRACE, int POL = 0, int PKS = 6>
+// AUX: the instantiation without LDS (smem == nullptr).
+template <int W, bool STAGED, bool TRACE, int POL = 0, int PKS = 6, bool AUX = false>
 __device__ __forceinline__ void binom_body(const BbxParams& p, char* smem, const BbxPolicy* pol = nullptr) {
   const int lane = lane_id();
   const int wave_in_block = uni((int)(threadIdx.x / WAVE));
@@ -327,12 +472,19 @@ __device__ __forceinline__ void binom_body(const BbxParams& p, char* smem, const
     return;
   }
 
+  // the HBM-resident instantiation for 16-byte monomials works through an LDS copy of what it gathers by index (BEnvC); the
+  // launcher provides BC_BYTES per wave for it, the Gebauer-Moeller peel scratch (update_lds_bytes) for the others
+  constexpr bool CACHE = W == 4 && !STAGED && POL == 0 && !AUX;
+  typedef typename std::conditional<CACHE, BEnvC, BEnv<W>>::type EnvB;
   BEnv<W> ge = benv_view<W>(grec, p.L);
-  BEnv<W> e = STAGED ? benv_view<W>(smem + (size_t)wave_in_block * L.rec_bytes, L) : ge;
+  EnvB e;
+  if constexpr (CACHE) e = benvc_view(grec, p.L, smem + (size_t)wave_in_block * BC_BYTES);
+  else e = STAGED ? benv_view<W>(smem + (size_t)wave_in_block * L.rec_bytes, L) : ge;
+  if (CACHE && status == BBX_ST_OK) benv_load_cache(e, nG, nP);
   bool staged_in = false;
   if (STAGED && status == BBX_ST_OK) {
     if (nG > (int)L.maxG || nP > (int)L.maxP) status = BBX_ST_SPILL;
-    else { bstage_copy<W>(e, ge, nG, nP); staged_in = true; wave_sync(); }
+    else { if constexpr (STAGED) bstage_copy<W>(e, ge, nG, nP); staged_in = true; wave_sync(); }
   }
   int steps_done = 0;
   bool obs_live = false;                                   // the caller's block holds the observation of the state as of the last step
@@ -340,7 +492,7 @@ __device__ __forceinline__ void binom_body(const BbxParams& p, char* smem, const
   const bool tracing = TRACE && p.trace != nullptr;
   const int obs_term_bytes = 4 * 2 * p.nvars * p.k;
   // HBM-resident instantiation: the launcher provides one Gebauer-Moeller peel scratch per wave in LDS
-  char* const peel_lds = (!STAGED && smem != nullptr) ? smem + (size_t)wave_in_block * update_lds_bytes<W>() : nullptr;
+  char* const peel_lds = (!STAGED && !CACHE && smem != nullptr) ? smem + (size_t)wave_in_block * update_lds_bytes<W>() : nullptr;
 #ifdef BBX_PROF_BUILD
   unsigned long long bprof[32] = {0};
   unsigned long long blast = __builtin_amdgcn_s_memtime();
@@ -349,7 +501,10 @@ __device__ __forceinline__ void binom_body(const BbxParams& p, char* smem, const
   for (;;) {
     if (status != BBX_ST_OK) break;
     if (need_reset) {
-      if (!bin_reset<W>(e, p, L, env, nG, nP, q_head, &status, gen_state, peel_lds)) {
+      bool reset_ok;
+      if constexpr (CACHE) reset_ok = bin_reset_inl<W>(e, p, L, env, nG, nP, q_head, &status, gen_state, peel_lds);
+      else reset_ok = bin_reset<W>(e, p, L, env, nG, nP, q_head, &status, gen_state, peel_lds);
+      if (!reset_ok) {
         if (STAGED && (status == BBX_ST_G_FULL || status == BBX_ST_P_FULL)) { status = BBX_ST_SPILL; nG = 0; nP = 0; }
         break;
       }
@@ -415,11 +570,20 @@ __device__ __forceinline__ void binom_body(const BbxParams& p, char* smem, const
     else if (p.agent == BBX_AGENT_FIRST) action = 0;
     else if (p.agent == BBX_AGENT_LAST) action = nP - 1;
     else if (p.agent == BBX_AGENT_STDRANDOM) action = std_choice(std_rng, nP);
+    else if constexpr (CACHE) action = select_pair_inl<W>(e, nP, p.agent, [&](int g) { return (int)(e.ginfo[g].y >> 16); });
     else action = select_pair<W>(e, nP, p.agent, [&](int g) { return (int)(e.ginfo[g].y >> 16); });
     action = uni(action);
     if (action < 0 || action >= nP) { status = BBX_ST_BAD_ACTION; break; }
     const uint32_t pr = (uint32_t)uni((int)e.pairs[action]);
     const int gi = pr & 0xffffu, gj = pr >> 16;
+    // The reducers' lead monomials do not change during a reduction: the first 64 * SR of them (reducer order) are
+    // loaded ONCE, all loads in flight together, and every round scans registers; larger bases continue in memory.
+    // (Requested here, ahead of the pair removal and the S-polynomial, whose own trips to memory they then overlap.)
+    constexpr int SR = W == 2 ? 8 : (W == 4 ? 6 : 3);
+    Mono<W> S[SR];
+    const int nsr = (nG + WAVE - 1) / WAVE < SR ? (nG + WAVE - 1) / WAVE : SR;
+#pragma unroll
+    for (int u = 0; u < SR; u++) { const int k = u * WAVE + lane; S[u] = (u < nsr && k < nG) ? m_ld<W>(e.slm + k) : m_zero<W>(); }
     for (int base = action; base < nP - 1; base += WAVE * 4) {         // P.erase(remove(action)), stable: four chunks per trip
       uint32_t v[4];
 #pragma unroll
@@ -458,13 +622,6 @@ __device__ __forceinline__ void binom_body(const BbxParams& p, char* smem, const
     r0.c = 0; r1.c = 0; r0.m = m_zero<W>(); r1.m = m_zero<W>();
     int nsteps_red = 0, rsug = 0;
     bool overflow = false;
-    // The reducers' lead monomials do not change during a reduction: the first 64 * SR of them (reducer order) are
-    // loaded ONCE, all loads in flight together, and every round scans registers; larger bases continue in memory.
-    constexpr int SR = W == 2 ? 8 : (W == 4 ? 6 : 3);
-    Mono<W> S[SR];
-    const int nsr = (nG + WAVE - 1) / WAVE < SR ? (nG + WAVE - 1) / WAVE : SR;
-#pragma unroll
-    for (int u = 0; u < SR; u++) { const int k = u * WAVE + lane; S[u] = (u < nsr && k < nG) ? e.slm[k] : m_zero<W>(); }
     while (uni((int)h0.c) != 0) {
       const int hn = h1.c ? 2 : 1;
       int found = -1;
@@ -565,7 +722,7 @@ __device__ __forceinline__ void binom_body(const BbxParams& p, char* smem, const
     BSTAMP(6);
     if (TRACE && tracing) {
       uint64_t oh = bin_obs<W, true>(e, p, env, nP, false, true);
-      uint64_t ph = wave_pairs_hash<W, BEnv<W>>(e, nP);
+      uint64_t ph = wave_pairs_hash<W, EnvB>(e, nP);
       uint64_t nh = nG > nG_before ? bin_poly_hash<W>(e, nG - 1) : 0;
       if (lane == 0) {
         BbxTraceRec& tr = p.trace[(size_t)env * p.trace_stride + rollout_pos];
@@ -592,7 +749,7 @@ __device__ __forceinline__ void binom_body(const BbxParams& p, char* smem, const
   if (POL == 0 && p.obs && status == BBX_ST_OK) { bin_obs<W, false>(e, p, env, nP, true, false, peel_lds); obs_trunc |= nP > p.obs_rows ? 1 : 0; }
   if (STAGED && staged_in) {
     wave_sync();
-    bstage_copy<W>(ge, e, nG, nP);
+    if constexpr (STAGED) bstage_copy<W>(ge, e, nG, nP);
   }
   if (lane == 0) {
     BbxHdr* h = ghdr;
@@ -625,5 +782,5 @@ __global__ __launch_bounds__(256, 4) void bbx_binom_policy_kernel(BbxParams p, B
 }
 template <int W>
 __global__ __launch_bounds__(256) void bbx_binom_aux_kernel(BbxParams p) {
-  binom_body<W, false, false>(p, nullptr);
+  binom_body<W, false, false, 0, 6, true>(p, nullptr);
 }

@@ -16,6 +16,7 @@ static int launch_binom_w(const BbxParams* p, int kind, int blocks, int threads,
     return 0;
   }
     lds = (size_t)(threads / WAVE) * update_lds_bytes<W>();           // Gebauer-Moeller peel scratch, one per wave
+    const size_t lds_plain = W == 4 ? (size_t)(threads / WAVE) * BC_BYTES : lds;   // 16-byte monomials: the LDS copy instead (BEnvC)
     if constexpr (W == 2 || W == 4) {
       if (p->policy && p->policy->rollout) {               // a policy rollout: its continuation pass, or the whole of it
         BbxParams q = *p; q.policy = nullptr; q.actions = nullptr; q.rewards = nullptr; q.dones = nullptr; q.rows = nullptr; q.obs_every_step = 0;
@@ -28,6 +29,7 @@ static int launch_binom_w(const BbxParams* p, int kind, int blocks, int threads,
         return 0;
       }
     }
+    lds = lds_plain;
     if (trace) BBX_LAUNCH((bbx_binom_kernel<W, false, true>)); else BBX_LAUNCH((bbx_binom_kernel<W, false, false>));
   return 0;
 }

@@ -98,6 +98,18 @@ __device__ __forceinline__ uint32_t pk_subsat(uint32_t a, uint32_t b) { return _
 
 template <int W> struct __attribute__((aligned(W * 4))) Mono { uint32_t w[W]; };
 
+// a monomial to / from memory word by word (adjacent words merge into one wide access): a struct assignment between address
+// spaces is a memcpy through a stack slot when it stands under a condition, and the slot then stays in scratch memory
+template <int W> __device__ __forceinline__ Mono<W> m_ld(const Mono<W>* p) {
+  Mono<W> r;
+#pragma unroll
+  for (int i = 0; i < W; i++) r.w[i] = p->w[i];
+  return r;
+}
+template <int W> __device__ __forceinline__ void m_st(Mono<W>* p, const Mono<W>& v) {
+#pragma unroll
+  for (int i = 0; i < W; i++) p->w[i] = v.w[i];
+}
 template <int W> __device__ __forceinline__ uint32_t m_deg(const Mono<W>& a) { return a.w[W - 1] >> 16; }
 template <int W> __device__ __forceinline__ Mono<W> m_zero() { Mono<W> r; for (int i = 0; i < W; i++) r.w[i] = 0; return r; }
 template <int W> __device__ __forceinline__ Mono<W> m_mul(const Mono<W>& a, const Mono<W>& b) {  // cpp:41-47 (degree slot adds too)
@@ -212,6 +224,7 @@ template <int W> __device__ __forceinline__ void obs_store(int32_t* dst, const M
 
 // ------------------------------------------------------------------ environment view
 template <int W> struct Env {
+  static constexpr bool kCached = false;               // (see BEnvC in bbx_binom.h)
   BbxHdr* hdr;
   Mono<W>*lm, *slm, *lcm, *am, *hm;
   uint32_t *poff, *pairs;
@@ -673,8 +686,11 @@ __device__ bool wave_update(EnvT& e, const BbxLayout& L, int& nG, int& nP, const
       uint32_t pr[UF]; Mono<W> li[UF], lj[UF]; bool in[UF];
 #pragma unroll
       for (int u = 0; u < UF; u++) { const int k = base + u * WAVE + lane; in[u] = k < nP; pr[u] = in[u] ? e.pairs[k] : 0u; }
+      if constexpr (EnvT::kCached) e.lm.gather_pairs(pr, li, lj);
+      else {
 #pragma unroll
-      for (int u = 0; u < UF; u++) { li[u] = e.lm[pr[u] & 0xffffu]; lj[u] = e.lm[pr[u] >> 16]; }   // (index 0 for absent lanes)
+        for (int u = 0; u < UF; u++) { li[u] = e.lm[pr[u] & 0xffffu]; lj[u] = e.lm[pr[u] >> 16]; }   // (index 0 for absent lanes)
+      }
       wave_sync();
 #pragma unroll
       for (int u = 0; u < UF; u++) {
@@ -697,11 +713,13 @@ __device__ bool wave_update(EnvT& e, const BbxLayout& L, int& nG, int& nP, const
     nP = w;
     if (first_drop) *first_drop = fdrop;
     USTAMP(8);
-    if (peel_lds != nullptr && m <= WAVE * UPD_CHUNKS) {
+    if ((EnvT::kCached && m <= 32 * WAVE) || (!EnvT::kCached && peel_lds != nullptr && m <= WAVE * UPD_CHUNKS)) {
       // (78-91) new pairs (i, m), everything on chip: L_i = lcm(LM G[i], LM f) in the wave's LDS scratch (element i at slot
       // i: conflict-free 16-byte reads), the candidate / coprime / emit flags one bit per element in three registers
       // (lane l owns elements l, l + 64, ...), a bucket's lcm travels by v_readlane.  The std::map walk keeps exactly the
       // lcms minimal under divisibility among the distinct values; they are peeled by increasing degree (see below).
+      // Environments with an LDS copy of their lead monomials (EnvT::kCached) need no scratch: L_i is formed from the copy
+      // wherever it is read.
       typedef uint32_t bbx_u32xW __attribute__((ext_vector_type(W)));
       __attribute__((address_space(3))) bbx_u32xW* Ll = (__attribute__((address_space(3))) bbx_u32xW*)peel_lds;
       const int nch = (m + WAVE - 1) / WAVE;
@@ -709,18 +727,23 @@ __device__ bool wave_update(EnvT& e, const BbxLayout& L, int& nG, int& nP, const
       for (int u = 0; u < nch; u++) {
         const int i = u * WAVE + lane;
         const bool v = i < m;
-        const Mono<W> li = v ? e.lm[i] : m_zero<W>();
-        const Mono<W> Li = m_lcm(li, lmf);
-        bbx_u32xW pk;
+        const Mono<W> li = v ? (Mono<W>)e.lm[i] : m_zero<W>();
+        if constexpr (!EnvT::kCached) {
+          const Mono<W> Li = m_lcm(li, lmf);
+          bbx_u32xW pk;
 #pragma unroll
-        for (int q = 0; q < W; q++) pk[q] = Li.w[q];
-        Ll[i] = pk;
+          for (int q = 0; q < W; q++) pk[q] = Li.w[q];
+          Ll[i] = pk;
+        }
         candb |= v ? (1u << u) : 0u;
         cpb |= (v && m_coprime(li, lmf)) ? (1u << u) : 0u;
       }
       wave_sync();
       USTAMP(9);
-      auto ldsL = [&](int i) { const bbx_u32xW pk = Ll[i]; Mono<W> r; for (int q = 0; q < W; q++) r.w[q] = pk[q]; return r; };
+      auto ldsL = [&](int i) {
+        if constexpr (EnvT::kCached) return m_lcm((Mono<W>)e.lm[i < m ? i : 0], lmf);
+        else { const bbx_u32xW pk = Ll[i]; Mono<W> r; for (int q = 0; q < W; q++) r.w[q] = pk[q]; return r; }
+      };
       for (;;) {
         uint32_t dm = 0xFFFFFFFFu;
         for (int u = 0; u < nch; u++) { const uint32_t d = m_deg(ldsL(u * WAVE + lane)); dm = ((candb >> u) & 1u) && d < dm ? d : dm; }
@@ -1088,7 +1111,7 @@ template <int W> __device__ __forceinline__ bool sel_less(const SelKey<W>& a, co
   return a.r < b.r;
 }
 template <int W, class EnvT, class SugarFn>
-__device__ int select_pair(const EnvT& e, int nP, int agent, SugarFn sugar_of) {
+__device__ __forceinline__ int select_pair_inl(const EnvT& e, int nP, int agent, SugarFn sugar_of) {
   const bool rev = agent >= BBX_AGENT_LAST;          // pick the maximum
   const bool by_deg = agent == BBX_AGENT_DEGREE || agent == BBX_AGENT_CODEGREE;
   const bool by_sugar = agent == BBX_AGENT_SUGAR || agent == BBX_AGENT_SPICE;
@@ -1119,6 +1142,10 @@ __device__ int select_pair(const EnvT& e, int nP, int agent, SugarFn sugar_of) {
   }
   return (int)best.r;
 }
+// (out of line where the inliner puts it there; environments that carry state in their view — BEnvC — take the inlined form,
+// or the view would have to live in memory for the call)
+template <int W, class EnvT, class SugarFn>
+__device__ int select_pair(const EnvT& e, int nP, int agent, SugarFn sugar_of) { return select_pair_inl<W>(e, nP, agent, sugar_of); }
 // choice(P.begin(), P.end(), rng) with std::default_random_engine (= minstd_rand0, x <- 16807 x mod 2^31-1) and a
 // fresh std::uniform_int_distribution<>(0, n-1) per call (ideals.h:68-73): libstdc++'s downscaling branch, since
 // the engine's range 2^31-3 always exceeds n-1: draw until below n*floor(range/n), then divide.
