@@ -712,7 +712,7 @@ int create_common(std::unique_ptr<bbx::IdealGen> proto, int nvars_obs, int elimi
   if (c.max_basis & 1) c.max_basis += c.max_basis < 65535 ? 1 : -1;
   b->binom = binomial && !c.general_class;
   // long-polynomial environments (fixed ideals such as cyclic-n) in small batches: one workgroup per environment
-  if ((b->fixed || list) && b->W <= 4) b->wide = c.wide_waves > 0 ? std::min(8, c.wide_waves) : (c.wide_waves < 0 ? 0 : (batch <= 4096 ? 8 : 0));
+  if (b->fixed || list) b->wide = c.wide_waves > 0 ? std::min(8, c.wide_waves) : (c.wide_waves < 0 ? 0 : (batch <= 4096 ? 8 : 0));
   if (c.wide_lds_terms < 0 || c.wide_lds_terms > 4096) return fail(BBX_E_ARG, "wide_lds_terms out of range");
   b->wide_terms = c.wide_lds_terms;
   b->no_growth = c.no_growth != 0;
@@ -733,7 +733,7 @@ int create_common(std::unique_ptr<bbx::IdealGen> proto, int nvars_obs, int elimi
   }
   // non-binomial random ideals in <= 7 variables: wave-per-environment kernel, long-polynomial environments continue one
   // workgroup each (bbx_wide.h) behind it
-  b->gen_to_wide = !b->binom && !b->wide && !b->staged && !b->fixed && !list && b->W <= 4 && c.wide_waves >= 0;
+  b->gen_to_wide = !b->binom && !b->wide && !b->staged && !b->fixed && !list && c.wide_waves >= 0;
   if (c.max_basis > 65535 || c.max_poly_terms > (1 << 22) || c.max_basis < 2 || c.max_pairs < 2 || c.max_poly_terms < 4 || c.queue_slots < 1)
     return fail(BBX_E_ARG, "capacities out of range");
   b->L = b->binom ? make_layout_binom(b->W, c.max_basis, c.max_pairs)

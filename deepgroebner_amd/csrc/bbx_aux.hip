@@ -289,7 +289,7 @@ extern "C" int bbx_launch_step(const BbxParams* p, int kind, int envs_per_block,
   const int blocks = (p->B + envs_per_block - 1) / envs_per_block;
   if (kind == 3) { bbx_launch_fast(p, blocks, threads, envs_per_block, stream); return (int)hipGetLastError(); }
   if (kind == 4) {
-    if (p->L.W != 2 && p->L.W != 4) return (int)hipErrorInvalidValue;   // (8-variable rings take the general class)
+    if (p->L.W != 2 && p->L.W != 4 && p->L.W != 8) return (int)hipErrorInvalidValue;
     return bbx_launch_wide(p, envs_per_block, stream);
   }
   const size_t lds = kind == 1 ? (size_t)envs_per_block * p->LL.rec_bytes : 0;

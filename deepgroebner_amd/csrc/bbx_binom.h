@@ -432,8 +432,19 @@ __device__ uint64_t bin_poly_hash(const EnvB& e, int g) {
 // outgrew the register/LDS-resident class or as the rollout kernel of a batch that is not in that class.  POL = unit
 // blocks of 32 of the hidden layer, PKS = the k-steps of the prepared weights (pmlp_ks_for(2 n k)).
 // AUX: the instantiation without LDS (smem == nullptr).
+// Kernel arguments are re-read from the kernarg segment where they are used, through a pointer the optimiser cannot see through
+// (constant address space + uniform address = s_load from the scalar cache): otherwise every field of the by-value struct is
+// loaded at kernel entry and stays live — in scalar registers, of which the step loop has none to spare (~400 of them spilled
+// to vector lanes) — across the whole loop.  The kernels take the BbxParams struct as their FIRST argument: offset 0.
+__device__ __forceinline__ const BbxParams& bbx_kparams() {
+  const __attribute__((address_space(4))) BbxParams* q = (const __attribute__((address_space(4))) BbxParams*)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(q));
+  return *(const BbxParams*)q;
+}
 template <int W, bool STAGED, bool TRACE, int POL = 0, int PKS = 6, bool AUX = false>
-__device__ __forceinline__ void binom_body(const BbxParams& p, char* smem, const BbxPolicy* pol = nullptr) {
+__device__ __forceinline__ void binom_body(const BbxParams& p_entry, char* smem, const BbxPolicy* pol = nullptr) {
+  const BbxParams& p = bbx_kparams();                      // (set-up; the step loop and the write-back behind it take their own)
+  (void)p_entry;
   const int lane = lane_id();
   const int wave_in_block = uni((int)(threadIdx.x / WAVE));
   const int env = blockIdx.x * (blockDim.x / WAVE) + wave_in_block;
@@ -499,6 +510,8 @@ __device__ __forceinline__ void binom_body(const BbxParams& p, char* smem, const
 #endif
 
   for (;;) {
+    const BbxParams& p = bbx_kparams();                    // (per step: nothing of it lives across the loop's back edge)
+    const BbxLayout& L = STAGED ? p.LL : p.L;
     if (status != BBX_ST_OK) break;
     if (need_reset) {
       bool reset_ok;
@@ -745,8 +758,9 @@ __device__ __forceinline__ void binom_body(const BbxParams& p, char* smem, const
 #ifdef BBX_PROF_BUILD
   if (lane == 0) for (int i = 0; i < 32; i++) if (bprof[i]) atomicAdd(&bbx_bin_prof_acc[i], bprof[i]);
 #endif
+  const BbxParams& pz = bbx_kparams();                    // (the write-back)
   const bool handoff = status == BBX_ST_SPILL;
-  if (POL == 0 && p.obs && status == BBX_ST_OK) { bin_obs<W, false>(e, p, env, nP, true, false, peel_lds); obs_trunc |= nP > p.obs_rows ? 1 : 0; }
+  if (POL == 0 && pz.obs && status == BBX_ST_OK) { bin_obs<W, false>(e, pz, env, nP, true, false, peel_lds); obs_trunc |= nP > pz.obs_rows ? 1 : 0; }
   if (STAGED && staged_in) {
     wave_sync();
     if constexpr (STAGED) bstage_copy<W>(ge, e, nG, nP);
@@ -759,13 +773,13 @@ __device__ __forceinline__ void binom_body(const BbxParams& p, char* smem, const
     h->total_additions = total_adds; h->episodes = episodes; h->zero_reductions = zero_red; h->steps_done = steps_done;
     h->budget = budget; h->rollout_pos = rollout_pos; h->done_last = done_last; h->alg_bytes = alg_bytes;
     h->vret = vret; h->vdisc = vdisc; h->obs_trunc = obs_trunc;
-    if (p.sess_target) h->sess_done = p.sess_target - budget;
-    if (p.lite) *(int4*)(p.lite + 4 * (size_t)env) = make_int4(status | (obs_trunc ? BBX_LITE_OBS_TRUNC : 0), q_head, budget, nP);
-    if (p.value_mode && p.values) p.values[env] = vret;
+    if (pz.sess_target) h->sess_done = pz.sess_target - budget;
+    if (pz.lite) *(int4*)(pz.lite + 4 * (size_t)env) = make_int4(status | (obs_trunc ? BBX_LITE_OBS_TRUNC : 0), q_head, budget, nP);
+    if (pz.value_mode && pz.values) pz.values[env] = vret;
     if (!handoff) {
-      if (p.rewards && (steps_done > 0 || p.pass == 0)) p.rewards[env] = last_reward;
-      if (p.dones) p.dones[env] = (uint8_t)((done_last || (nP == 0 && !need_reset)) ? 1 : 0);
-      if (p.rows) p.rows[env] = nP;
+      if (pz.rewards && (steps_done > 0 || pz.pass == 0)) pz.rewards[env] = last_reward;
+      if (pz.dones) pz.dones[env] = (uint8_t)((done_last || (nP == 0 && !need_reset)) ? 1 : 0);
+      if (pz.rows) pz.rows[env] = nP;
     }
   }
 }

@@ -90,7 +90,16 @@ __device__ __forceinline__ Mono<4> wide_unkey(uint64_t k, Mono<4>*) {
   m.w[2] = (hi & 0xffu) | ((hi & 0xff00u) << 8); m.w[3] = ((hi >> 16) & 0xffu) | ((hi >> 8) & 0xff0000u);
   return m;
 }
+// 32-byte monomials (the reference's N = 8, polynomials.h:29) have no 8-byte key: for them the kernel works in its unkeyed
+// regime throughout — the one 16-byte monomials enter when an exponent passes a byte: h as plain monomials in the record's
+// scratch, lead terms fetched one by one, merges on HBM-resident views (tier 3).  The two functions below exist so that the
+// keyed code compiles; wide_keys_ok() keeps every path that would call them closed.
+__device__ __forceinline__ uint64_t wide_key(const Mono<8>&) { return 0; }
+__device__ __forceinline__ Mono<8> wide_unkey(uint64_t, Mono<8>*) { return m_zero<8>(); }
 template <int W> __device__ __forceinline__ Mono<W> wide_unkey(uint64_t k) { return wide_unkey(k, (Mono<W>*)nullptr); }
+// can terms of sugar degree <= hsug be held as keys?  (8-byte monomials are their own key; 16-byte ones pack while every
+// slot fits a byte, and the sugar degree bounds them all)
+template <int W> __device__ __forceinline__ bool wide_keys_ok(int hsug) { return W == 2 || (W == 4 && hsug <= 255); }
 __device__ __forceinline__ bool wk_gt(uint64_t a, uint64_t b) { return a > b; }
 __device__ __forceinline__ bool wk_eq(uint64_t a, uint64_t b) { return a == b; }
 template <int W> __device__ __forceinline__ bool wk_gt(const Mono<W>& a, const Mono<W>& b) { return m_gt(a, b); }
@@ -276,12 +285,22 @@ template <int W> struct WideTable {
   __device__ __forceinline__ Mono<W> mono(int i) const {
     Mono<W> r;
     if constexpr (W == 2) { const bbx_u32x2 v = *(BBX_AS3 bbx_u32x2*)(lm + 2 * i); r.w[0] = v.x; r.w[1] = v.y; }
-    else { const bbx_u32x4 v = *(BBX_AS3 bbx_u32x4*)(lm + 4 * i); r.w[0] = v.x; r.w[1] = v.y; r.w[2] = v.z; r.w[3] = v.w; }
+    else {
+#pragma unroll
+      for (int q = 0; q < W / 4; q++) {
+        const bbx_u32x4 v = *(BBX_AS3 bbx_u32x4*)(lm + W * i + 4 * q); r.w[4 * q] = v.x; r.w[4 * q + 1] = v.y; r.w[4 * q + 2] = v.z; r.w[4 * q + 3] = v.w;
+      }
+    }
     return r;
   }
   __device__ __forceinline__ void put_mono(int i, const Mono<W>& mm) const {
     if constexpr (W == 2) { bbx_u32x2 v; v.x = mm.w[0]; v.y = mm.w[1]; *(BBX_AS3 bbx_u32x2*)(lm + 2 * i) = v; }
-    else { bbx_u32x4 v; v.x = mm.w[0]; v.y = mm.w[1]; v.z = mm.w[2]; v.w = mm.w[3]; *(BBX_AS3 bbx_u32x4*)(lm + 4 * i) = v; }
+    else {
+#pragma unroll
+      for (int q = 0; q < W / 4; q++) {
+        bbx_u32x4 v; v.x = mm.w[4 * q]; v.y = mm.w[4 * q + 1]; v.z = mm.w[4 * q + 2]; v.w = mm.w[4 * q + 3]; *(BBX_AS3 bbx_u32x4*)(lm + W * i + 4 * q) = v;
+      }
+    }
   }
 };
 
@@ -553,7 +572,7 @@ __device__ __forceinline__ void wide_body(char* smem) {
     int as = hoff;
     const int an = hn - as;
     if (bn == 0) return true;
-    const bool keyable = W == 2 || hsug <= 255 || from_s;                     // sugar bounds every degree in h and in x^shift * f
+    const bool keyable = wide_keys_ok<W>(hsug) || (W <= 4 && from_s);          // sugar bounds every degree in h and in x^shift * f
     if (an + bn > 2 * maxT) { status = BBX_ST_POLY_TOO_LONG; return false; }
     int nn = 0;
     if (keyable && an + bn <= HC) {
@@ -685,7 +704,7 @@ __device__ __forceinline__ void wide_body(char* smem) {
       hsug = uni(si > sj ? si : sj);
       if (hsug > 65535) { status = BBX_ST_DEG_OVERFLOW; break; }
       if (na + nb > 2 * maxT || na > maxT) { status = BBX_ST_POLY_TOO_LONG; break; }
-      if ((W == 2 || hsug <= 255) && na <= HC) {
+      if (wide_keys_ok<W>(hsug) && na <= HC) {
         wide_load_scaled<W>(T, e.am + offi + 1, e.ac + offi + 1, na, shi, sci, x);
         in_lds = true; cur = 0;
       } else {
@@ -730,7 +749,7 @@ __device__ __forceinline__ void wide_body(char* smem) {
           if (!hH && !hS) { zero = true; break; }
           uint64_t kH = 0, kS = 0; uint32_t cH = 0, cS = 0;
           Mono<W> mH = m_zero<W>();
-          const bool keyed = in_lds || W == 2 || hsug <= 255;                 // H terms comparable as keys
+          const bool keyed = W <= 4 && (in_lds || wide_keys_ok<W>(hsug));     // H terms comparable as keys
           if (hH) {
             if (in_lds) { const LdsKeys Hc = T.off(cur * HC); kH = Hc.key(hoff); cH = Hc.coef(hoff); }
             else {
@@ -771,7 +790,7 @@ __device__ __forceinline__ void wide_body(char* smem) {
           step_bytes += 8LL * nG + 12LL * (2 * (an + 1) - 1);
           // r grows directly behind the arena's end.  Its terms collect in LDS and go out WRB at a time: a store per
           // term would stall the next barrier's s_waitcnt vmcnt(0) for a round trip to memory
-          if (W == 2 || hsug <= 255) {
+          if (wide_keys_ok<W>(hsug)) {
             if (rn - rflushed == WRB) flush_r();
             if (x.tid == 0) RB.put(rn - rflushed, wide_key(lmh), lch);
           } else {
@@ -791,7 +810,7 @@ __device__ __forceinline__ void wide_body(char* smem) {
           // followed by more; with the accumulator variant's random-agent workloads the extra scan was measured to cost
           // 15 %): while the next terms of h sit in LDS as keys, four of them are tested per scan; the leading irreducible
           // ones move to r together, the first reducible one is left to the next round.
-          while (!LAZY && in_lds && (W == 2 || hsug <= 255) && hn - hoff >= 2 && rn + 4 <= maxT) {
+          while (!LAZY && in_lds && wide_keys_ok<W>(hsug) && hn - hoff >= 2 && rn + 4 <= maxT) {
             const LdsKeys Hc = T.off(cur * HC);
             const int nc = hn - hoff < 4 ? hn - hoff : 4;
             Mono<W> cm[4]; uint64_t ck[4]; uint32_t cc[4];
@@ -849,7 +868,7 @@ __device__ __forceinline__ void wide_body(char* smem) {
       // where the scaled reducer tail goes: into the accumulator while it fits there (and exponents fit a byte), else
       // into H — after the accumulator has been emptied into H (its terms are all byte-sized: they were when they went in)
       // — and only while that saves work: a short H (one merge tile with the tail) is rewritten just as cheaply
-      const bool to_s = LAZY && fn > 0 && fn <= SC && (W == 2 || hsug <= 255) &&
+      const bool to_s = LAZY && fn > 0 && fn <= SC && wide_keys_ok<W>(hsug) &&
                         (sn - soff > 0 || !in_lds || (hn - hoff) + fn > x.NT * WSEG);
       const bool flush_s = LAZY && sn - soff > 0 && (!to_s || (sn - soff) + fn > SC);
       bool ok = true;

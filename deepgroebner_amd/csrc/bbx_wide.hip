@@ -12,6 +12,7 @@ extern "C" int bbx_launch_wide(const BbxParams* p, int nw, hipStream_t stream) {
                           q.agent == BBX_AGENT_LAST || q.agent == BBX_AGENT_CODEGREE || q.agent == BBX_AGENT_STRANGE || q.agent == BBX_AGENT_SPICE;
     bool lazy = !q.accounting && !strategy;
     if (const char* ev = getenv("BBX_WIDE_EAGER")) lazy = !q.accounting && ev[0] == '0';
+    if (W_ == 8) lazy = false;                             // (32-byte monomials have no sort key: the accumulator holds keys)
     const bool acct = q.accounting != 0;
     bool one_per_cu = false;
     if (q.wide_hc > 0) {                                   // forced capacities (tests, experiments): as asked, as far as 160 KB go
@@ -47,7 +48,8 @@ extern "C" int bbx_launch_wide(const BbxParams* p, int nw, hipStream_t stream) {
       hipError_t err_ = hipFuncSetAttribute((const void*)bbx_wide_eager_kernel<WW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl); \
       if (err_ != hipSuccess) return (int)err_; \
       hipLaunchKernelGGL((bbx_wide_eager_kernel<WW>), dim3(p->B), dim3(nw * WAVE), wl, stream, *p); } while (0)
-    if (!tr && one_per_cu && !getenv("BBX_WIDE_NO1CU")) {
+    if (W_ == 8) { if (tr) BBX_WIDE_LAUNCH(8, true, false); else BBX_WIDE_LAUNCH(8, false, false); }   // one variant: tier 3 throughout
+    else if (!tr && one_per_cu && !getenv("BBX_WIDE_NO1CU")) {
       if (W_ == 2) { if (lazy) BBX_WIDE_LAUNCH1(2, true, false); else if (acct) BBX_WIDE_LAUNCH1(2, false, true); else BBX_WIDE_LAUNCH1(2, false, false); }
       else { if (lazy) BBX_WIDE_LAUNCH1(4, true, false); else if (acct) BBX_WIDE_LAUNCH1(4, false, true); else BBX_WIDE_LAUNCH1(4, false, false); }
     } else if (!tr && !lazy && !acct) {
