@@ -432,15 +432,6 @@ __device__ uint64_t bin_poly_hash(const EnvB& e, int g) {
 // outgrew the register/LDS-resident class or as the rollout kernel of a batch that is not in that class.  POL = unit
 // blocks of 32 of the hidden layer, PKS = the k-steps of the prepared weights (pmlp_ks_for(2 n k)).
 // AUX: the instantiation without LDS (smem == nullptr).
-// Kernel arguments are re-read from the kernarg segment where they are used, through a pointer the optimiser cannot see through
-// (constant address space + uniform address = s_load from the scalar cache): otherwise every field of the by-value struct is
-// loaded at kernel entry and stays live — in scalar registers, of which the step loop has none to spare (~400 of them spilled
-// to vector lanes) — across the whole loop.  The kernels take the BbxParams struct as their FIRST argument: offset 0.
-__device__ __forceinline__ const BbxParams& bbx_kparams() {
-  const __attribute__((address_space(4))) BbxParams* q = (const __attribute__((address_space(4))) BbxParams*)__builtin_amdgcn_kernarg_segment_ptr();
-  asm volatile("" : "+s"(q));
-  return *(const BbxParams*)q;
-}
 template <int W, bool STAGED, bool TRACE, int POL = 0, int PKS = 6, bool AUX = false>
 __device__ __forceinline__ void binom_body(const BbxParams& p_entry, char* smem, const BbxPolicy* pol = nullptr) {
   const BbxParams& p = bbx_kparams();                      // (set-up; the step loop and the write-back behind it take their own)

@@ -223,6 +223,15 @@ template <int W> __device__ __forceinline__ void obs_store(int32_t* dst, const M
 }
 
 // ------------------------------------------------------------------ environment view
+// Kernel arguments are re-read from the kernarg segment where they are used, through a pointer the optimiser cannot see through
+// (constant address space + uniform address = s_load from the scalar cache): otherwise every field of the by-value struct is
+// loaded at kernel entry and stays live — in scalar registers, of which the step loop has none to spare (~400 of them spilled
+// to vector lanes) — across the whole loop.  The kernels take the BbxParams struct as their FIRST argument: offset 0.
+__device__ __forceinline__ const BbxParams& bbx_kparams() {
+  const __attribute__((address_space(4))) BbxParams* q = (const __attribute__((address_space(4))) BbxParams*)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(q));
+  return *(const BbxParams*)q;
+}
 template <int W> struct Env {
   static constexpr bool kCached = false;               // (see BEnvC in bbx_binom.h)
   BbxHdr* hdr;
