@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from oracle import ffi
-from oracle.trace import fnv64, poly_words, run_trace
+from oracle.trace import degree_action, fnv64, poly_words, run_trace
 from tests.golden_util import load_trace, meta, trace_names
 
 pytestmark = pytest.mark.gpu
@@ -753,6 +753,69 @@ def test_long_polynomials_cyclic7_all_merge_paths(wide, lds_terms, lean):
         assert max(len(c) for c, _ in basis) > 600                     # long enough to take the cooperative path
         want = _state_words(o.basis(), o.pairs(), o.reducer_order())
         assert np.array_equal(_state_words(basis, pairs, order), want), e
+
+
+@pytest.mark.parametrize("waves", [3, 5, 8])
+@pytest.mark.parametrize("lean", [0, 1])
+def test_wide_class_lockstep_stress(waves, lean):
+    """The wide class keeps the waves of a workgroup in lockstep through hand-placed barriers and parity-buffered exchange
+    slots (bbx_wide.h): a missing barrier or a branch on a value that is not workgroup-uniform shows as a wrong reduction only
+    for particular combinations of workgroup width, LDS capacities (which decide the merge tier of every round) and
+    polynomial lengths.  Sweep: widths 3 / 5 / 8 waves x LDS windows of 40 .. 1000 terms x the random agent (lazy accumulator
+    when lean) and the Degree strategy (eager merges, four-term run scan) on cyclic-6, 150 steps, against the oracle's
+    counters and complete final states."""
+    from deepgroebner_amd import VecLeadMonomialsEnv
+    bo = ffi.load("bo")
+    B, T, k = 2, 150, 1
+    want_hash = bo.run_random_many("cyclic-6", k, [0] * B, range(B), T, True, 0)
+    for lds_terms in (40, 64, 128, 256, 1000):
+        for agent in ("random", "degree"):
+            env = VecLeadMonomialsEnv("cyclic-6", batch=B, k=k, caps={"wide_waves": waves, "wide_lds_terms": lds_terms})
+            env.seed_agent(np.arange(B)); env.reset()
+            if lean:
+                env.accounting(False)
+            env.rollout(agent, T, auto_reset=True)
+            st = env.stats()
+            assert (st[:, 4] == 0).all()
+            if agent == "random":
+                for key, col in (("steps", 0), ("additions", 1), ("episodes", 2), ("zero_reductions", 3), ("nG", 7)):
+                    assert np.array_equal(st[:, col], np.array([r[key] for r in want_hash])), (waves, lds_terms, lean, key)
+                for e in range(B):
+                    assert fnv64(_state_words(*env.state(e))) == want_hash[e]["state_hash"], (waves, lds_terms, lean, e)
+            else:                                       # both environments run the same strategy on the same ideal
+                o = bo.env("cyclic-6"); o.reset()
+                adds = 0
+                for t in range(T):
+                    if o.nP == 0:
+                        o.reset()
+                    adds += int(-o.step(degree_action(o)))
+                assert (st[:, 1] == adds).all() and (st[:, 7] == o.nG).all(), (waves, lds_terms, lean)
+                assert np.array_equal(_state_words(*env.state(0)), _state_words(o.basis(), o.pairs(), o.reducer_order())), (waves, lds_terms, lean)
+            del env
+
+
+def test_wide_class_32_byte_monomials_cyclic8():
+    """cyclic-8 lives in the reference's full N = 8 ring (polynomials.h:29): 32-byte monomials have no 8-byte sort key, so the
+    wide class runs its unkeyed regime throughout (h as plain monomials in the record's scratch, merges on HBM-resident
+    views).  60 steps of the random agent and of the Degree strategy against the oracle, counters and complete states; the
+    wave-per-environment general class (wide_waves = -1) on the same ideal as the cross-check."""
+    from deepgroebner_amd import VecLeadMonomialsEnv
+    bo = ffi.load("bo")
+    B, T, k = 2, 60, 2
+    want = bo.run_random_many("cyclic-8", k, [0] * B, range(B), T, True, 0)
+    for caps in (None, {"wide_waves": 3, "wide_lds_terms": 64}, {"wide_waves": -1}):
+        for lean in (0, 1):
+            env = VecLeadMonomialsEnv("cyclic-8", batch=B, k=k, caps=caps)
+            env.seed_agent(np.arange(B)); env.reset()
+            if lean:
+                env.accounting(False)
+            env.rollout("random", T, auto_reset=True)
+            st = env.stats()
+            assert (st[:, 4] == 0).all()
+            for key, col in (("steps", 0), ("additions", 1), ("zero_reductions", 3), ("nG", 7)):
+                assert np.array_equal(st[:, col], np.array([r[key] for r in want])), (caps, lean, key)
+            for e in range(B):
+                assert fnv64(_state_words(*env.state(e))) == want[e]["state_hash"], (caps, lean, e)
 
 
 def test_strategy_stats_like_make_strat():
