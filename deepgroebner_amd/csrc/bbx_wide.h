@@ -868,7 +868,9 @@ __device__ __forceinline__ void wide_body(char* smem) {
       // where the scaled reducer tail goes: into the accumulator while it fits there (and exponents fit a byte), else
       // into H — after the accumulator has been emptied into H (its terms are all byte-sized: they were when they went in)
       // — and only while that saves work: a short H (one merge tile with the tail) is rewritten just as cheaply
-      const bool to_s = LAZY && fn > 0 && fn <= SC && wide_keys_ok<W>(hsug) &&
+      const bool to_s = LAZY && fn > 0 && fn <= SC && (W == 2 || hsug <= 255) &&   // (written out, not wide_keys_ok: as a call the
+                        // condition lands in other blocks and the lazy kernel spills 152 instead of 60 registers — 18.6 k instead of
+                        // 33.8 k env-steps/s on cyclic-7; 32-byte monomials never run the lazy variant)
                         (sn - soff > 0 || !in_lds || (hn - hoff) + fn > x.NT * WSEG);
       const bool flush_s = LAZY && sn - soff > 0 && (!to_s || (sn - soff) + fn > SC);
       bool ok = true;

@@ -38,7 +38,7 @@ for i in range(1, 5):
                      "us_per_batch_step_under_counters": sum(dur.values()) / steps / 1e3})
     for c, v in acc.items():
         counters[c] = v / steps                            # per batch step (4096 environment steps)
-res = {"round": 3, "kernel": pmc_kern,
+res = {"round": int(tag.lstrip("r") or 0), "kernel": pmc_kern,
        "workload": "bench.py --steps 1024 --warmup 64 --no-persistent: 3-20-10-weighted, 4096 envs, k=2, obs every step, ideals drawn on the device, "
                    "one kernel per launch (counter collection serialises kernels: see scripts/profile_bench.sh)",
        "passes": per_pass, "counters_per_batch_step": counters}

@@ -7,7 +7,7 @@
 # The library is built BEFORE any profiled run (bench.py would otherwise start hipcc / make as children of the profiled
 # process); the program itself stands directly behind `--`.
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?run on the GPU box (gpurun)}"
-tag=${1:-r03}
+tag=${1:-r04}
 python3 -c 'import __graft_entry__ as g; g.build()' || exit 1
 for kw in "20 5" "1024 64"; do
   set -- $kw

@@ -3,7 +3,9 @@
 # (--no-twin: no accounting replay, whose kernel is another instantiation of the same template).
 #   bash scripts/profile_configs.sh r02    -> gpurun_out/cfg_<tag>_*; then python3 scripts/profile_configs_summary.py r02
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?run on the GPU box (gpurun)}"
-tag=${1:-r03}
+tag=${1:-r04}
+part=${2:-all}            # a gpurun call lasts at most 20 minutes: configs | general | policy | all
+want() { [ "$part" = all ] || [ "$part" = "$1" ]; }
 python3 -c 'import __graft_entry__ as g; g.build()' || exit 1     # (never inside a profiled process)
 run() {  # name kernel args...
   name=$1; kern=$2; shift 2
@@ -12,14 +14,20 @@ run() {  # name kernel args...
   # the judged line itself: lean timing + algorithmic bytes from the accounting replay + compiled reference beside it
   timeout -k 10 600 python3 scripts/bench_configs.py "$@" --kernel $kern > gpurun_out/cfg_${tag}_${name}.json 2> gpurun_out/cfg_${tag}_${name}.err || echo "bench line $name failed"
 }
+if want configs; then
 run cyclic7 bbx_wide_kernel cyclic-7 --batch 512 --steps 512
 run u5 bbx_binom_kernel 5-10-5-uniform --batch 4096 --steps 2048 --obs-rows 2048
+fi
+if want general; then
 # the general class on a non-binomial distribution: wave-per-environment kernel (polynomials stay short) ...
 run general bbx_step_kernel 3-5-4-0.5-uniform --batch 4096 --steps 512 --obs-rows 512
 # ... and where polynomials get long (thousands of terms): environments continue one workgroup each in the wide kernel
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/cfg_${tag}_general_long_stats -o s -- python3 scripts/bench_configs.py 5-4-4-1.0-uniform --batch 4096 --steps 64 --obs-rows 1024 --cpu-envs 0 --no-twin > gpurun_out/cfg_${tag}_general_long_stats.log 2>&1 || echo "stats run general_long failed"
 timeout -k 10 900 python3 scripts/bench_configs.py 5-4-4-1.0-uniform --batch 4096 --steps 64 --obs-rows 1024 --cpu-envs 64 --kernel "bbx_step_kernel + bbx_wide_kernel" > gpurun_out/cfg_${tag}_general_long.json 2> gpurun_out/cfg_${tag}_general_long.err || echo "bench line general_long failed"
 timeout -k 10 300 python3 scripts/bench_configs.py cyclic-7 --batch 1 --agent degree --to-completion --obs-rows 4096 --cpu-envs 1 > gpurun_out/cfg_${tag}_cyclic7_single.json 2>/dev/null || echo "cyclic-7 single failed"
+timeout -k 10 200 python3 scripts/bench_long8.py --batch 64 --cpu > gpurun_out/long8_${tag}.json 2>/dev/null || echo "bench_long8 failed"
+fi
+if want policy; then
 # the policy in the loop (scripts/bench_policy.py): kernel-trace stats of the rollout kernel and of the per-step path, and the lines
 for mode in rollout per_step; do
   flag=""; [ $mode = per_step ] && flag="--per-step"
@@ -32,3 +40,4 @@ timeout -k 10 300 python3 scripts/bench_policy.py --per-step --no-persistent > g
 timeout -k 10 300 python3 scripts/bench_value.py > gpurun_out/value_${tag}.json 2>/dev/null || echo "bench_value failed"
 timeout -k 10 300 python3 scripts/bench_gym.py > gpurun_out/gym_${tag}.log 2>&1 || echo "bench_gym failed"
 timeout -k 10 300 python3 scripts/bench_single.py > gpurun_out/single_${tag}.log 2>&1 || echo "bench_single failed"
+fi
