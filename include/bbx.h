@@ -50,8 +50,10 @@ typedef struct bbx_caps {
   int32_t arena_terms;    /* total terms of all basis polynomials */
   int32_t max_poly_terms; /* longest intermediate polynomial during spoly/reduce; basis elements hold <= 65535 terms */
   int32_t queue_slots;    /* pre-generated ideals buffered per environment for device-side resets */
-  int32_t lds_max_basis;  /* |G| up to which a small (3-variable binomial) environment is kept LDS-resident
-                             for a whole launch; 0 = default (128), negative = never */
+  int32_t lds_max_basis;  /* |G| up to which a small (3-variable binomial) environment is kept register/LDS-resident
+                             for a whole launch; 0 = default (256 for the class of the reference's C++ LeadMonomialsEnv —
+                             Gebauer-Moeller, sorted reducers —, its policy kernels and the other eliminations: 128),
+                             negative = never */
   int32_t wide_waves;     /* fixed ideals (long polynomials): waves of the workgroup that serves ONE environment;
                              0 = default (8 when batch <= 4096, else one wave per environment), negative = never */
   int32_t general_class;  /* non-zero: never use the binomial kernel class (term arena + general merges even for
