@@ -370,6 +370,9 @@ class CLeadMonomialsEnv:
         if self._mimic == "cpp":
             elimination, rewards = "gebauermoeller", "additions"
         self._vec = VecLeadMonomialsEnv(ideal_dist, 1, elimination, rewards, sort_input, sort_reducers, k, device, caps, self._mimic)
+        # (no algorithmic-byte counting behind the gym surface — the reference has nothing like it —: the lean kernels, and
+        # with them the resident kernel that serves a loop of step() calls through a host mailbox, bbx_api.cpp mbox_step)
+        self._vec.accounting(False)
 
     def reset(self):
         return self._vec.reset()[0]

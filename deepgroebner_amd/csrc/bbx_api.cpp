@@ -57,7 +57,7 @@ bbx_batch::~bbx_batch() {
                  d_vrecs, d_vhdr, d_vsrc, d_vseeds, d_vvals, d_stage, d_obs_off, d_obs_packed};
   for (void* q : dev) if (q) (void)hipFree(q);
   for (void* q : retired) if (q) (void)hipFree(q);
-  void* pinned[] = {h_io, h_act, h_stage, h_zobs, h_obs};
+  void* pinned[] = {h_io, h_act, h_stage, h_zobs, h_obs, (void*)h_mbox};
   for (void* q : pinned) if (q) (void)hipHostFree(q);
   bbx_host::pool_synced(false);
 }
@@ -408,8 +408,50 @@ int grow_records(bbx_batch* b, unsigned need, int env, hipStream_t stream) {
 // every later call, and environments that only needed service (STARVED / SPILL) have been served before the first
 // error of another environment is returned.
 int session_kernel(bbx_batch* b, bool first, hipStream_t after, bool sliced);
+int ps_write_ctl(bbx_batch* b, bool stop);
+int finish_impl(bbx_batch* b, hipStream_t stream);
 
 int finish(bbx_batch* b, hipStream_t stream) {
+  b->api_epoch++;
+  const bool mbox = b->ps_active && b->ps_mbox;              // (closing a mailbox session switches the pinned outputs on: off again behind it)
+  if (mbox) {
+    // nothing owed (the host waited for every step it issued): tell the waves to go, wait for the kernel, done — no closing kernel
+    bool settled = true;
+    const volatile int32_t* w = (const volatile int32_t*)b->h_io;
+    const uint32_t want = (uint32_t)(b->ps_target % 16000) + 1u;
+    for (int e = 0; e < b->B; e++) { const uint32_t v = (uint32_t)w[(size_t)e * 4]; settled = settled && (v >> 17) == want && (v & 0xffffu) == BBX_ST_OK; }
+    if (settled) {
+      b->ps_active = false;
+      int rc0 = ps_write_ctl(b, true);
+      if (rc0) return rc0;
+      b->ps_mbox = false;
+      // every wave marks its status block when it has stored its environment and left (bbx_fast.h): a spin of a few
+      // microseconds instead of the runtime's wait for the kernel (hundreds, once per episode of a gym loop)
+      bool gone = false;
+      const auto t0 = std::chrono::steady_clock::now();
+      for (unsigned spins = 0; !gone; spins++) {
+        gone = true;
+        for (int e = 0; e < b->B; e++) gone = gone && (w[(size_t)e * 4 + 2] & 0x40000000);
+        if (!gone && (spins & 255) == 255 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+      }
+      std::atomic_thread_fence(std::memory_order_acquire);
+      if (!gone) HIPCHK(hipStreamSynchronize(b->ps_stream));
+      b->last = b->ps_p; b->last.recs = b->d_recs; b->last.L = b->L; b->last.ctl = nullptr; b->last.sess_target = 0; b->last.set_budget = 0;
+      b->last.policy = nullptr; b->last.mbox = 0;
+      b->last_stream = b->ps_stream;
+      b->h_lite.resize((size_t)b->B * 4);
+      memcpy(b->h_lite.data(), b->h_io, (size_t)b->B * 16);
+      for (int e = 0; e < b->B; e++) { b->h_lite[(size_t)e * 4 + 2] &= 0x3fffffff; b->h_head[e] = b->h_lite[(size_t)e * 4 + 1]; }
+      b->in_flight = false; b->async_chain = 0;
+      return BBX_OK;                                        // (every status word said OK: nothing to serve, nothing to report)
+    }
+  }
+  const int rc = finish_impl(b, stream);
+  if (mbox) b->zc_active = false;
+  return rc;
+}
+
+int finish_impl(bbx_batch* b, hipStream_t stream) {
   int err = BBX_OK;
   const int async_chain = b->async_chain;              // (asynchronous external-action steps behind this wait)
   b->async_chain = 0;
@@ -507,6 +549,11 @@ int finish(bbx_batch* b, hipStream_t stream) {
 constexpr uint32_t PS_SLICE_TICKS = 1000000u;            // 10 ms of the 100 MHz clock
 
 int ps_write_ctl(bbx_batch* b, bool stop) {              // all writes to the control word travel on one stream, in order
+  if (b->ps_mbox) {                                        // (a mailbox session's word is in host memory: the host writes it itself)
+    std::atomic_thread_fence(std::memory_order_release);
+    __atomic_store_n(b->h_mbox, (unsigned long long)b->ps_target | (stop ? (1ull << 32) : 0ull), __ATOMIC_RELEASE);
+    return BBX_OK;
+  }
   int lrc = bbx_launch_ctl(b->d_ctl, (unsigned long long)b->ps_target | (stop ? (1ull << 32) : 0ull), b->ps_ctl_stream);
   if (lrc) return fail(BBX_E_DEVICE, "control launch failed: %s", hipGetErrorString((hipError_t)lrc));
   return BBX_OK;
@@ -516,14 +563,17 @@ int ps_write_ctl(bbx_batch* b, bool stop) {              // all writes to the co
 // later one (every environment takes what it still owes of the total), behind the last write to the control word and
 // behind what the caller queued on `after` (or null).  `sliced`: it leaves when its time slice is over.
 int session_kernel(bbx_batch* b, bool first, hipStream_t after, bool sliced) {
-  HIPCHK(hipEventRecord(b->ps_ev, b->ps_ctl_stream));
-  HIPCHK(hipStreamWaitEvent(b->ps_stream, b->ps_ev, 0));
+  if (!b->ps_mbox) {                                       // (a mailbox session's control word is written by the host, not on a stream)
+    HIPCHK(hipEventRecord(b->ps_ev, b->ps_ctl_stream));
+    HIPCHK(hipStreamWaitEvent(b->ps_stream, b->ps_ev, 0));
+  }
   if (after) {
     HIPCHK(hipEventRecord(b->ps_ev, after));
     HIPCHK(hipStreamWaitEvent(b->ps_stream, b->ps_ev, 0));
   }
   BbxParams q = b->ps_p;
-  q.recs = b->d_recs; q.L = b->L; q.ctl = b->d_ctl; q.ctl_stats = b->d_ctl + 8;
+  q.recs = b->d_recs; q.L = b->L; q.ctl = b->ps_mbox ? b->mbox_dev : b->d_ctl; q.ctl_stats = b->d_ctl ? b->d_ctl + 8 : nullptr;
+  q.mbox = b->ps_mbox ? 1 : 0;
   q.nsteps = (int32_t)b->ps_target; q.slice_ticks = sliced ? PS_SLICE_TICKS : 0u;
   q.set_budget = first ? 1 : 0; q.sess_target = first ? 0 : (int32_t)b->ps_target; q.pass = 0;
   b->ps_kernels++;
@@ -547,6 +597,7 @@ int session_close(bbx_batch* b, bool wait, hipStream_t then, bool sliced) {
   b->ps_active = false;
   int rc = ps_write_ctl(b, true);
   if (rc) return rc;
+  const bool was_mbox = b->ps_mbox;
   if (!sliced) {
     // The host will not be there to start the next kernel when a slice ends, and ONE kernel without time limit would keep
     // every environment that leaves the register/LDS class on the HBM-resident pass until the very end (a straggler of
@@ -564,8 +615,9 @@ int session_close(bbx_batch* b, bool wait, hipStream_t then, bool sliced) {
   rc = session_kernel(b, false, nullptr, sliced);
   if (rc) return rc;
   b->last = b->ps_p; b->last.recs = b->d_recs; b->last.L = b->L;   // (a resumed pass continues from the budgets left in the headers)
-  b->last.ctl = nullptr; b->last.sess_target = 0; b->last.set_budget = 0; b->last.policy = nullptr;
+  b->last.ctl = nullptr; b->last.sess_target = 0; b->last.set_budget = 0; b->last.policy = nullptr; b->last.mbox = 0;
   b->last_stream = b->ps_stream;
+  if (was_mbox) { b->ps_mbox = false; b->zc_active = true; }   // (its outputs are in the pinned block: finish() reads them there)
   if (wait) {                                              // (`then` may be the null stream)
     HIPCHK(hipEventRecord(b->ps_ev, b->ps_stream));
     HIPCHK(hipStreamWaitEvent(then, b->ps_ev, 0));
@@ -580,6 +632,7 @@ bool session_same_call(const BbxParams& a, const BbxParams& c) {
 }
 
 int launch(bbx_batch* b, BbxParams& p, hipStream_t stream, bool obs_external = false, bool device_async = false) {
+  b->api_epoch++;
   // a launch recorded into a HIP graph (the caller's stream is capturing) must be a pure function of device state: nothing
   // for the host to upload, no events, no second stream
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
@@ -870,7 +923,7 @@ void bbx_destroy(bbx_batch* b) { delete b; }
 
 int bbx_copy(const bbx_batch* s, bbx_batch** out) {
   if (!s || !out) return fail(BBX_E_ARG, "null argument");
-  HIPCHK(hipSetDevice(s->device));
+  HIPCHK(hipSetDevice(s->device)); const_cast<bbx_batch*>(s)->api_epoch++;
   if (s->ps_active) { int rc_ = session_close(const_cast<bbx_batch*>(s), false, nullptr, false); if (rc_) return rc_; }
   HIPCHK(hipDeviceSynchronize());
   auto b = std::make_unique<bbx_batch>();
@@ -912,7 +965,7 @@ int bbx_copy(const bbx_batch* s, bbx_batch** out) {
 // allocation.  src and dst must not overlap.
 int bbx_clone_envs(bbx_batch* b, int n, const int32_t* src, const int32_t* dst) {
   if (!b || n < 0 || (n && (!src || !dst))) return fail(BBX_E_ARG, "bad arguments");
-  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipSetDevice(b->device)); b->api_epoch++;
   if (b->in_flight) { int rc = finish(b, b->last_stream); if (rc) return rc; }
   {
     std::vector<uint8_t> role((size_t)b->B, 0);          // 1: read, 2: written (a destination may be named once)
@@ -962,7 +1015,7 @@ int bbx_clone_envs(bbx_batch* b, int n, const int32_t* src, const int32_t* dst) 
 int bbx_seed(bbx_batch* b, const int64_t* seeds) {
   if (!b || !seeds) return fail(BBX_E_ARG, "null argument");
   if (b->fixed) return BBX_OK;                 // FixedIdealGenerator::seed is a no-op (ideals.h:94)
-  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipSetDevice(b->device)); b->api_epoch++;
   if (b->device_gen) {
     if (b->in_flight) { int rc = finish(b, b->last_stream); if (rc) return rc; }
     std::vector<long long> s(seeds, seeds + b->B);
@@ -979,7 +1032,8 @@ int bbx_seed(bbx_batch* b, const int64_t* seeds) {
 
 int bbx_seed_agent(bbx_batch* b, const uint32_t* seeds) {
   if (!b || !seeds) return fail(BBX_E_ARG, "null argument");
-  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipSetDevice(b->device)); b->api_epoch++;
+  if (b->in_flight) { int rc_ = finish(b, b->last_stream); if (rc_) return rc_; }   // (the headers are the truth only when nothing is resident)
   // written straight into the headers (field agent_seed), strided copy
   HIPCHK(hipMemcpy2D(b->d_recs + offsetof(BbxHdr, agent_seed), b->L.rec_bytes, seeds, sizeof(uint32_t), sizeof(uint32_t), b->B, hipMemcpyHostToDevice));
   // the agent's step counter restarts with a new seed
@@ -990,7 +1044,7 @@ int bbx_seed_agent(bbx_batch* b, const uint32_t* seeds) {
 
 int bbx_seed_strategy(bbx_batch* b, const int64_t* seeds) {
   if (!b || !seeds) return fail(BBX_E_ARG, "null argument");
-  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipSetDevice(b->device)); b->api_epoch++;
   if (b->in_flight) { int rc = finish(b, b->last_stream); if (rc) return rc; }
   // linear_congruential_engine<uint_fast32_t, 16807, 0, 2^31-1>::seed(s): the int seed converts to the 64-bit
   // unsigned result_type first; x = s mod m, and 0 becomes 1 (libstdc++-11 bits/random.tcc)
@@ -1005,7 +1059,9 @@ int bbx_seed_strategy(bbx_batch* b, const int64_t* seeds) {
 
 int bbx_reset(bbx_batch* b, const uint8_t* mask, int32_t* rows) {
   if (!b) return fail(BBX_E_ARG, "null argument");
-  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipSetDevice(b->device)); b->api_epoch++;
+  // (a session's waves hold their environments in registers: the mark below must meet the records they have stored)
+  if (b->in_flight) { int rc_ = finish(b, b->last_stream); if (rc_) return rc_; }
   if (mask) HIPCHK(hipMemcpy(b->d_mask, mask, (size_t)b->B, hipMemcpyHostToDevice));
   int lrc = bbx_launch_mark_reset(b->d_recs, b->L.rec_bytes, b->B, mask ? b->d_mask : nullptr, 0);
   if (lrc) return fail(BBX_E_DEVICE, "launch failed: %s", hipGetErrorString((hipError_t)lrc));
@@ -1020,10 +1076,113 @@ int bbx_reset(bbx_batch* b, const uint8_t* mask, int32_t* rows) {
   return BBX_OK;
 }
 
+// ---- host mailbox sessions ---------------------------------------------------------------------------------------------
+// A host-driven step of a small batch (the reference's usage: ONE environment stepped from Python, wrapped.pyx:23-26) used
+// to be one kernel launch per step: ~14 us in the library for ~3 us of work.  On the register/LDS-resident class with
+// device-drawn ideals the step calls of a loop feed ONE resident kernel instead (a persistent session, DESIGN.md 4.1.1, whose
+// control word and action buffer are pinned host memory the host writes itself): a step is a store of the actions, a store of
+// the control word, and a spin on the status words the kernel publishes with every step's outputs.  Everything else on
+// the handle closes the session through the usual path (finish): it is never observable except in time.
+static bool mbox_eligible(const bbx_batch* b) {
+  return b->zero_copy && b->fast && b->staged && b->device_gen && !b->accounting && !b->timing && !(b->d_trace && b->trace_cap >= 1) &&
+         b->mbox_misses < 3 && !getenv("BBX_NO_MAILBOX");
+}
+// p: the step's parameters (external agent, zero-copy outputs, nsteps = 1).  Returns BBX_OK with the step taken and its outputs
+// in the pinned block, or an error; *used = false: not taken here (the caller launches as before).
+static int mbox_step(bbx_batch* b, BbxParams& p, bool* used) {
+  *used = false;
+  int rc;
+  const bool join = b->ps_active && b->ps_mbox && session_same_call(b->ps_p, p) && b->ps_target < (1ll << 30);
+  if (!join) {
+    // a session pays when the steps come in a row (a loop); a caller that does something else on the handle between steps
+    // (value() per step, pg.py:461-465) is served by one launch per step as before: four steps in a row start a session
+    b->mbox_streak = (b->api_epoch == b->mbox_epoch + 1) ? b->mbox_streak + 1 : 0;   // (+ 1: this call's own entry)
+    if (b->mbox_streak < 4) return BBX_OK;
+    if (!b->h_mbox) {                                       // (the session's streams exist from the first session on, not before)
+      HIPCHK(hipHostMalloc((void**)&b->h_mbox, 64, hipHostMallocCoherent | hipHostMallocMapped));
+      HIPCHK(hipHostGetDevicePointer((void**)&b->mbox_dev, b->h_mbox, 0));
+      if (!b->ps_stream) {
+        HIPCHK(hipStreamCreateWithFlags(&b->ps_stream, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&b->ps_ctl_stream, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&b->ps_ev, hipEventDisableTiming));
+      }
+    }
+    if (b->in_flight) { rc = finish(b, b->last_stream); if (rc) return rc; }
+    rc = fill_queues(b, 1, nullptr);
+    if (rc) return rc;
+    for (int e = 0; e < b->B; e++) ((volatile int32_t*)b->h_io)[(size_t)e * 4] = 0;
+    p.mbox = 1;
+    b->ps_p = p; b->ps_p.ctl = nullptr; b->ps_p.policy = nullptr;
+    b->ps_mbox = true; b->ps_active = true; b->ps_target = 1; b->ps_sessions++;
+    b->ps_recent.clear();
+    rc = ps_write_ctl(b, false);
+    if (rc) return rc;
+    b->last = p; b->last.ctl = nullptr; b->last.policy = nullptr; b->last.mbox = 0;
+    b->policy_rollout = false; b->last_stream = b->ps_stream; b->in_flight = true; b->obs_external = false; b->device_async = false;
+    rc = session_kernel(b, true, nullptr, true);
+    if (rc) return rc;
+  } else {
+    b->ps_target++;
+    rc = ps_write_ctl(b, false);
+    if (rc) return rc;
+    b->ps_joined++;
+    if (hipStreamQuery(b->ps_stream) == hipSuccess) { rc = session_kernel(b, false, nullptr, true); if (rc) return rc; }   // (slice over, or idle for 20 ms)
+  }
+  // the step's sequence number on every environment's status word — or something else to look at
+  const uint32_t want = (uint32_t)(b->ps_target % 16000) + 1u;
+  const volatile int32_t* w = (const volatile int32_t*)b->h_io;
+  const auto t0 = std::chrono::steady_clock::now();
+  bool all = false, trouble = false, timed_out = false;
+  for (unsigned spins = 0;; spins++) {
+    all = true;
+    for (int e = 0; e < b->B; e++) {
+      const uint32_t v = (uint32_t)w[(size_t)e * 4];
+      if ((v >> 17) != want) all = false;
+      else if ((v & 0xffffu) != BBX_ST_OK || (v & BBX_LITE_OBS_TRUNC)) trouble = true;
+    }
+    if (all || trouble) break;
+    if ((spins & 63) == 63) {
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(3)) { timed_out = true; break; }
+      // the kernel may have left (its slice, 20 ms without news, an environment that needs the host): the next one takes the step
+      if (hipStreamQuery(b->ps_stream) == hipSuccess) {
+        bool seen = true;
+        for (int e = 0; e < b->B; e++) seen = seen && (((uint32_t)w[(size_t)e * 4]) >> 17) == want;
+        if (seen) { all = true; break; }
+        bool stopped = false;                                // an environment that left with something to report ends the mailbox
+        for (int e = 0; e < b->B; e++) { const uint32_t st = (uint32_t)w[(size_t)e * 4] & 0xffffu; stopped = stopped || (st != BBX_ST_OK && st != BBX_ST_TIMESLICE); }
+        if (stopped) break;
+        rc = session_kernel(b, false, nullptr, true);
+        if (rc) return rc;
+      }
+    }
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  *used = true;
+  if (all && !trouble) {
+    b->mbox_misses = 0;
+    b->h_lite.resize((size_t)b->B * 4);
+    memcpy(b->h_lite.data(), b->h_io, (size_t)b->B * 16);
+    return BBX_OK;
+  }
+  // not through the mailbox (an error status, rows beyond the caller's block, an environment that left the class, no answer):
+  // the session closes the usual way — its closing kernels take whatever step is still owed — and reports what there is
+  if (timed_out) b->mbox_misses++;
+  return finish(b, b->ps_stream);
+}
+
 static int step_host(bbx_batch* b, const int32_t* actions, double* rewards, uint8_t* dones, int32_t* rows, int auto_reset) {
   if (!b || !actions) return fail(BBX_E_ARG, "null argument");
-  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipSetDevice(b->device)); b->api_epoch++;
   memcpy(b->h_act, actions, (size_t)b->B * sizeof(int32_t));
+  if (mbox_eligible(b)) {
+    BbxParams p; fill_params(b, &p);
+    p.nsteps = 1; p.set_budget = 1; p.agent = BBX_AGENT_EXTERNAL; p.auto_reset = auto_reset;
+    p.actions = b->zc_act_dev; zc_outputs(b, &p);
+    bool used = false;
+    int rc = mbox_step(b, p, &used);
+    if (rc) return rc;
+    if (used) { b->mbox_epoch = b->api_epoch; return copy_out(b, rewards, dones, rows); }
+  }
   BbxParams p; fill_params(b, &p);
   p.nsteps = 1; p.set_budget = 1; p.agent = BBX_AGENT_EXTERNAL; p.auto_reset = auto_reset;
   if (b->zero_copy) { p.actions = b->zc_act_dev; zc_outputs(b, &p); b->zc_active = true; }
@@ -1035,6 +1194,7 @@ static int step_host(bbx_batch* b, const int32_t* actions, double* rewards, uint
   if (!rc) rc = finish(b, 0);
   b->zc_active = false;
   if (rc) return rc;
+  b->mbox_epoch = b->api_epoch;
   return copy_out(b, rewards, dones, rows);
 }
 
@@ -1059,7 +1219,7 @@ static int ensure_obs_block(bbx_batch* b, int rows_cap) {
 int bbx_step_obs(bbx_batch* b, const int32_t* actions, int auto_reset, double* rewards, uint8_t* dones, int32_t* rows,
                  const int32_t** obs, const int32_t** offsets) {
   if (!b || !obs || !offsets) return fail(BBX_E_ARG, "null argument");
-  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipSetDevice(b->device)); b->api_epoch++;
   const int cols = 2 * b->nvars * b->k;
   const bool zc = b->zero_copy;
   int rc;
@@ -1090,11 +1250,20 @@ int bbx_step_obs(bbx_batch* b, const int32_t* actions, int auto_reset, double* r
     const size_t cap = zc ? b->zobs_rows_cap : b->obs_rows_cap;
     p.obs = zc ? b->zc_obs_dev : b->d_obs; p.obs_rows = (int)cap; p.obs_fill = 0; p.obs_every_step = 0;
     if (attempt) { p.nsteps = 0; p.actions = nullptr; }     // the step is done: only rewrite the observation
-    b->zc_active = zc;
-    rc = launch(b, p, 0);
-    if (!rc) rc = finish(b, 0);
-    b->zc_active = false;
-    if (rc) return rc;
+    bool used = false;
+    if (!attempt && actions && zc && mbox_eligible(b)) {    // a step of a loop: through the resident kernel's mailbox
+      BbxParams q = p;
+      q.obs_every_step = 1;                                 // (the kernel stays: every step writes its observation)
+      rc = mbox_step(b, q, &used);
+      if (rc) return rc;
+    }
+    if (!used) {
+      b->zc_active = zc;
+      rc = launch(b, p, 0);
+      if (!rc) rc = finish(b, 0);
+      b->zc_active = false;
+      if (rc) return rc;
+    }
     if (!attempt) copy_out(b, rewards, dones, rows);
     int maxr = 0; size_t total = 0;
     for (int e = 0; e < b->B; e++) { const int r = b->h_lite[(size_t)e * 4 + 3]; maxr = r > maxr ? r : maxr; total += (size_t)r; }
@@ -1140,13 +1309,14 @@ int bbx_step_obs(bbx_batch* b, const int32_t* actions, int auto_reset, double* r
       HIPCHK(hipStreamSynchronize(0));
     }
     *offsets = b->h_obs; *obs = b->h_obs + b->B + 1;
+    if (actions) b->mbox_epoch = b->api_epoch;              // (a step: the next one in a row counts towards a mailbox session)
     return BBX_OK;
   }
 }
 
 int bbx_rollout(bbx_batch* b, int agent, int nsteps, int auto_reset, double* rewards, uint8_t* dones, int32_t* rows) {
   if (!b || nsteps < 0 || agent < BBX_RANDOM_HASH || agent > BBX_RANDOM_STD) return fail(BBX_E_ARG, "bad rollout arguments");
-  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipSetDevice(b->device)); b->api_epoch++;
   if (b->d_trace && nsteps > b->trace_cap) return fail(BBX_E_ARG, "rollout of %d steps exceeds the trace capacity %d", nsteps, b->trace_cap);
   BbxParams p; fill_params(b, &p);
   p.nsteps = nsteps; p.set_budget = 1; p.agent = agent; p.auto_reset = auto_reset ? 1 : 0;
@@ -1161,7 +1331,7 @@ int bbx_rollout(bbx_batch* b, int agent, int nsteps, int auto_reset, double* rew
 static int step_device(bbx_batch* b, const int32_t* d_actions, double* d_rewards, uint8_t* d_dones, int32_t* d_rows,
                        int32_t* d_obs, int obs_rows, int obs_fill, void* stream, int auto_reset) {
   if (!b || !d_actions) return fail(BBX_E_ARG, "null argument");
-  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipSetDevice(b->device)); b->api_epoch++;
   if (d_obs && obs_rows < 1) return fail(BBX_E_ARG, "obs_rows must be positive");
   BbxParams p; fill_params(b, &p);
   p.nsteps = 1; p.set_budget = 1; p.agent = BBX_AGENT_EXTERNAL; p.auto_reset = auto_reset; p.actions = d_actions;
@@ -1290,7 +1460,7 @@ int bbx_policy_step_device(bbx_batch* b, const float* d_prepared, int hidden, co
   if (!b || !d_prepared || !d_u || !d_actions || !d_logprobs || !d_rows || !d_obs) return fail(BBX_E_ARG, "null argument");
   if (obs_rows < 1) return fail(BBX_E_ARG, "obs_rows must be positive");
   if (obs_rows > 1024) return fail(BBX_E_UNSUPPORTED, "the policy kernels score at most 1024 rows per environment (obs_rows = %d)", obs_rows);
-  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipSetDevice(b->device)); b->api_epoch++;
   const int cols = 2 * b->nvars * b->k;
   if (bbx_pmlp_prepared_floats(cols, hidden) < 0) return BBX_E_UNSUPPORTED;
   // one launch for policy + step where the step kernel has the policy built in (the register/LDS-resident class, lean
@@ -1302,7 +1472,7 @@ int bbx_policy_step_device(bbx_batch* b, const float* d_prepared, int hidden, co
     if (rc) return rc;
     return step_device(b, d_actions, d_rewards, d_dones, d_rows, d_obs, obs_rows, obs_fill, stream, 1);
   }
-  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipSetDevice(b->device)); b->api_epoch++;
   if (b->ps_enabled && b->nvars == 3 && b->k == 2 && b->device_gen) {
     // persistent sessions: the call joins (or begins) a session whose kernel has the policy inside its step loop — the
     // uniforms of consecutive calls must then be consecutive [B] slices of one array (what a rollout loop that draws its
@@ -1340,7 +1510,7 @@ int bbx_policy_rollout_device(bbx_batch* b, const float* d_prepared, int hidden,
   if (b->accounting) return fail(BBX_E_UNSUPPORTED, "policy rollouts run the lean kernel: call bbx_accounting(b, 0) first");
   if (b->d_trace && b->trace_cap >= 1) return fail(BBX_E_UNSUPPORTED, "policy rollouts are not traced");
   if (d_obs && obs_step_stride != 0 && obs_step_stride < (long long)b->B * obs_rows * cols) return fail(BBX_E_ARG, "obs_step_stride smaller than one block");
-  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipSetDevice(b->device)); b->api_epoch++;
   BbxPolicy pol{d_prepared, hidden, d_u, d_actions, d_logprobs, 1, d_rewards, d_dones, d_rows, obs_step_stride, b->B, 0};
   BbxParams p; fill_params(b, &p);
   p.nsteps = nsteps; p.set_budget = 1; p.agent = BBX_AGENT_EXTERNAL; p.auto_reset = 1;
@@ -1356,7 +1526,7 @@ int bbx_policy_rollout_device(bbx_batch* b, const float* d_prepared, int hidden,
 int bbx_rollout_device(bbx_batch* b, int agent, int nsteps, int auto_reset, double* d_rewards, uint8_t* d_dones,
                        int32_t* d_rows, int32_t* d_obs, int obs_rows, int obs_fill, int obs_every_step, void* stream) {
   if (!b || nsteps < 0 || agent < BBX_RANDOM_HASH || agent > BBX_RANDOM_STD) return fail(BBX_E_ARG, "bad rollout arguments");
-  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipSetDevice(b->device)); b->api_epoch++;
   if (b->d_trace && nsteps > b->trace_cap) return fail(BBX_E_ARG, "rollout of %d steps exceeds the trace capacity %d", nsteps, b->trace_cap);
   if (d_obs && obs_rows < 1) return fail(BBX_E_ARG, "obs_rows must be positive");
   BbxParams p; fill_params(b, &p);
@@ -1368,14 +1538,14 @@ int bbx_rollout_device(bbx_batch* b, int agent, int nsteps, int auto_reset, doub
 
 int bbx_sync(bbx_batch* b) {
   if (!b) return fail(BBX_E_ARG, "null argument");
-  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipSetDevice(b->device)); b->api_epoch++;
   if (!b->in_flight) { HIPCHK(hipDeviceSynchronize()); return BBX_OK; }
   return finish(b, b->last_stream);
 }
 
 int bbx_persistent(bbx_batch* b, int enable) {
   if (!b) return fail(BBX_E_ARG, "null argument");
-  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipSetDevice(b->device)); b->api_epoch++;
   if (b->in_flight) { int rc = finish(b, b->last_stream); if (rc) return rc; }
   if (enable && !b->d_ctl) {
     HIPCHK(hipMalloc((void**)&b->d_ctl, 65536));          // (word 0: control, word 8: statistics; the rest: scripts/patches)
@@ -1391,7 +1561,7 @@ int bbx_persistent(bbx_batch* b, int enable) {
 
 int bbx_session_stats(bbx_batch* b, int64_t* out5) {   // out: 5 values
   if (!b || !out5) return fail(BBX_E_ARG, "null argument");
-  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipSetDevice(b->device)); b->api_epoch++;
   out5[0] = b->ps_sessions; out5[1] = b->ps_joined; out5[2] = 0; out5[3] = b->ps_kernels; out5[4] = 0;
   if (b->d_ctl) {
     if (b->in_flight) { int rc = finish(b, b->last_stream); if (rc) return rc; }
@@ -1404,7 +1574,7 @@ int bbx_session_stats(bbx_batch* b, int64_t* out5) {   // out: 5 values
 
 int bbx_join(bbx_batch* b, void* stream) {
   if (!b) return fail(BBX_E_ARG, "null argument");
-  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipSetDevice(b->device)); b->api_epoch++;
   if (!b->ps_active) return BBX_OK;
   return session_close(b, true, (hipStream_t)stream, false);
 }
@@ -1434,7 +1604,7 @@ int bbx_accounting(bbx_batch* b, int enable) {
 
 int bbx_prefetch(bbx_batch* b) {
   if (!b) return fail(BBX_E_ARG, "null argument");
-  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipSetDevice(b->device)); b->api_epoch++;
   if (b->in_flight) { int rc = finish(b, b->last_stream); if (rc) return rc; }
   else { int rc = read_headers(b); if (rc) return rc; }
   return fill_queues(b, (int)b->nslots);
@@ -1451,7 +1621,7 @@ int bbx_timing(bbx_batch* b, int enable, double* kernel_ms, int32_t* launches) {
 
 int bbx_obs(bbx_batch* b, int32_t* out, int max_rows, int fill) {
   if (!b || !out || max_rows < 1) return fail(BBX_E_ARG, "bad arguments");
-  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipSetDevice(b->device)); b->api_epoch++;
   const size_t cols = (size_t)2 * b->nvars * b->k;
   const size_t need = (size_t)b->B * max_rows * cols;
   if (b->obs_rows_cap < (size_t)max_rows) {

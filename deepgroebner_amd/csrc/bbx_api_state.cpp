@@ -13,7 +13,7 @@ extern "C" {
 int bbx_stats(bbx_batch* b, int64_t* out8) {
   int64_t* out6 = out8;
   if (!b || !out6) return fail(BBX_E_ARG, "null argument");
-  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipSetDevice(b->device)); b->api_epoch++;
   if (b->ps_active) { int rc_ = session_close(b, false, nullptr, false); if (rc_) return rc_; }
   HIPCHK(hipDeviceSynchronize());
   int rc = read_headers(b);
@@ -30,7 +30,7 @@ int bbx_stats(bbx_batch* b, int64_t* out8) {
 // (bbx_alg.cpp) where the records of a quiet batch live
 int bbx_internal_records(bbx_batch* b, const char** recs, BbxLayout* L, int* device, int* W, int* batch) {
   if (!b) return fail(BBX_E_ARG, "null argument");
-  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipSetDevice(b->device)); b->api_epoch++;
   if (b->in_flight) { int rc = finish(b, b->last_stream); if (rc) return rc; }
   HIPCHK(hipDeviceSynchronize());
   *recs = b->d_recs; *L = b->L; *device = b->device; *W = b->W; *batch = b->B;
@@ -45,7 +45,7 @@ int bbx_capacities(bbx_batch* b, int32_t* out5) {
 
 int bbx_env_status(bbx_batch* b, int32_t* status) {
   if (!b || !status) return fail(BBX_E_ARG, "null argument");
-  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipSetDevice(b->device)); b->api_epoch++;
   if (b->ps_active) { int rc_ = session_close(b, false, nullptr, false); if (rc_) return rc_; }
   HIPCHK(hipDeviceSynchronize());
   int rc = read_headers(b);
@@ -56,7 +56,7 @@ int bbx_env_status(bbx_batch* b, int32_t* status) {
 
 int bbx_state_sizes(bbx_batch* b, int idx, int32_t* basis_size, int32_t* npairs, int32_t* nterms_total) {
   if (!b || idx < 0 || idx >= b->B) return fail(BBX_E_ARG, "bad environment index");
-  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipSetDevice(b->device)); b->api_epoch++;
   if (b->ps_active) { int rc_ = session_close(b, false, nullptr, false); if (rc_) return rc_; }
   HIPCHK(hipDeviceSynchronize());
   BbxHdr h;
@@ -69,7 +69,7 @@ int bbx_state_sizes(bbx_batch* b, int idx, int32_t* basis_size, int32_t* npairs,
 
 int bbx_state_get(bbx_batch* b, int idx, int32_t* nterms, int32_t* coefs, int32_t* exps, int32_t* pairs, int32_t* order) {
   if (!b || idx < 0 || idx >= b->B) return fail(BBX_E_ARG, "bad environment index");
-  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipSetDevice(b->device)); b->api_epoch++;
   if (b->ps_active) { int rc_ = session_close(b, false, nullptr, false); if (rc_) return rc_; }
   HIPCHK(hipDeviceSynchronize());
   const char* rec = b->d_recs + (size_t)idx * b->L.rec_bytes;
@@ -163,7 +163,7 @@ int bbx_reduced_basis(bbx_batch* b, int idx, int32_t* basis_size, int32_t* nterm
 
 int bbx_trace_enable(bbx_batch* b, int capacity_steps) {
   if (!b || capacity_steps < 0) return fail(BBX_E_ARG, "bad arguments");
-  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipSetDevice(b->device)); b->api_epoch++;
   HIPCHK(hipDeviceSynchronize());
   if (b->d_trace) { HIPCHK(hipFree(b->d_trace)); b->d_trace = nullptr; }
   b->trace_cap = capacity_steps;
@@ -178,7 +178,7 @@ int bbx_trace_read(bbx_batch* b, int env, int first, int count, bbx_trace_rec* o
   if (!b || !out || !b->d_trace || env < 0 || env >= b->B || first < 0 || count < 0 || first + count > b->trace_cap)
     return fail(BBX_E_ARG, "bad trace range");
   static_assert(sizeof(bbx_trace_rec) == sizeof(BbxTraceRec), "trace record layouts must match");
-  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipSetDevice(b->device)); b->api_epoch++;
   HIPCHK(hipMemcpy(out, b->d_trace + (size_t)env * b->trace_cap + first, (size_t)count * sizeof(BbxTraceRec), hipMemcpyDeviceToHost));
   return BBX_OK;
 }

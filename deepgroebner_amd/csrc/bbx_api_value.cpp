@@ -122,13 +122,13 @@ int values_for(bbx_batch* b, const std::vector<int32_t>& envs, const char* strat
 
 extern "C" int bbx_value(bbx_batch* b, int idx, const char* strategy, double gamma, double* out) {
   if (!b || !strategy || !out || idx < 0 || idx >= b->B) return fail(BBX_E_ARG, "bad arguments");
-  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipSetDevice(b->device)); b->api_epoch++;
   return values_for(b, std::vector<int32_t>{idx}, strategy, gamma, nullptr, out);
 }
 
 extern "C" int bbx_values_seeded(bbx_batch* b, const char* strategy, double gamma, const int64_t* seeds, double* out) {
   if (!b || !strategy || !out) return fail(BBX_E_ARG, "bad arguments");
-  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipSetDevice(b->device)); b->api_epoch++;
   std::vector<int32_t> envs(b->B);
   for (int e = 0; e < b->B; e++) envs[e] = e;
   return values_for(b, envs, strategy, gamma, seeds, out);
@@ -136,7 +136,7 @@ extern "C" int bbx_values_seeded(bbx_batch* b, const char* strategy, double gamm
 
 extern "C" int bbx_values(bbx_batch* b, const char* strategy, double gamma, double* out) {
   if (!b || !strategy || !out) return fail(BBX_E_ARG, "bad arguments");
-  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipSetDevice(b->device)); b->api_epoch++;
   std::vector<int32_t> envs(b->B);
   for (int e = 0; e < b->B; e++) envs[e] = e;
   return values_for(b, envs, strategy, gamma, nullptr, out);

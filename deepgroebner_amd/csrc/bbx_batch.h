@@ -102,6 +102,13 @@ struct bbx_batch {
                                       // lack of space are an error the caller must hear about (bbx_sync)
   // persistent sessions (bbx_persistent): see BbxParams::ctl
   bool ps_enabled = false, ps_active = false;
+  // host mailbox sessions (BbxParams::mbox): host-driven steps of small zero-copy batches on the register/LDS-resident class
+  bool ps_mbox = false;                 // the session in progress is one
+  unsigned long long* h_mbox = nullptr; // its control word, in pinned host memory, and the device's address of it
+  unsigned long long* mbox_dev = nullptr;
+  unsigned long long api_epoch = 0, mbox_epoch = ~0ull;   // launches / waits on the handle so far; the count as the last host step left it
+  int mbox_streak = 0;                  // host steps in a row with nothing else on the handle in between (a loop: worth a session)
+  int mbox_misses = 0;                  // steps whose result did not arrive through the mailbox in time (three in a row: no more mailbox sessions)
   unsigned long long* d_ctl = nullptr;
   hipStream_t ps_stream = nullptr, ps_ctl_stream = nullptr;   // the session's kernel / the writes to its control word
   hipEvent_t ps_ev = nullptr;

@@ -185,6 +185,10 @@ struct BbxParams {
   int32_t spill_terms;      // general class, != 0: a merge of more than this many terms hands the environment (untouched: the
                             // step is restartable) to the wide class — one workgroup per environment — launched right behind
   uint32_t slice_ticks;     // persistent kernels: leave after this many ticks of the 100 MHz clock (0: no limit)
+  int32_t mbox;             // persistent kernels, != 0: a host MAILBOX session — the control word and the action buffer live in
+                            // pinned host memory and are written by the host itself (no launch per step), and every step publishes
+                            // its outputs (rewards / dones / rows / observation block, then the status word with the step's
+                            // sequence number) to the pinned block the host spins on: bbx_step / bbx_step_obs of small batches
   int32_t wide_hc, wide_fc, wide_rc, wide_sc;   // wide class: LDS capacities (terms) of the polynomial being reduced, the
                                        // reducer-tail window, the reducer table and the accumulator; wide_hc == 0: chosen by the launcher
 };

@@ -55,6 +55,7 @@ struct BbxFastParams {
   const unsigned long long* ctl; int32_t sess_target; uint32_t slice_ticks;   // persistent sessions: see BbxParams
   double gamma; double* values;                       // VAL instantiation (value(), buchberger.cpp:332-351): discount, [B] returns
   unsigned long long* ctl_stats;                      // statistics word: steps taken by closing launches
+  int32_t mbox;                                       // host mailbox session (BbxParams::mbox)
 };
 
 __device__ __forceinline__ uint32_t f_readlane(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
@@ -615,7 +616,9 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem, in
         const uint32_t t0 = (uint32_t)__builtin_amdgcn_s_memrealtime();
         bool more = false;
         for (;;) {
-          const unsigned long long w = __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          // (a mailbox session's word lives in host memory and is followed by the step's action: acquire, system scope)
+          const unsigned long long w = cq->mbox ? __hip_atomic_load(ctl, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM)
+                                                : __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           const int tgt = uni((int)(uint32_t)w), stop = uni((int)(uint32_t)(w >> 32));
           if (tgt > taken) { budget = tgt - taken; more = true; break; }
           if (stop & 1) break;
@@ -666,7 +669,11 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem, in
       action = pmlp_sample(lg, pn, env, uu, pol->actions + (size_t)pol_tt * (size_t)pol->stride_out, pol->logprobs + (size_t)pol_tt * (size_t)pol->stride_out);
     } else
     if (agent == BBX_AGENT_HASH) action = (int)(((uint64_t)f_readlane(hv, t_agent & 63) * (uint32_t)nP) >> 32);   // bbx_agent_action32
-    else if (agent == BBX_AGENT_EXTERNAL) action = ext_action >= 0 ? ext_action : uni(f_cold_params()->actions[env]);
+    else if (agent == BBX_AGENT_EXTERNAL) {
+      const FColdParams ca = f_cold_params();
+      if (PERSIST && ca->mbox) action = uni(__hip_atomic_load(ca->actions + env, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));   // (host memory, rewritten per step)
+      else action = ext_action >= 0 ? ext_action : uni(ca->actions[env]);
+    }
     else if (agent == BBX_AGENT_FIRST) action = 0;
     else if (!HL && agent == BBX_AGENT_STDRANDOM) {        // choice(P.begin(), P.end(), rng) of the seeded engine (buchberger.cpp:200-203, 244)
       uint32_t x = (uint32_t)uni((int)std_rng);
@@ -1042,6 +1049,26 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem, in
         if (pol->post_obs && pol->rows_t) pol->rows_t[env] = nP;
       }
     }
+    if constexpr (PERSIST && POL == 0 && !HL) {
+      // a host mailbox session: the host spins on this environment's status word for the step's sequence number; the step's
+      // outputs — and the observation rows written above — reach host memory first
+      const FColdParams cm = f_cold_params();
+      if (cm->mbox) {
+        __threadfence_system();
+        if (lane == 0) {
+          const BbxHdr* hh = (const BbxHdr*)(cm->recs + (size_t)env * cm->rec_bytes);
+          const int taken = (cm->set_budget ? 0 : hh->sess_done) + t_agent - hh->t;      // steps of the session's total taken, this one included
+          if (cm->rewards) cm->rewards[env] = cm->rewards_mode == BBX_REW_ADDITIONS ? (-1.0 - (double)nred) : -1.0;
+          if (cm->dones) cm->dones[env] = (uint8_t)(done ? 1 : 0);
+          if (cm->rows) cm->rows[env] = nP;
+          int32_t* lw = cm->lite + 4 * (size_t)env;
+          lw[1] = q_head; lw[2] = budget - 1; lw[3] = nP;
+          __threadfence_system();
+          __hip_atomic_store(lw, BBX_ST_OK | ((obs_trunc | (nP > cm->obs_rows && cm->obs ? 1 : 0)) ? BBX_LITE_OBS_TRUNC : 0) | (((taken % 16000) + 1) << 17),
+                             __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+      }
+    }
     budget--; if (TRACE) trace_pos++;
     done_last = done ? 1 : 0;
     if (done) { episodes++; if (auto_reset) need_reset = 1; }
@@ -1096,7 +1123,8 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem, in
     h->obs_trunc = trunc_all;
     if (!handoff) {
       double* rw = cz->rewards; uint8_t* dn = cz->dones; int32_t* rws = cz->rows;
-      if (rw && (steps_done > 0 || cz->pass == 0))
+      // (a later kernel of a session that found nothing owed leaves the reward of the step an earlier one took alone)
+      if (rw && (steps_done > 0 || (cz->pass == 0 && !cz->sess_target)))
         rw[env] = last_nred < 0 ? 0.0 : (cz->rewards_mode == BBX_REW_ADDITIONS ? (-1.0 - (double)last_nred) : -1.0);
       if (dn) dn[env] = (uint8_t)((done_last || (nP == 0 && !need_reset)) ? 1 : 0);
       if (rws) rws[env] = nP;
@@ -1104,11 +1132,14 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem, in
     if (cz->lite) {
       // the host may be spinning on this word (done_seq): everything else this wave wrote — rewards, rows, the observation
       // block in host memory — has to be visible first
-      const int seq = cz->done_seq;
+      // (a mailbox session: the sequence number of the last step this environment took, as its per-step publication left it)
+      const int seq = (PERSIST && cz->mbox) ? (h->sess_done % 16000) + 1 : cz->done_seq;
       int32_t* lw = cz->lite + 4 * (size_t)env;
       const int word0 = status | (trunc_all ? BBX_LITE_OBS_TRUNC : 0) | (seq << 17);
       if (seq) {                                       // the word the host watches goes last and alone, behind a system-scope fence
-        lw[1] = q_head; lw[2] = budget; lw[3] = nP;
+        // (a mailbox session: bit 30 of the budget word says "this wave has left and stored its environment" — what the host
+        // waits for when it closes the session, instead of the runtime's completion signal)
+        lw[1] = q_head; lw[2] = (PERSIST && cz->mbox) ? (budget | 0x40000000) : budget; lw[3] = nP;
         __threadfence_system();
         __hip_atomic_store(lw, word0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
       } else *(int4*)lw = make_int4(word0, q_head, budget, nP);

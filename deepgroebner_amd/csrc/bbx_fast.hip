@@ -18,7 +18,7 @@ extern "C" int bbx_launch_fast(const BbxParams* p, int blocks, int threads, int 
   f.lite = p->lite; f.done_seq = p->done_seq;
   f.gen = p->gen;
   f.sort_input = p->sort_input;
-  f.ctl = p->ctl; f.sess_target = p->sess_target; f.ctl_stats = p->ctl_stats; f.slice_ticks = p->slice_ticks;
+  f.ctl = p->ctl; f.sess_target = p->sess_target; f.ctl_stats = p->ctl_stats; f.slice_ticks = p->slice_ticks; f.mbox = p->mbox;
   f.gamma = p->gamma; f.values = p->values;
   const size_t lds = (size_t)envs_per_block * FLay<FNBK_WIDE>::BYTES, lds_pol = (size_t)envs_per_block * FLay<FNBK_POL>::BYTES;
 #ifdef BBX_PROF_BUILD
