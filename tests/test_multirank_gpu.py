@@ -64,12 +64,12 @@ def test_bench_two_ranks_via_its_own_launcher():
         assert r["value"] > 0 and r["scaling"] == "weak" and r["roofline"]["launches"] == 3
 
 
-def test_five_ranks_sharing_the_device_equal_one_process_and_bench_runs_five():
-    """Five ranks at once — a GPU box of this pool lets one user have six processes on a card, and the test runner is one
-    (the 8-rank launch is rehearsed without GPUs in tests/test_multirank_cpu.py) — each with its shard: their union equals one
-    process running all of it, and `bench.py --gpus 5` (oversubscribed, said so in the line) goes through rendezvous, build
-    barrier and reduction."""
-    B, T, world = 32, 100, 5
+def test_four_ranks_sharing_the_device_equal_one_process_and_bench_runs_four():
+    """Four ranks at once — a GPU box of this pool lets one user have six processes on a card, and the test runner and the
+    launcher count (the 8-rank launch is rehearsed without GPUs in tests/test_multirank_cpu.py) — each with its shard: their
+    union equals one process running all of it, and `bench.py --gpus 4` (oversubscribed, said so in the line) goes through
+    rendezvous, build barrier and reduction."""
+    B, T, world = 32, 100, 4
     procs = [_child(r, world, B, T) for r in range(world)]
     outs = []
     for p in procs:
@@ -83,9 +83,9 @@ def test_five_ranks_sharing_the_device_equal_one_process_and_bench_runs_five():
     outs.sort(key=lambda o: o["rank"])
     assert sum((o["ids"] for o in outs), []) == whole["ids"] == list(range(B * world))
     assert np.array_equal(np.array(sum((o["stats"] for o in outs), [])), np.array(whole["stats"]))
-    five = _bench("--gpus", "5", "--batch", "64", "--allow-oversubscribe")
-    assert five["n_gpus"] == 5 and five["oversubscribed"] is True and len(five["per_rank_value"]) == 5 and five["config"]["global_batch"] == 320
-    assert five["value"] > 0 and five["rehearsal"] is False
+    four = _bench("--gpus", "4", "--batch", "64", "--allow-oversubscribe")
+    assert four["n_gpus"] == 4 and four["oversubscribed"] is True and len(four["per_rank_value"]) == 4 and four["config"]["global_batch"] == 256
+    assert four["value"] > 0 and four["rehearsal"] is False
 
 
 def test_bench_refuses_more_ranks_than_gpus():
