@@ -551,7 +551,9 @@ constexpr uint32_t PS_SLICE_TICKS = 1000000u;            // 10 ms of the 100 MHz
 int ps_write_ctl(bbx_batch* b, bool stop) {              // all writes to the control word travel on one stream, in order
   if (b->ps_mbox) {                                        // (a mailbox session's word is in host memory: the host writes it itself)
     std::atomic_thread_fence(std::memory_order_release);
-    __atomic_store_n(b->h_mbox, (unsigned long long)b->ps_target | (stop ? (1ull << 32) : 0ull), __ATOMIC_RELEASE);
+    // (one environment: the step's action rides in bits 33.. of the word, + 1 — 0: look in the action buffer)
+    const unsigned long long act = (b->B == 1 && !stop && b->h_act[0] >= 0) ? ((unsigned long long)(uint32_t)(b->h_act[0] + 1) << 33) : 0ull;
+    __atomic_store_n(b->h_mbox, (unsigned long long)b->ps_target | (stop ? (1ull << 32) : 0ull) | act, __ATOMIC_RELEASE);
     return BBX_OK;
   }
   int lrc = bbx_launch_ctl(b->d_ctl, (unsigned long long)b->ps_target | (stop ? (1ull << 32) : 0ull), b->ps_ctl_stream);

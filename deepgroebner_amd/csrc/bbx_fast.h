@@ -194,6 +194,8 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem, in
   if (p.set_budget) { budget = bbx_st_capacity(status) ? budget + p.nsteps : p.nsteps; rollout_pos = 0; done_last = 0; }   // (bbx_common.h: bbx_st_capacity)
   if (p.sess_target) budget = p.sess_target - uni(ghdr->sess_done);   // later kernels of a persistent session: what is still owed
   const uint32_t t_begin = PERSIST ? (uint32_t)__builtin_amdgcn_s_memrealtime() : 0u;
+  int mb_action = -1;                                  // mailbox session of ONE environment: the action that came with the control word
+  bool mb_pending = false;                             // mailbox session: a step has been taken whose outputs the host is waiting for
   int pol_t0 = 0;                                      // POL + PERSIST: agent step counter minus session step, fixed for the kernel
   if (POL > 0 && PERSIST) { int vz_; asm volatile("v_mov_b32 %0, 0" : "=v"(vz_)); pol_t0 = vz_ + (t_agent - (p.set_budget ? 0 : uni(ghdr->sess_done))); }
   if (p.pass == 1 && !(status == BBX_ST_OK && (need_reset || (budget > 0 && nP > 0)))) return;
@@ -604,6 +606,28 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem, in
       need_reset = 0;
     }
     FSTAMP(0);                                             // 0: loop top / reset
+    if constexpr (PERSIST && POL == 0 && !HL) {
+      // A host mailbox session: the host spins on this environment's status word for the step's sequence number.  The step's
+      // outputs reach host memory first — here, behind the reset of an environment whose episode the step ended (auto-reset:
+      // the observation and the row count the call returns are the new episode's, as in a launch per step).
+      if (mb_pending) {
+        mb_pending = false;
+        const FColdParams cm = f_cold_params();
+        if (done_last && auto_reset && cm->obs) { if (obs32) write_obs32(); else write_obs(true, false); obs_trunc |= nP > cm->obs_rows ? 1 : 0; }
+        __threadfence_system();
+        if (lane == 0) {
+          const BbxHdr* hh = (const BbxHdr*)(cm->recs + (size_t)env * cm->rec_bytes);
+          const int taken = (cm->set_budget ? 0 : hh->sess_done) + t_agent - hh->t;      // steps of the session's total taken so far
+          if (cm->rewards) cm->rewards[env] = cm->rewards_mode == BBX_REW_ADDITIONS ? (-1.0 - (double)last_nred) : -1.0;
+          if (cm->dones) cm->dones[env] = (uint8_t)done_last;
+          if (cm->rows) cm->rows[env] = nP;
+          int32_t* lw = cm->lite + 4 * (size_t)env;
+          lw[1] = q_head; lw[2] = budget; lw[3] = nP;
+          __threadfence_system();
+          __hip_atomic_store(lw, BBX_ST_OK | (obs_trunc ? BBX_LITE_OBS_TRUNC : 0) | (((taken % 16000) + 1) << 17), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+      }
+    }
     if (budget <= 0) {
       if constexpr (PERSIST) {
         // every step issued so far is taken: have more been issued meanwhile?  (Nothing about the session is kept live
@@ -620,12 +644,14 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem, in
           const unsigned long long w = cq->mbox ? __hip_atomic_load(ctl, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM)
                                                 : __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           const int tgt = uni((int)(uint32_t)w), stop = uni((int)(uint32_t)(w >> 32));
-          if (tgt > taken) { budget = tgt - taken; more = true; break; }
+          // (a mailbox session of one environment carries the step's action in bits 33.. of the word, + 1: one read over the bus
+          // instead of two; valid for the LAST step issued, i.e. when exactly one step is owed)
+          if (tgt > taken) { budget = tgt - taken; more = true; mb_action = (cq->mbox && budget == 1) ? uni((int)(uint32_t)(w >> 33)) - 1 : -1; break; }
           if (stop & 1) break;
           const uint32_t now = (uint32_t)__builtin_amdgcn_s_memrealtime();
           if (now - t0 > 2000000u) break;                                // 20 ms without news
           if (cq->slice_ticks && now - t_begin > cq->slice_ticks) break; // the slice is over anyway
-          __builtin_amdgcn_s_sleep(32);
+          if (cq->mbox) __builtin_amdgcn_s_sleep(4); else __builtin_amdgcn_s_sleep(32);   // (a host waits on the other side: short naps)
         }
         if (!more) break;
       } else break;
@@ -671,7 +697,10 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem, in
     if (agent == BBX_AGENT_HASH) action = (int)(((uint64_t)f_readlane(hv, t_agent & 63) * (uint32_t)nP) >> 32);   // bbx_agent_action32
     else if (agent == BBX_AGENT_EXTERNAL) {
       const FColdParams ca = f_cold_params();
-      if (PERSIST && ca->mbox) action = uni(__hip_atomic_load(ca->actions + env, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));   // (host memory, rewritten per step)
+      if (PERSIST && ca->mbox) {                           // (host memory, rewritten per step)
+        if (mb_action >= 0) { action = mb_action; mb_action = -1; }
+        else action = uni(__hip_atomic_load(ca->actions + env, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+      }
       else action = ext_action >= 0 ? ext_action : uni(ca->actions[env]);
     }
     else if (agent == BBX_AGENT_FIRST) action = 0;
@@ -1049,26 +1078,7 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem, in
         if (pol->post_obs && pol->rows_t) pol->rows_t[env] = nP;
       }
     }
-    if constexpr (PERSIST && POL == 0 && !HL) {
-      // a host mailbox session: the host spins on this environment's status word for the step's sequence number; the step's
-      // outputs — and the observation rows written above — reach host memory first
-      const FColdParams cm = f_cold_params();
-      if (cm->mbox) {
-        __threadfence_system();
-        if (lane == 0) {
-          const BbxHdr* hh = (const BbxHdr*)(cm->recs + (size_t)env * cm->rec_bytes);
-          const int taken = (cm->set_budget ? 0 : hh->sess_done) + t_agent - hh->t;      // steps of the session's total taken, this one included
-          if (cm->rewards) cm->rewards[env] = cm->rewards_mode == BBX_REW_ADDITIONS ? (-1.0 - (double)nred) : -1.0;
-          if (cm->dones) cm->dones[env] = (uint8_t)(done ? 1 : 0);
-          if (cm->rows) cm->rows[env] = nP;
-          int32_t* lw = cm->lite + 4 * (size_t)env;
-          lw[1] = q_head; lw[2] = budget - 1; lw[3] = nP;
-          __threadfence_system();
-          __hip_atomic_store(lw, BBX_ST_OK | ((obs_trunc | (nP > cm->obs_rows && cm->obs ? 1 : 0)) ? BBX_LITE_OBS_TRUNC : 0) | (((taken % 16000) + 1) << 17),
-                             __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-      }
-    }
+    if constexpr (PERSIST && POL == 0 && !HL) mb_pending = f_cold_params()->mbox != 0;   // (published at the loop top, behind a reset)
     budget--; if (TRACE) trace_pos++;
     done_last = done ? 1 : 0;
     if (done) { episodes++; if (auto_reset) need_reset = 1; }

@@ -169,3 +169,66 @@ def test_policy_step_calls_join_a_session(caps):
     assert envs[1].session_stats()["sessions"] == 1 and envs[1].session_stats()["joined"] == T - 1
     for a, b, name in zip(outs[0], outs[1], ("actions", "logprobs", "rewards", "dones", "rows", "obs", "stats")):
         assert np.array_equal(a, b), name
+
+
+@pytest.mark.parametrize("B,auto_reset", [(1, False), (3, True), (8, True)])
+def test_host_mailbox_session_is_invisible_except_in_time(B, auto_reset):
+    """Host-driven steps of a small batch (the reference's usage: one environment stepped from Python, wrapped.pyx:23-26) on the
+    register/LDS class: from the fifth step in a row on, the calls feed ONE resident kernel through pinned host memory
+    (bbx_api.cpp mbox_step) — control word and actions written by the host, rewards / dones / rows / observation published by
+    the waves with every step.  Every step's reward, done flag and observation matrix against the oracle; in between, calls
+    that need the records (state, copy, value, stats) and that close the session; an out-of-range action surfaces as an error
+    and the batch goes on; the statistics say that sessions were in fact used."""
+    from deepgroebner_amd import VecLeadMonomialsEnv, _ffi
+    bo = ffi.load("bo")
+    k = 2
+    env = VecLeadMonomialsEnv(DIST, batch=B, k=k)
+    env.seed(np.arange(B) + 77); env.accounting(False)
+    states = env.reset()
+    oracles = []
+    for e in range(B):
+        o = bo.env(DIST); o.seed(77 + e); o.reset(); oracles.append(o)
+    copies = []
+    for t in range(400):
+        for e, o in enumerate(oracles):
+            assert np.array_equal(states[e], o.obs(k)), (t, e)
+        if not auto_reset and oracles[0].nP == 0:
+            for o in oracles:
+                o.reset()
+            states = env.reset()
+            continue
+        acts = np.array([ffi.agent_hash(e + 1, t) % max(o.nP, 1) for e, o in enumerate(oracles)], dtype=np.int32)
+        states, rew, done, _ = env.step(acts, auto_reset=auto_reset)
+        for e, o in enumerate(oracles):
+            assert rew[e] == o.step(int(acts[e])), (t, e)
+            assert bool(done[e]) == (o.nP == 0), (t, e)
+            if o.nP == 0 and auto_reset:
+                o.reset()
+        if t == 60:                                        # the records, read in the middle of a session
+            basis, pairs, order = env.state(B - 1)
+            assert np.array_equal(_state_words(basis, pairs, order), _state_words(oracles[B - 1].basis(), oracles[B - 1].pairs(), oracles[B - 1].reducer_order()))
+        if t == 120:
+            copies.append((env.copy(), [o.copy() for o in oracles]))
+        if t == 200 and oracles[0].nP > 0:
+            assert env.value(0, "degree", 0.99) == oracles[0].value("degree", 0.99)
+        if t == 300:                                       # an action beyond the pair set is an error (the reference indexes out of
+            bad = acts.copy(); bad[0] = 100000                 # bounds, buchberger.cpp:399); a reset clears it, like everywhere else
+            with pytest.raises(_ffi.BbxError) as ei:
+                env.step(bad, auto_reset=auto_reset)
+            assert ei.value.code == -6
+            for o in oracles:
+                o.reset()
+            states = env.reset()
+    ss = env.session_stats()
+    assert ss["sessions"] >= 2 and ss["joined"] > 200, ss
+    cenv, coracles = copies[0]                             # a copy made in the middle of a session continues like its source did
+    for t in range(30):
+        acts = np.array([0] * B, dtype=np.int32)
+        if any(o.nP == 0 for o in coracles) and not auto_reset:
+            break
+        st, rew, done, _ = cenv.step(acts, auto_reset=auto_reset)
+        for e, o in enumerate(coracles):
+            assert rew[e] == o.step(0)
+            if o.nP == 0 and auto_reset:
+                o.reset()
+            assert np.array_equal(st[e], o.obs(k))
