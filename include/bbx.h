@@ -120,7 +120,11 @@ int bbx_reset(bbx_batch* b, const uint8_t* mask, int32_t* rows);
 
 /* ---- LeadMonomialsEnv::step (buchberger.cpp:398-408, wrapped.pyx:23-26) -----------------------
  * actions[e] indexes the rows of environment e's observation.  Environments that are done are
- * left untouched (reward 0).  rewards/dones/rows may be NULL. */
+ * left untouched (reward 0).  rewards/dones/rows may be NULL.
+ * Small batches (<= 8 environments) on the class of the reference's C++ LeadMonomialsEnv: the step calls of a loop (from
+ * the fifth call in a row on: bbx_step, bbx_step_autoreset, bbx_step_obs) feed one resident kernel through pinned host memory
+ * instead of launching one each — a host mailbox session; any other call on the handle ends it first.
+ * Results are those of one launch per step; the environment variable BBX_NO_MAILBOX restores that. */
 int bbx_step(bbx_batch* b, const int32_t* actions, double* rewards, uint8_t* dones, int32_t* rows);
 
 /* The vectorised-environment convention: an environment whose episode ends with this step is reset inside the same
