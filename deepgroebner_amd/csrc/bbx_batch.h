@@ -1,5 +1,6 @@
-// The batch handle of libbbx's C ABI and the internals its translation units share (bbx_api.cpp: creation, launches,
-// sessions, stepping; bbx_api_value.cpp: value(); bbx_api_state.cpp: introspection, generators, text format).
+// The batch handle of libbbx's C ABI and the internals its translation units share (bbx_api.cpp: creation, kernels of a
+// launch, waits, stepping; bbx_api_session.cpp: what a call becomes — persistent / mailbox sessions, recorded steps;
+// bbx_api_value.cpp: value(); bbx_api_state.cpp: introspection, generators, text format).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -137,5 +138,15 @@ int read_headers(bbx_batch* b, hipStream_t stream = 0);
 void fill_params(bbx_batch* b, BbxParams* p);
 int grow_records(bbx_batch* b, unsigned need, int env, hipStream_t stream);
 const char* status_name(int s);
+// bbx_api.cpp
+int fill_queues(bbx_batch* b, int min_avail = 1, hipStream_t stream = 0);
+int enqueue(bbx_batch* b, const BbxParams& p0, bool resume, hipStream_t stream);   // the kernels of one logical launch
+// bbx_api_session.cpp
+int launch(bbx_batch* b, BbxParams& p, hipStream_t stream, bool obs_external = false, bool device_async = false);
+int ps_write_ctl(bbx_batch* b, bool stop);
+int session_kernel(bbx_batch* b, bool first, hipStream_t after, bool sliced);
 int session_close(bbx_batch* b, bool wait, hipStream_t then, bool sliced);
+bool session_same_call(const BbxParams& a, const BbxParams& c);
+bool mbox_eligible(const bbx_batch* b);
+int mbox_step(bbx_batch* b, BbxParams& p, bool* used);
 }  // namespace bbx_host
