@@ -138,6 +138,11 @@ struct WideCtx {
 #endif
 };
 
+// a value every lane holds alike (an LDS or memory load from a uniform address), pinned to scalar registers: the compiler
+// takes every load for per-lane, and with it each comparison, branch and counter that depends on one
+__device__ __forceinline__ uint64_t uni64(uint64_t v) {
+  return ((uint64_t)(uint32_t)uni((int)(uint32_t)(v >> 32)) << 32) | (uint32_t)uni((int)(uint32_t)v);
+}
 __device__ __forceinline__ int wide_shr1(int v) {         // lane i <- lane i-1 (lane 0: undefined, fixed by the caller)
   return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xF, 0xF, false);
 }
@@ -164,6 +169,7 @@ __device__ __forceinline__ int wide_merge_seg(const AV& A, int na_, const BV& B,
   const int total = na + nb;
   int ci = 0, cj = 0;                                     // merge-path boundary at the start of the current tile
   for (int base = 0; base < total; base += x.NT * SEG) {
+    x.par_end = uni(x.par_end); x.par_count = uni(x.par_count);
     // ---- my END boundary: (i1, j1), i1 + j1 = d, such that A[0..i1) and B[0..j1) are exactly the first d terms of the
     // merge (ties: the A term first); an equal pair is never split across a boundary
     int d = base + (x.tid + 1) * SEG; d = d < total ? d : total;
@@ -534,10 +540,19 @@ __device__ __forceinline__ void wide_body(char* smem) {
 #define WIDE_HC(P, E, B) ((E).hc + (size_t)(B) * (P).L.maxT)
 #define WIDE_SACC(I) T.off(2 * HC + FC + WRB + (I) * SC)
 
+  // Everything the loops below branch on is the same in every lane by construction; the compiler has to be told.  One value
+  // it cannot prove uniform (a counter advanced under a branch it takes for per-lane) turns every loop-carried value after it
+  // into a vector register and every branch into exec-mask code: the step loop then runs on spilled vector registers, with
+  // reloads from scratch on the critical path of every reduction round.  WPIN breaks such chains at the loop heads.
+#define WPIN(v) v = uni(v)
+#define WPINB(v) v = uni((int)(v)) != 0
+
   // dst <- dst_live + B, where dst is S (to_s) or H and B is the live accumulator S (from_s; S is empty afterwards) or
   // (scale * x^shift) * f[0..fn), f = arena terms [foff, foff + fn)  (polynomials.cpp:148-202).  Returns false on
   // overflow (status set).  All threads, uniform arguments; ends with the result complete and visible.
   auto poly_add = [&](bool to_s, bool from_s, int foff, int fn, const Mono<W>& shift, uint32_t scale) __attribute__((always_inline)) -> bool {
+    WPIN(hn); WPIN(hoff); WPIN(sn); WPIN(soff); WPIN(cur); WPIN(scur); WPIN(hbuf); WPINB(in_lds); WPIN(status);
+    WPIN(x.par_found); WPIN(x.par_count); WPIN(x.par_end);
     const BbxParams& p = wide_params();
     const Env<W> e = env_view<W>(WIDE_REC(p), p.L);
     const Mono<W>* const fm = e.am + foff; const uint16_t* const fc = e.ac + foff;
@@ -550,6 +565,7 @@ __device__ __forceinline__ void wide_body(char* smem) {
       if (from_s) return wide_merge(A, an, Sl, sl, O, 0, ocap, x);
       int nn = 0, a0 = 0, c0 = 0;
       do {
+        WPIN(nn); WPIN(a0); WPIN(c0);
         const int cn = fn - c0 < FC ? fn - c0 : FC;
         WCOUNT(14, 1);
         wide_load_scaled<W>(F, fm + c0, fc + c0, cn, shift, scale, x);
@@ -584,6 +600,7 @@ __device__ __forceinline__ void wide_body(char* smem) {
         as = 0; cur = 0; in_lds = true;
         __syncthreads();
       }
+      WPIN(as); WPIN(cur); WPINB(in_lds);
       nn = lds_add(T.off(cur * HC + as), an, T.off((cur ^ 1) * HC), HC);
       cur ^= 1;
     } else {
@@ -595,6 +612,7 @@ __device__ __forceinline__ void wide_body(char* smem) {
         as = 0; in_lds = false; hbuf = 0;
         __syncthreads();
       }
+      WPIN(as); WPINB(in_lds); WPIN(hbuf);
       const Mono<W>* const hm = WIDE_HM(p, e, hbuf) + as; const uint16_t* const hc = WIDE_HC(p, e, hbuf) + as;
       Mono<W>* const nm = WIDE_HM(p, e, hbuf ^ 1); uint16_t* const nc = WIDE_HC(p, e, hbuf ^ 1);
       const GlbOut<W> O{nm, nc};
@@ -606,6 +624,7 @@ __device__ __forceinline__ void wide_body(char* smem) {
         if (!from_s) wide_load_scaled<W>(BB, fm, fc, fn, shift, scale, x);
         int b0 = 0, w0 = 0;
         do {
+          WPIN(nn); WPIN(b0); WPIN(w0);
           const int wn = an - w0 < HC ? an - w0 : HC;
           wide_load_plain<W>(Sw, hm + w0, hc + w0, wn, x);
           __syncthreads();
@@ -616,7 +635,7 @@ __device__ __forceinline__ void wide_body(char* smem) {
       } else {
         // ---- tier 3: the same merge on HBM-resident views (exponents beyond a byte, or f longer than the LDS)
         WCOUNT(12, 1);
-        nn = wide_merge_hbm<W>(hm, hc, an, fm, fc, fn, shift, scale, nm, nc, maxT, x);
+        nn = uni(wide_merge_hbm<W>(hm, hc, an, fm, fc, fn, shift, scale, nm, nc, maxT, x));
         __syncthreads();
       }
       if (nn > maxT) { status = BBX_ST_POLY_TOO_LONG; return false; }
@@ -630,6 +649,8 @@ __device__ __forceinline__ void wide_body(char* smem) {
 
   for (;;) {
     WSTAMP(8);
+    WPIN(status); WPIN(need_reset); WPIN(budget); WPIN(nP); WPIN(nG); WPIN(arena_used); WPIN(t_agent); WPINB(table_dirty); WPIN(rcl);
+    WPIN(par_any); WPIN(x.par_found); WPIN(x.par_count); WPIN(x.par_end);
     if (status != BBX_ST_OK) break;
     if (need_reset) {                                                         // leader alone (once per episode), wave-level code
       if (leader) wide_leader_reset<W>(&wide_params(), x.ctl, env);
@@ -712,6 +733,7 @@ __device__ __forceinline__ void wide_body(char* smem) {
         for (int t = x.tid; t < na; t += x.NT) { dm[t] = m_mul(e.am[offi + 1 + t], shi); dc[t] = (uint16_t)mulmod(e.ac[offi + 1 + t], sci); }
         in_lds = false; hbuf = 1;
       }
+      WPINB(in_lds); WPIN(cur); WPIN(hbuf);
       hoff = 0; hn = na; hwn = 0;
       __syncthreads();
       sp_foff = offj + 1; sp_fn = nb; sp_shift = shj; sp_scale = scj; sp_na = na;
@@ -737,6 +759,9 @@ __device__ __forceinline__ void wide_body(char* smem) {
       __syncthreads();
     };
     for (;;) {
+      WPIN(hn); WPIN(hoff); WPIN(hsug); WPIN(cur); WPIN(hbuf); WPIN(hw0); WPIN(hwn); WPIN(sn); WPIN(soff); WPIN(scur); WPINB(in_lds);
+      WPIN(nsteps_red); WPIN(rn); WPIN(rsug); WPIN(rflushed); WPINB(first); WPIN(status);
+      WPIN(par_any); WPIN(x.par_found); WPIN(x.par_count); WPIN(x.par_end);
       int fn, foff, found = -1, an = 0;
       Mono<W> shift; uint32_t scale;
       if (first) { foff = sp_foff; fn = sp_fn; shift = sp_shift; scale = sp_scale; }
@@ -744,6 +769,8 @@ __device__ __forceinline__ void wide_body(char* smem) {
         // ---- the lead term of h = H + S leaves h (it is either cancelled by the reducer or moved to r)
         Mono<W> lmh; uint32_t lch = 0;
         bool zero = false;
+        const Mono<W>* slm_g;
+        { const BbxParams& p = wide_params(); slm_g = (const Mono<W>*)(WIDE_REC(p) + p.L.off_slm); }
         for (;;) {
           const bool hH = hoff < hn, hS = LAZY && soff < sn;
           if (!hH && !hS) { zero = true; break; }
@@ -762,10 +789,12 @@ __device__ __forceinline__ void wide_body(char* smem) {
                 else { hwn = 1; mH = WIDE_HM(p, e, hbuf)[hoff]; cH = WIDE_HC(p, e, hbuf)[hoff]; }
                 __syncthreads();
               }
+              WPIN(hw0); WPIN(hwn);
               if (keyed) { kH = T.key(hoff - hw0); cH = T.coef(hoff - hw0); }
             }
           }
           if (hS) { const LdsKeys Sc = WIDE_SACC(scur); kS = Sc.key(soff); cS = Sc.coef(soff); }
+          kH = uni64(kH); kS = uni64(kS); cH = (uint32_t)uni((int)cH); cS = (uint32_t)uni((int)cS);
           if (!keyed) { lmh = mH; lch = cH; hoff++; hwn = 0; break; }          // (then S is empty: see poly_add)
           if (hH && (!hS || kH > kS)) { lmh = wide_unkey<W>(kH); lch = cH; hoff++; break; }
           if (hS && (!hH || kS > kH)) { lmh = wide_unkey<W>(kS); lch = cS; soff++; break; }
@@ -777,8 +806,6 @@ __device__ __forceinline__ void wide_body(char* smem) {
 #pragma unroll
         for (int q = 0; q < W; q++) lmh.w[q] = (uint32_t)uni((int)lmh.w[q]);
         lch = (uint32_t)uni((int)lch);
-        const Mono<W>* slm_g;
-        { const BbxParams& p = wide_params(); slm_g = (const Mono<W>*)(WIDE_REC(p) + p.L.off_slm); }
         found = wide_find_divisor<W>(R, rcl, slm_g, nG, lmh, x);
         WSTAMP(2);
 #ifdef BBX_PROF_BUILD
@@ -802,6 +829,7 @@ __device__ __forceinline__ void wide_body(char* smem) {
             }
             rflushed = rn + 1;
           }
+          WPIN(rflushed);
           const int d = (int)m_deg(lmh);
           rsug = d > rsug ? d : rsug;
           rn++;
@@ -874,7 +902,7 @@ __device__ __forceinline__ void wide_body(char* smem) {
                         (sn - soff > 0 || !in_lds || (hn - hoff) + fn > x.NT * WSEG);
       const bool flush_s = LAZY && sn - soff > 0 && (!to_s || (sn - soff) + fn > SC);
       bool ok = true;
-      for (int pass = flush_s ? 0 : 1; pass < 2 && ok; pass++) ok = poly_add(pass == 1 && to_s, pass == 0, foff, fn, shift, scale);
+      for (int pass = flush_s ? 0 : 1; pass < 2 && ok; pass++) ok = uni((int)poly_add(pass == 1 && to_s, pass == 0, foff, fn, shift, scale)) != 0;
       if (!ok) { overflow = true; break; }
       if (in_lds) WSTAMP(5); else WSTAMP(6);
       if (first) { step_bytes += 12LL * (sp_na + fn + 2 + (hn - hoff)); first = false; }
@@ -971,6 +999,8 @@ __device__ __forceinline__ void wide_body(char* smem) {
       if (p.rows) p.rows[env] = nP;
     }
   }
+#undef WPIN
+#undef WPINB
 #undef WIDE_REC
 #undef WIDE_HM
 #undef WIDE_HC
