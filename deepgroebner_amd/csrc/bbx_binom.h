@@ -503,6 +503,8 @@ __device__ __forceinline__ void binom_body(const BbxParams& p_entry, char* smem,
   for (;;) {
     const BbxParams& p = bbx_kparams();                    // (per step: nothing of it lives across the loop's back edge)
     const BbxLayout& L = STAGED ? p.LL : p.L;
+    pin(nG, nP, status, need_reset, q_head, t_agent, episode_steps, episodes, zero_red, budget, rollout_pos, done_last, obs_trunc, steps_done);
+    pin(total_steps, total_adds, alg_bytes, std_rng, gen_state, vret, vdisc, last_reward, obs_live);   // (bbx_device.h: pin)
     if (status != BBX_ST_OK) break;
     if (need_reset) {
       bool reset_ok;

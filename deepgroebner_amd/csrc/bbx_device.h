@@ -45,6 +45,17 @@ __device__ __forceinline__ void wave_sync() {
 __device__ __forceinline__ uint64_t ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }   // (not __ballot: that one materialises the predicate in a VGPR first)
 __device__ __forceinline__ int prefix_of(uint64_t mask, int lane) { return __popcll(mask & ((1ull << lane) - 1ull)); }
 __device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
+// A value every lane of the wave holds alike, pinned to scalar registers.  The compiler proves uniformity from the data
+// flow; one counter advanced under a branch it takes for per-lane, one value loaded from LDS, and every loop-carried
+// value downstream becomes a vector register and every branch on it exec-mask code.  The step loops pin their state at
+// the loop heads (pin(x)): a v_readfirstlane per value where the proof fails, nothing where it holds.
+__device__ __forceinline__ uint32_t uni(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+__device__ __forceinline__ bool uni(bool x) { return __builtin_amdgcn_readfirstlane((int)x) != 0; }
+__device__ __forceinline__ uint64_t uni(uint64_t x) { return ((uint64_t)uni((uint32_t)(x >> 32)) << 32) | uni((uint32_t)x); }
+__device__ __forceinline__ long long uni(long long x) { return (long long)uni((uint64_t)x); }
+__device__ __forceinline__ double uni(double x) { return __longlong_as_double(uni(__double_as_longlong(x))); }
+template <class T> __device__ __forceinline__ void pin(T& v) { v = uni(v); }
+template <class T, class... R> __device__ __forceinline__ void pin(T& v, R&... r) { v = uni(v); pin(r...); }
 // Load from memory that no kernel writes (the ideal queue: filled by the host between launches) through the constant
 // address space: with a wave-uniform address this is a scalar load, the value lives in an SGPR and everything derived
 // from it (loop bounds, branch conditions) stays on the scalar unit.
