@@ -49,6 +49,7 @@ bbx_batch::~bbx_batch() {
   bbx_host::pool_synced(true);
   for (auto& ev : ev_open) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
   if (d_ctl) (void)hipFree(d_ctl);
+  if (d_wide_done) (void)hipFree(d_wide_done);
   if (ps_ev) (void)hipEventDestroy(ps_ev);
   if (ps_stream) (void)hipStreamDestroy(ps_stream);
   if (ps_ctl_stream) (void)hipStreamDestroy(ps_ctl_stream);
@@ -218,7 +219,7 @@ void fill_params(bbx_batch* b, BbxParams* p) {
 // HBM-resident pass that serves whatever the first could not hold; aux launches (nsteps == 0) use one kernel
 int enqueue(bbx_batch* b, const BbxParams& p0, bool resume, hipStream_t stream) {
   BbxParams p = p0;
-  int kinds[2]; int nk = 0;
+  int kinds[3]; int nk = 0;
   if (p.nsteps == 0 && !resume) kinds[nk++] = 2;
   else if (p.ctl) { kinds[nk++] = 3; kinds[nk++] = 0; }   // a kernel of a persistent session, and behind it the HBM-resident
                                                       // class for the environments that outgrew the register/LDS class
@@ -226,6 +227,14 @@ int enqueue(bbx_batch* b, const BbxParams& p0, bool resume, hipStream_t stream) 
   else if (b->gen_to_wide) {                          // general class, <= 7 variables: wave-per-environment kernel, and behind it the
     kinds[nk++] = 0; kinds[nk++] = 4;                 // workgroup-per-environment kernel for the environments whose polynomials got long
     p.spill_terms = 384;
+  }
+  // wide class with more workgroups than CUs: a second kernel for the tail of the launch (BbxParams::wide_tail)
+  int tail_at = -1;
+  if (nk > 0 && kinds[nk - 1] == 4 && nk < 3 && b->ncu > 0 && b->B > b->ncu && p.L.W <= 4 && !getenv("BBX_NO_WIDE_TAIL")) {
+    if (!b->d_wide_done) HIPCHK(hipMalloc((void**)&b->d_wide_done, 256));
+    HIPCHK(hipMemsetAsync(b->d_wide_done, 0, 256, stream));
+    tail_at = nk; kinds[nk++] = 4;
+    p.wide_done = b->d_wide_done; p.wide_ncu = b->ncu;
   }
   else {   // the hand-tuned kernel knows the external / random / degree / first agents; the others take the class kernel
     const bool pol_hbm_only = p.policy && p.policy->rollout == 2;     // a policy rollout outside the register/LDS class
@@ -248,6 +257,7 @@ int enqueue(bbx_batch* b, const BbxParams& p0, bool resume, hipStream_t stream) 
   } else p.done_seq = 0;
   for (int i = 0; i < nk; i++) {
     if (resume || i > 0) { p.set_budget = 0; p.pass = 1; }
+    p.wide_tail = tail_at < 0 ? 0 : (i == tail_at ? 2 : (i == tail_at - 1 ? 1 : 0));
     if (i > 0 && p0.ctl) { p.ctl = nullptr; p.sess_target = p0.nsteps; }   // (what is owed of the session's total when it runs; slice_ticks
                                                                            // != 0 tells it that the host looks after environments it hands back)
     // a per-step policy call: only the first pass of the fast class evaluates the policy (the follow-up reads its actions);
@@ -255,7 +265,7 @@ int enqueue(bbx_batch* b, const BbxParams& p0, bool resume, hipStream_t stream) 
     if (p.policy && !(p.policy->rollout ? (!resume && (kinds[i] == 3 || kinds[i] == 0)) : (!resume && i == 0 && kinds[i] == 3))) p.policy = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     // the primary (dominant) kernel of the sequence; where long polynomials continue in the wide kernel, that one too
-    const bool timed = b->timing && kinds[i] != 2 && (i == 0 || (b->gen_to_wide && kinds[i] == 4));
+    const bool timed = b->timing && kinds[i] != 2 && (i == 0 || kinds[i] == 4);
     if (timed) {
       HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
       HIPCHK(hipEventRecord(e0, stream));
@@ -568,6 +578,7 @@ int create_common(std::unique_ptr<bbx::IdealGen> proto, int nvars_obs, int elimi
 
   auto b = std::make_unique<bbx_batch>();
   b->B = batch; b->device = device; b->k = k;
+  { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess) b->ncu = cus; }
   b->elim = elimination; b->rewards = rewards; b->sort_input = sort_input ? 1 : 0; b->sort_reducers = sort_reducers ? 1 : 0;
   b->fixed = proto->fixed();
   b->listed = list != nullptr;
@@ -772,6 +783,7 @@ int bbx_copy(const bbx_batch* s, bbx_batch** out) {
   HIPCHK(hipDeviceSynchronize());
   auto b = std::make_unique<bbx_batch>();
   b->B = s->B; b->device = s->device; b->k = s->k; b->nvars = s->nvars; b->W = s->W;
+  b->ncu = s->ncu;
   b->elim = s->elim; b->rewards = s->rewards; b->sort_input = s->sort_input; b->sort_reducers = s->sort_reducers;
   b->fixed = s->fixed; b->listed = s->listed; b->binom = s->binom; b->L = s->L; b->LL = s->LL; b->slot_words = s->slot_words; b->nslots = s->nslots;
   b->h_q = s->h_q; b->h_tail = s->h_tail; b->h_head = s->h_head; b->q_dirty = true;

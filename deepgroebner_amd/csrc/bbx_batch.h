@@ -98,6 +98,8 @@ struct bbx_batch {
   int fast_G = 0, fast_P = 0;          // capacities of the register/LDS-resident class (BbxParams::fast_G)
   int wide = 0;                       // > 0: waves per environment of the wide (one workgroup per environment) class
   int wide_terms = 0;                 // forced LDS capacity of the wide class (caps.wide_lds_terms), 0 = automatic
+  int32_t* d_wide_done = nullptr;     // wide class: workgroups that have left the launch's first kernel (BbxParams::wide_tail)
+  int ncu = 0;                        // compute units of the device
   bool device_async = false;          // the launch in flight came through a *_device entry point (no host poll per step)
   bool obs_external = false;          // the launch in flight writes observations into a caller-owned block: rows cut for
                                       // lack of space are an error the caller must hear about (bbx_sync)

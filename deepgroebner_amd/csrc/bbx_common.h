@@ -191,6 +191,13 @@ struct BbxParams {
                             // sequence number) to the pinned block the host spins on: bbx_step / bbx_step_obs of small batches
   int32_t wide_hc, wide_fc, wide_rc, wide_sc;   // wide class: LDS capacities (terms) of the polynomial being reduced, the
                                        // reducer-tail window, the reducer table and the accumulator; wide_hc == 0: chosen by the launcher
+  // wide class, batches of more than one workgroup per CU: the launch is two kernels.  The first (wide_tail == 1, two
+  // workgroups per CU, 128 registers) counts the workgroups that have left in *wide_done; once those still at work would fit
+  // one per CU (wide_ncu) each of them stops at its next step boundary (BBX_ST_TIMESLICE, budget kept), and the second
+  // (wide_tail == 2: the variant without the register cap, 160 KB of LDS) takes what they owe — a rollout of T steps per
+  // environment ends with its slowest environments, and those then run at the speed of a workgroup that has a CU to itself
+  int32_t wide_tail, wide_ncu;
+  int32_t* wide_done;
 };
 
 // Device-side ideal generation (RandomBinomialIdealGenerator, ideals.cpp:156-201): one immutable table per batch, words:

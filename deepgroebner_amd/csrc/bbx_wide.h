@@ -511,7 +511,10 @@ __device__ __forceinline__ void wide_body(char* smem) {
     agent_seed = (uint32_t)uni((int)h->agent_seed);
     if (status == BBX_ST_STARVED || status == BBX_ST_SPILL || status == BBX_ST_TIMESLICE) status = BBX_ST_OK;
     if (p.set_budget) budget = bbx_st_capacity(status) ? budget + p.nsteps : p.nsteps;   // (bbx_common.h: bbx_st_capacity)
-    if (p.pass == 1 && !(status == BBX_ST_OK && (need_reset || (budget > 0 && nP > 0)))) return;   // (whole workgroup)
+    if (p.pass == 1 && !(status == BBX_ST_OK && (need_reset || (budget > 0 && nP > 0)))) {         // (whole workgroup)
+      if (p.wide_tail == 1 && x.tid == 0) atomicAdd(p.wide_done, 1);
+      return;
+    }
     if (x.tid == 0) {
       st->total_steps = h->total_steps; st->total_adds = h->total_additions; st->alg_bytes = h->alg_bytes;
       st->vret = h->vret; st->vdisc = h->vdisc; st->last_reward = 0.0;
@@ -663,6 +666,17 @@ __device__ __forceinline__ void wide_body(char* smem) {
     }
     if (budget <= 0) break;
     if (nP == 0) break;
+    {
+      // first kernel of a two-kernel launch (BbxParams::wide_tail): once the workgroups still at work would fit one per CU,
+      // stop here, at a step boundary; the second kernel — no register cap, twice the LDS — takes the steps still owed
+      const BbxParams& p = wide_params();
+      if (p.wide_tail == 1) {
+        if (x.tid == 0) x.ctl->bc[6] = __hip_atomic_load(p.wide_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const int left = p.B - uni(x.ctl->bc[6]);
+        if (left <= p.wide_ncu) { status = BBX_ST_TIMESLICE; break; }
+      }
+    }
     if (x.tid == 0) st->rng_mark = st->std_rng;
     {
       const BbxParams& p = wide_params();
@@ -997,6 +1011,7 @@ __device__ __forceinline__ void wide_body(char* smem) {
       if (p.rewards && (steps_done > 0 || p.pass == 0)) p.rewards[env] = st->last_reward;
       if (p.dones) p.dones[env] = (uint8_t)((done_last || (nP == 0 && !need_reset)) ? 1 : 0);
       if (p.rows) p.rows[env] = nP;
+      if (p.wide_tail == 1) atomicAdd(p.wide_done, 1);
     }
   }
 #undef WPIN

@@ -24,8 +24,8 @@ extern "C" int bbx_launch_wide(const BbxParams* p, int nw, hipStream_t stream) {
       static int ncu = 0;
       if (!ncu) { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount; if (ncu <= 0) ncu = 256; }
       // one workgroup per CU while the batch fits that way (160 KB each), otherwise two per CU (80 KB each)
-      const bool one = q.B <= ncu;
-      one_per_cu = one || getenv("BBX_WIDE_UNCAPPED") != nullptr;
+      const bool one = q.B <= ncu || q.wide_tail == 2;     // (the tail kernel: the workgroups with work left fit one per CU)
+      one_per_cu = one;
       const size_t budget = one ? 160u * 1024u : 80u * 1024u;
       // (without the accumulator's two buffers the reducer table can hold twice as many reducers)
       q.wide_fc = one ? 1024 : 512; q.wide_rc = one ? (lazy ? 1024 : 2048) : (lazy ? 704 : 1024); q.wide_sc = lazy ? (one ? 1536 : 1024) : 0;
