@@ -135,8 +135,16 @@ struct WideCtx {
   int par_found, par_count, par_end;                      // parities of the exchange slots (advance once per use)
 #ifdef BBX_PROF_BUILD
   int prof_trips;
+  unsigned long long mt[5], ml;                           // merge phases: search, boundary exchange, sequential part, count exchange, stores
 #endif
 };
+#ifdef BBX_PROF_BUILD
+#define MSTAMP0() do { x.ml = __builtin_amdgcn_s_memtime(); } while (0)
+#define MSTAMP(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); x.mt[k] += t_ - x.ml; x.ml = t_; } while (0)
+#else
+#define MSTAMP0() do {} while (0)
+#define MSTAMP(k) do {} while (0)
+#endif
 
 // a value every lane holds alike (an LDS or memory load from a uniform address), pinned to scalar registers: the compiler
 // takes every load for per-lane, and with it each comparison, branch and counter that depends on one
@@ -170,6 +178,7 @@ __device__ __forceinline__ int wide_merge_seg(const AV& A, int na_, const BV& B,
   int ci = 0, cj = 0;                                     // merge-path boundary at the start of the current tile
   for (int base = 0; base < total; base += x.NT * SEG) {
     x.par_end = uni(x.par_end); x.par_count = uni(x.par_count);
+    MSTAMP0();
     // ---- my END boundary: (i1, j1), i1 + j1 = d, such that A[0..i1) and B[0..j1) are exactly the first d terms of the
     // merge (ties: the A term first); an equal pair is never split across a boundary
     int d = base + (x.tid + 1) * SEG; d = d < total ? d : total;
@@ -183,6 +192,7 @@ __device__ __forceinline__ int wide_merge_seg(const AV& A, int na_, const BV& B,
     }
     int i1 = lo, j1 = d - lo;
     if (i1 > 0 && j1 < nb && wk_eq(A.key(i1 - 1), B.key(j1))) j1++;
+    MSTAMP(0);
     // ---- my START boundary = the END boundary of the thread before me
     const int pe = x.par_end; x.par_end ^= 1;
     if (x.lane == 63) { x.ctl->wend[pe][x.wave][0] = i1; x.ctl->wend[pe][x.wave][1] = j1; }
@@ -193,6 +203,7 @@ __device__ __forceinline__ int wide_merge_seg(const AV& A, int na_, const BV& B,
       else { i0 = x.ctl->wend[pe][x.wave - 1][0]; j0 = x.ctl->wend[pe][x.wave - 1][1]; }
     }
     ci = uni(x.ctl->wend[pe][x.NW - 1][0]); cj = uni(x.ctl->wend[pe][x.NW - 1][1]);
+    MSTAMP(1);
     // ---- sequential merge of A[i0..i1) with B[j0..j1): at most SEG + 1 elements, at most SEG + 1 outputs
     K om[SEG + 1]; uint32_t oc[SEG + 1];
     int i = i0, j = j0;
@@ -214,6 +225,7 @@ __device__ __forceinline__ int wide_merge_seg(const AV& A, int na_, const BV& B,
       if (takeA) { i++; if (i < i1) { a = A.key(i); ac = A.coef(i); } }
       if (takeB || eq) { j++; if (j < j1) { b = B.key(j); bc = B.coef(j); } }
     }
+    MSTAMP(2);
     // ---- positions: thread-major, within a thread in merge order
     int prefix = 0, wtot = 0;
 #pragma unroll
@@ -233,11 +245,13 @@ __device__ __forceinline__ int wide_merge_seg(const AV& A, int na_, const BV& B,
       for (int w = 0; w < WNWMAX; w++) { woff += w < x.wave ? cw[w] : 0; ttot += cw[w]; }
     }
     int pos = nout + woff + prefix;
+    MSTAMP(3);
 #pragma unroll
     for (int s = 0; s <= SEG; s++) {
       if (oc[s] != 0) { if (pos < ocap) O.put(pos, om[s], oc[s]); pos++; }
     }
     nout = uni(nout + ttot);
+    MSTAMP(4);
   }
   return nout;
 }
@@ -478,6 +492,8 @@ __device__ __forceinline__ void wide_body(char* smem) {
   int par_any = 0;                                         // (eager variants only: the run scan's exchange slot)
 #ifdef BBX_PROF_BUILD
   x.prof_trips = 0;
+  for (int i = 0; i < 5; i++) x.mt[i] = 0;
+  x.ml = 0;
 #endif
   const int env = (int)blockIdx.x;
   const bool leader = x.wave == 0;
@@ -554,8 +570,6 @@ __device__ __forceinline__ void wide_body(char* smem) {
   // (scale * x^shift) * f[0..fn), f = arena terms [foff, foff + fn)  (polynomials.cpp:148-202).  Returns false on
   // overflow (status set).  All threads, uniform arguments; ends with the result complete and visible.
   auto poly_add = [&](bool to_s, bool from_s, int foff, int fn, const Mono<W>& shift, uint32_t scale) __attribute__((always_inline)) -> bool {
-    WPIN(hn); WPIN(hoff); WPIN(sn); WPIN(soff); WPIN(cur); WPIN(scur); WPIN(hbuf); WPINB(in_lds); WPIN(status);
-    WPIN(x.par_found); WPIN(x.par_count); WPIN(x.par_end);
     const BbxParams& p = wide_params();
     const Env<W> e = env_view<W>(WIDE_REC(p), p.L);
     const Mono<W>* const fm = e.am + foff; const uint16_t* const fc = e.ac + foff;
@@ -652,8 +666,6 @@ __device__ __forceinline__ void wide_body(char* smem) {
 
   for (;;) {
     WSTAMP(8);
-    WPIN(status); WPIN(need_reset); WPIN(budget); WPIN(nP); WPIN(nG); WPIN(arena_used); WPIN(t_agent); WPINB(table_dirty); WPIN(rcl);
-    WPIN(par_any); WPIN(x.par_found); WPIN(x.par_count); WPIN(x.par_end);
     if (status != BBX_ST_OK) break;
     if (need_reset) {                                                         // leader alone (once per episode), wave-level code
       if (leader) wide_leader_reset<W>(&wide_params(), x.ctl, env);
@@ -773,9 +785,6 @@ __device__ __forceinline__ void wide_body(char* smem) {
       __syncthreads();
     };
     for (;;) {
-      WPIN(hn); WPIN(hoff); WPIN(hsug); WPIN(cur); WPIN(hbuf); WPIN(hw0); WPIN(hwn); WPIN(sn); WPIN(soff); WPIN(scur); WPINB(in_lds);
-      WPIN(nsteps_red); WPIN(rn); WPIN(rsug); WPIN(rflushed); WPINB(first); WPIN(status);
-      WPIN(par_any); WPIN(x.par_found); WPIN(x.par_count); WPIN(x.par_end);
       int fn, foff, found = -1, an = 0;
       Mono<W> shift; uint32_t scale;
       if (first) { foff = sp_foff; fn = sp_fn; shift = sp_shift; scale = sp_scale; }
@@ -991,6 +1000,7 @@ __device__ __forceinline__ void wide_body(char* smem) {
     const int tslot[6] = {2, 4, 20, 22, 5, 8}, cslot[7] = {10, 13, 23, 24, 25, 15, 31};
     for (int i = 0; i < 6; i++) atomicAdd(&bbx_wide_prof_acc[tslot[i]], wprof[i]);
     for (int i = 0; i < 7; i++) atomicAdd(&bbx_wide_prof_acc[cslot[i]], wcnt[i]);
+    for (int i = 0; i < 5; i++) atomicAdd(&bbx_wide_prof_acc[26 + i], x.mt[i]);
   }
 #endif
   {

@@ -33,3 +33,9 @@ scans = max(1.0, a[10] + a[13])
 print("tier-1 rewrites %d  accumulator merges %d  tail-moves %d | scans: trips/scan %.2f  mean found index %.0f  mean |G| %.0f" %
       (a[10], a[15], a[13], a[23] / scans, a[24] / max(1.0, scans - a[13]), a[25] / scans))
 print("cycles (100 MHz s_memtime ticks x 21) per reduction round: %.0f ticks" % (tot / scans))
+mn = ["search of the diagonal", "boundary exchange + barrier", "sequential merge", "ballots + count exchange + barrier", "stores"]
+mt = sum(a[26 + i] for i in range(5))
+if mt > 0:
+    print("inside the merges (%.1f %% of the phases above):" % (100 * mt / tot))
+    for i in range(5):
+        print("  %-36s %6.2f %%" % (mn[i], 100 * a[26 + i] / mt))
