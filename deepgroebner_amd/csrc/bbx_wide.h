@@ -39,6 +39,7 @@ typedef uint32_t bbx_u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t bbx_u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int WSEG = 4;                                   // merged positions per thread per tile
+constexpr int WSEG_SHORT = 2;                             // ... of short merges (see wide_merge)
 constexpr int WNWMAX = 8;                                 // waves per workgroup (512 threads)
 constexpr int WRB = 256;                                  // terms of the remainder r buffered in LDS between flushes to the arena
 
@@ -54,6 +55,7 @@ struct WideCold {
 struct __attribute__((aligned(16))) WideCtl {             // LDS control block (parity double-buffered exchange slots)
   int wfound[2][WNWMAX];                                  // per-wave first divisor of a scan chunk (absent waves: INT_MAX)
   int wcount[2][WNWMAX];                                  // per-wave output count of a merge tile (absent waves: 0)
+  int wcnt4[2][4][WNWMAX];                                // per-wave output counts of the four sub-tiles of a per-element merge tile
   int wend[2][WNWMAX][2];                                 // per-wave last merge-path boundary of a tile
   int wany[2][WNWMAX];                                    // per-wave mask of scan candidates with a divisor (absent waves: 0)
   int bc[16];                                             // values the leader wave publishes to the workgroup
@@ -256,9 +258,107 @@ __device__ __forceinline__ int wide_merge_seg(const AV& A, int na_, const BV& B,
   return nout;
 }
 
+// The same merge for two polynomials held as keys in LDS, one OUTPUT position per thread and sub-tile: thread t of sub-tile k
+// searches the diagonal d = base + k NT + t of the merge path — i = the number of A terms among the first d of the merge,
+// ties to A — and the term at position d is then A[i] or B[d - i] by one comparison: A[i] with the coefficients summed when
+// B[d - i] is the same monomial, nothing when it is a B term whose monomial A[i - 1] already carried.  No boundary travels
+// between neighbouring threads and no thread merges sequentially: per tile one exchange (the waves' counts) instead of two,
+// and the K searches of a thread run interleaved (K loads in flight per trip to LDS).
+template <int K, class OV>
+__device__ __forceinline__ int wide_merge_el(const LdsKeys& A, int na_, const LdsKeys& B, int nb_, const OV& O, int nout_, int ocap_, WideCtx& x) {
+  const int na = uni(na_), nb = uni(nb_), ocap = uni(ocap_);
+  int nout = uni(nout_);
+  const int total = na + nb;
+  for (int base = 0; base < total; base += x.NT * K) {
+    x.par_count = uni(x.par_count);
+    MSTAMP0();
+    int lo[K], hi[K], dd[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      const int d = base + k * x.NT + x.tid;
+      dd[k] = d < total ? d : total;
+      lo[k] = dd[k] - nb > 0 ? dd[k] - nb : 0; hi[k] = dd[k] < na ? dd[k] : na;
+    }
+    for (;;) {
+      bool any = false;
+      uint64_t ak[K], bk[K];
+#pragma unroll
+      for (int k = 0; k < K; k++) {
+        const bool go = lo[k] < hi[k];
+        any = any || go;
+        const int mid = (lo[k] + hi[k]) >> 1;
+        ak[k] = A.key(go ? mid : 0); bk[k] = B.key(go ? dd[k] - 1 - mid : 0);
+      }
+      if (!any) break;
+#pragma unroll
+      for (int k = 0; k < K; k++) {
+        const bool go = lo[k] < hi[k];
+        const int mid = (lo[k] + hi[k]) >> 1;
+        if (go) { if (ak[k] >= bk[k]) lo[k] = mid + 1; else hi[k] = mid; }       // A[mid] is among the first d terms of the merge
+      }
+    }
+    MSTAMP(0);
+    uint64_t om[K]; uint32_t oc[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      const int i = lo[k], j = dd[k] - lo[k];
+      const bool ha = i < na, hb = j < nb;
+      const uint64_t a = A.key(ha ? i : 0), b = B.key(hb ? j : 0), ap = A.key(i > 0 ? i - 1 : 0);
+      const uint32_t ca = A.coef(ha ? i : 0), cb = B.coef(hb ? j : 0);
+      const bool takeA = ha && (!hb || a >= b);
+      uint32_t c;
+      if (takeA) c = (hb && a == b) ? addmod(ca, cb) : ca;
+      else c = (hb && !(i > 0 && ap == b)) ? cb : 0u;
+      om[k] = takeA ? a : b;
+      oc[k] = base + k * x.NT + x.tid < total ? c : 0u;               // 0: nothing here (beyond the end, merged into A, or cancelled)
+    }
+    MSTAMP(2);
+    int prefix[K], wtot[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      const uint64_t mk = ballot64(oc[k] != 0);
+      prefix[k] = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+      wtot[k] = __popcll(mk);
+    }
+    const int pc = x.par_count; x.par_count ^= 1;
+    if (x.lane == 0) {
+#pragma unroll
+      for (int k = 0; k < K; k++) x.ctl->wcnt4[pc][k][x.wave] = wtot[k];
+    }
+    __syncthreads();
+    int pos0 = nout;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      const bbx_i32x4 c0 = *(BBX_AS3 bbx_i32x4*)&x.ctl->wcnt4[pc][k][0], c1 = *(BBX_AS3 bbx_i32x4*)&x.ctl->wcnt4[pc][k][4];
+      const int cw[WNWMAX] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+      int woff = 0, ttot = 0;
+#pragma unroll
+      for (int w = 0; w < WNWMAX; w++) { woff += w < x.wave ? cw[w] : 0; ttot += cw[w]; }
+      const int pos = pos0 + woff + prefix[k];
+      if (oc[k] != 0 && pos < ocap) O.put(pos, om[k], oc[k]);
+      pos0 = uni(pos0 + ttot);
+    }
+    MSTAMP(3);
+    nout = pos0;
+    MSTAMP(4);
+  }
+  return nout;
+}
+
 // SEG merged positions per thread per tile: short merges (the common case when one environment owns the whole device:
 // a few hundred terms) are spread over more threads, which shortens each thread's sequential part
-constexpr int WSEG_SHORT = 2;
+#ifndef BBX_WIDE_SEGMERGE
+template <class OV>
+__device__ __forceinline__ int wide_merge(const LdsKeys& A, int na, const LdsKeys& B, int nb, const OV& O, int nout, int ocap, WideCtx& x) {
+  // (one position per thread while the merge fits one tile that way: the Degree run of cyclic-7 5.77 -> 5.50 s; long merges
+  // keep one search per SEG positions — a search per output position costs more than it saves there: with K = 2 / 4 sub-tiles
+  // cyclic-7 under the random agent ran at 37.7 k instead of 42.6 k env-steps/s, the Degree run at 5.82 s with K = 2)
+  const int total = uni(na + nb);
+  if (total <= x.NT) return wide_merge_el<1>(A, na, B, nb, O, nout, ocap, x);
+  if (total <= x.NT * WSEG_SHORT) return wide_merge_seg<WSEG_SHORT>(A, na, B, nb, O, nout, ocap, x);
+  return wide_merge_seg<WSEG>(A, na, B, nb, O, nout, ocap, x);
+}
+#endif
 template <class AV, class BV, class OV>
 __device__ __forceinline__ int wide_merge(const AV& A, int na, const BV& B, int nb, const OV& O, int nout, int ocap, WideCtx& x) {
   if (uni(na + nb) <= x.NT * WSEG_SHORT) return wide_merge_seg<WSEG_SHORT>(A, na, B, nb, O, nout, ocap, x);
@@ -541,6 +641,7 @@ __device__ __forceinline__ void wide_body(char* smem) {
     }
   }
   if (x.tid < 2 * WNWMAX) { (&x.ctl->wfound[0][0])[x.tid] = 0x7fffffff; (&x.ctl->wcount[0][0])[x.tid] = 0; (&x.ctl->wany[0][0])[x.tid] = 0; }
+  if (x.tid < 2 * 4 * WNWMAX) (&x.ctl->wcnt4[0][0][0])[x.tid] = 0;
   __syncthreads();
   bool table_dirty = true;
   int rcl = 0;                                                                // reducers staged in LDS
@@ -792,8 +893,22 @@ __device__ __forceinline__ void wide_body(char* smem) {
         // ---- the lead term of h = H + S leaves h (it is either cancelled by the reducer or moved to r)
         Mono<W> lmh; uint32_t lch = 0;
         bool zero = false;
-        const Mono<W>* slm_g;
-        { const BbxParams& p = wide_params(); slm_g = (const Mono<W>*)(WIDE_REC(p) + p.L.off_slm); }
+        if (W <= 4 && in_lds && wide_keys_ok<W>(hsug)) {
+          // the common case — H in LDS as keys — without a branch per case: both heads come in one trip to LDS, an exhausted
+          // side reads as key 0 (below every key), the larger head leaves h (both when the monomials agree)
+          const LdsKeys Hc = T.off(cur * HC), Sc = WIDE_SACC(scur);
+          for (;;) {
+            const bool hH = hoff < hn, hS = LAZY && soff < sn;
+            if (!hH && !hS) { zero = true; break; }
+            uint64_t kH = Hc.key(hH ? hoff : 0), kS = LAZY ? Sc.key(hS ? soff : 0) : 0;
+            uint32_t cH = Hc.coef(hH ? hoff : 0), cS = LAZY ? Sc.coef(hS ? soff : 0) : 0;
+            kH = hH ? uni64(kH) : 0; kS = hS ? uni64(kS) : 0; cH = uni(cH); cS = uni(cS);
+            const bool fromH = kH >= kS, fromS = kS >= kH;
+            lch = addmod(fromH ? cH : 0u, fromS ? cS : 0u);
+            hoff += fromH ? 1 : 0; soff += fromS ? 1 : 0;
+            if (lch != 0) { lmh = wide_unkey<W>(fromH ? kH : kS); break; }   // (a zero sum: the term does not exist)
+          }
+        } else
         for (;;) {
           const bool hH = hoff < hn, hS = LAZY && soff < sn;
           if (!hH && !hS) { zero = true; break; }
@@ -829,6 +944,8 @@ __device__ __forceinline__ void wide_body(char* smem) {
 #pragma unroll
         for (int q = 0; q < W; q++) lmh.w[q] = (uint32_t)uni((int)lmh.w[q]);
         lch = (uint32_t)uni((int)lch);
+        const Mono<W>* slm_g = nullptr;                                       // (reducers beyond the LDS table: rare)
+        if (nG > rcl) { const BbxParams& p = wide_params(); slm_g = (const Mono<W>*)(WIDE_REC(p) + p.L.off_slm); }
         found = wide_find_divisor<W>(R, rcl, slm_g, nG, lmh, x);
         WSTAMP(2);
 #ifdef BBX_PROF_BUILD
