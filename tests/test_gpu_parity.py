@@ -794,6 +794,53 @@ def test_wide_class_lockstep_stress(waves, lean):
             del env
 
 
+def test_wide_class_two_kernel_launch_for_more_workgroups_than_cus():
+    """A wide-class launch of more workgroups than the device has CUs is two kernels (BbxParams::wide_tail): the first runs two
+    workgroups per CU and stops — at step boundaries, BBX_ST_TIMESLICE — once the workgroups still at work would fit one per
+    CU; the second takes the steps still owed.  Nothing of that may show: every environment of a batch of 300 against the
+    oracle (counters of all, complete states of a sample), lean and accounting variants, and the same batch with the second
+    kernel switched off; the general class's hand-over of long polynomials (5-4-4-1.0-uniform) likewise."""
+    import os
+    from deepgroebner_amd import VecLeadMonomialsEnv
+    bo = ffi.load("bo")
+    B, T, k = 300, 100, 1
+    want = bo.run_random_many("cyclic-6", k, [0] * B, range(B), T, True, 0)
+    for lean, tail in ((1, 1), (0, 1), (1, 0)):
+        if not tail:
+            os.environ["BBX_NO_WIDE_TAIL"] = "1"
+        try:
+            env = VecLeadMonomialsEnv("cyclic-6", batch=B, k=k)
+            env.seed_agent(np.arange(B)); env.reset()
+            if lean:
+                env.accounting(False)
+            env.timing(True)
+            env.rollout("random", T, auto_reset=True)
+            _, launches = env.timing(False)
+        finally:
+            os.environ.pop("BBX_NO_WIDE_TAIL", None)
+        assert launches == (2 if tail else 1), (lean, tail, launches)
+        st = env.stats()
+        assert (st[:, 4] == 0).all()
+        for key, col in (("steps", 0), ("additions", 1), ("episodes", 2), ("zero_reductions", 3), ("nG", 7)):
+            assert np.array_equal(st[:, col], np.array([r[key] for r in want])), (lean, tail, key)
+        for e in list(range(0, B, 23)) + [int(st[:, 1].argmax())]:      # (the slowest environment certainly went through the second kernel)
+            assert fnv64(_state_words(*env.state(e))) == want[e]["state_hash"], (lean, tail, e)
+        del env
+    B, T, k = 320, 48, 2
+    seeds = list(range(1000, 1000 + B))
+    want = bo.run_random_many("5-4-4-1.0-uniform", k, seeds, range(B), T, True, 0)
+    env = VecLeadMonomialsEnv("5-4-4-1.0-uniform", batch=B, k=k)
+    env.seed(np.array(seeds)); env.seed_agent(np.arange(B)); env.reset(); env.accounting(False)
+    env.rollout("random", T, auto_reset=True)
+    st = env.stats()
+    assert (st[:, 4] == 0).all()
+    for key, col in (("steps", 0), ("additions", 1), ("episodes", 2), ("zero_reductions", 3), ("nG", 7)):
+        assert np.array_equal(st[:, col], np.array([r[key] for r in want])), key
+    for e in list(range(0, B, 37)) + [int(st[:, 1].argmax())]:
+        assert fnv64(_state_words(*env.state(e))) == want[e]["state_hash"], e
+
+
+
 def test_wide_class_32_byte_monomials_cyclic8():
     """cyclic-8 lives in the reference's full N = 8 ring (polynomials.h:29): 32-byte monomials have no 8-byte sort key, so the
     wide class runs its unkeyed regime throughout (h as plain monomials in the record's scratch, merges on HBM-resident
