@@ -101,6 +101,7 @@ SIGNATURES = {
     "bbx_join": (C.c_int, [_vp, _vp]),
     "bbx_graph_replayed": (C.c_int, [_vp, _vp]),
     "bbx_session_stats": (C.c_int, [_vp, _vp]),
+    "bbx_kernels_launched": (C.c_int, [_vp, _vp]),
     "bbx_state_sizes": (C.c_int, [_vp, C.c_int, _i32p, _i32p, _i32p]),
     "bbx_state_get": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     "bbx_reduced_basis": (C.c_int, [_vp, C.c_int, _i32p, _i32p, _vp, _vp, _vp]),

@@ -308,6 +308,12 @@ class VecLeadMonomialsEnv:
         _ffi.check(_ffi.lib().bbx_session_stats(self._h, _ffi.ptr(out)))
         return dict(zip(("sessions", "joined", "later_kernel_steps", "kernels", "spills"), (int(v) for v in out)))
 
+    def kernels_launched(self):
+        """Step / reset / observation kernels launched for this batch so far (bbx_kernels_launched)."""
+        out = np.zeros(1, dtype=np.int64)
+        _ffi.check(_ffi.lib().bbx_kernels_launched(self._h, _ffi.ptr(out)))
+        return int(out[0])
+
     def join(self, stream=0):
         """Device-side end of the persistent session in flight: `stream` waits for it (the host does not)."""
         _ffi.check(_ffi.lib().bbx_join(self._h, C.c_void_p(int(stream))))

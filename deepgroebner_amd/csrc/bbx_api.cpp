@@ -228,14 +228,6 @@ int enqueue(bbx_batch* b, const BbxParams& p0, bool resume, hipStream_t stream) 
     kinds[nk++] = 0; kinds[nk++] = 4;                 // workgroup-per-environment kernel for the environments whose polynomials got long
     p.spill_terms = 384;
   }
-  // wide class with more workgroups than CUs: a second kernel for the tail of the launch (BbxParams::wide_tail)
-  int tail_at = -1;
-  if (nk > 0 && kinds[nk - 1] == 4 && nk < 3 && b->ncu > 0 && b->B > b->ncu && p.L.W <= 4 && !getenv("BBX_NO_WIDE_TAIL")) {
-    if (!b->d_wide_done) HIPCHK(hipMalloc((void**)&b->d_wide_done, 256));
-    HIPCHK(hipMemsetAsync(b->d_wide_done, 0, 256, stream));
-    tail_at = nk; kinds[nk++] = 4;
-    p.wide_done = b->d_wide_done; p.wide_ncu = b->ncu;
-  }
   else {   // the hand-tuned kernel knows the external / random / degree / first agents; the others take the class kernel
     const bool pol_hbm_only = p.policy && p.policy->rollout == 2;     // a policy rollout outside the register/LDS class
     if (b->staged && !pol_hbm_only) kinds[nk++] = (b->fast && p.agent <= BBX_AGENT_FIRST) ? 3 : 1;
@@ -244,6 +236,14 @@ int enqueue(bbx_batch* b, const BbxParams& p0, bool resume, hipStream_t stream) 
     // finish() continues it (one launch less on the latency path)
     // (asynchronous calls on caller buffers always get it: nobody polls their status words between steps)
     if (!b->staged || pol_hbm_only || resume || p.nsteps > 1 || b->obs_external || b->device_async) kinds[nk++] = 0;
+  }
+  // wide class with more workgroups than CUs: a second kernel for the tail of the launch (BbxParams::wide_tail)
+  int tail_at = -1;
+  if (nk > 0 && kinds[nk - 1] == 4 && nk < 3 && b->ncu > 0 && b->B > b->ncu && p.L.W <= 4 && !getenv("BBX_NO_WIDE_TAIL")) {
+    if (!b->d_wide_done) HIPCHK(hipMalloc((void**)&b->d_wide_done, 256));
+    HIPCHK(hipMemsetAsync(b->d_wide_done, 0, 256, stream));
+    tail_at = nk; kinds[nk++] = 4;
+    p.wide_done = b->d_wide_done; p.wide_ncu = b->ncu;
   }
   // a host-driven zero-copy step whose only kernel is the hand-tuned one: the host spins on the status words in pinned
   // memory instead of waiting for the runtime's completion signal (read_lite)
@@ -272,6 +272,7 @@ int enqueue(bbx_batch* b, const BbxParams& p0, bool resume, hipStream_t stream) 
     }
     int lrc = bbx_launch_step(&p, kinds[i], kinds[i] == 4 ? (b->wide ? b->wide : 8) : b->envs_per_block, stream);
     if (lrc) return fail(BBX_E_DEVICE, "kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
+    b->step_kernels++;
     if (timed) { HIPCHK(hipEventRecord(e1, stream)); b->ev_open.push_back({e0, e1}); }
   }
   return BBX_OK;

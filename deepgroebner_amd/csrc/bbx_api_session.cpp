@@ -332,6 +332,12 @@ int bbx_session_stats(bbx_batch* b, int64_t* out5) {   // out: 5 values
   return BBX_OK;
 }
 
+int bbx_kernels_launched(bbx_batch* b, int64_t* out) {
+  if (!b || !out) return fail(BBX_E_ARG, "null argument");
+  *out = b->step_kernels;
+  return BBX_OK;
+}
+
 int bbx_join(bbx_batch* b, void* stream) {
   if (!b) return fail(BBX_E_ARG, "null argument");
   HIPCHK(hipSetDevice(b->device)); b->api_epoch++;

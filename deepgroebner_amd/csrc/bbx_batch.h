@@ -125,6 +125,7 @@ struct bbx_batch {
   bool gen_to_wide = false;           // general class with <= 16-byte monomials: long-polynomial environments continue in the wide class
   bool no_growth = false;             // bbx_caps.no_growth: the configured capacities are hard limits (BBX_E_CAPACITY)
   int grow_events = 0;                // times the records were enlarged (bbx_capacities)
+  long long step_kernels = 0;         // kernels enqueue() has launched for this handle (bbx_kernels_launched: what a call costs in launches)
   bbx_batch() = default;
   bbx_batch(const bbx_batch&) = delete;
   bbx_batch& operator=(const bbx_batch&) = delete;

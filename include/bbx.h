@@ -269,6 +269,10 @@ int bbx_join(bbx_batch* b, void* stream);
  *         environments that left the register/LDS-resident class (basis beyond 256 elements / 512 pairs) and were continued
  *         by the HBM-resident pass: counted while sessions are enabled} */
 int bbx_session_stats(bbx_batch* b, int64_t* out5);
+/* Step / reset / observation kernels launched for the handle so far (the kernels of one call: the class's kernel, the
+ * continuation pass behind it where the class has one, the second kernel of a wide-class launch of more workgroups than CUs):
+ * what a call costs in launches, for tests and for callers who budget them.  No reference counterpart. */
+int bbx_kernels_launched(bbx_batch* b, int64_t* out);
 
 /* ---- HIP graphs ---------------------------------------------------------------------------------------------------------
  * The asynchronous device calls (bbx_step_device[_autoreset], bbx_rollout_device, bbx_policy_step_device,

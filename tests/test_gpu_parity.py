@@ -794,6 +794,38 @@ def test_wide_class_lockstep_stress(waves, lean):
             del env
 
 
+def test_kernels_per_call():
+    """What a call costs in launches (bbx_kernels_launched): one kernel for a reset (the Python reset() is two calls: the reset
+    and the observation it returns), for a host-driven step of a small batch and for a rollout of a class without a
+    continuation pass; two where the register/LDS class has the HBM-resident pass behind it, where
+    the general class hands long polynomials to the wide class, and for a wide-class launch of more workgroups than CUs.  (A
+    misplaced `else` once added the classes' kernels to every launch: nothing failed, every call paid for it.)"""
+    from deepgroebner_amd import VecLeadMonomialsEnv
+    def cost(env, fn):
+        k0 = env.kernels_launched(); fn(); env.sync(); return env.kernels_launched() - k0
+    env = VecLeadMonomialsEnv("3-20-10-weighted", batch=64, k=2)
+    env.seed(np.arange(64)); env.accounting(False)
+    assert cost(env, env.reset) == 2
+    assert cost(env, lambda: env.rollout("random", 16, auto_reset=True)) == 2          # fast class + HBM-resident continuation
+    small = VecLeadMonomialsEnv("3-20-10-weighted", batch=4, k=2)
+    small.seed(np.arange(4)); small.accounting(False); small.reset()
+    assert cost(small, lambda: small.step(np.zeros(4, dtype=np.int32))) == 1            # zero-copy host step: the hand-tuned kernel alone
+    u5 = VecLeadMonomialsEnv("5-10-5-uniform", batch=64, k=2)
+    u5.seed(np.arange(64)); u5.accounting(False)
+    assert cost(u5, u5.reset) == 2
+    assert cost(u5, lambda: u5.rollout("random", 16, auto_reset=True)) == 1             # HBM-resident binomial class
+    cyc = VecLeadMonomialsEnv("cyclic-6", batch=8, k=1)
+    assert cost(cyc, cyc.reset) == 2
+    assert cost(cyc, lambda: cyc.rollout("random", 8, auto_reset=True)) == 1            # wide class, one workgroup per CU
+    big = VecLeadMonomialsEnv("cyclic-6", batch=300, k=1)
+    big.reset()
+    assert cost(big, lambda: big.rollout("random", 4, auto_reset=True)) == 2            # ... more workgroups than CUs
+    gen = VecLeadMonomialsEnv("3-5-4-0.5-uniform", batch=64, k=2)
+    gen.seed(np.arange(64))
+    assert cost(gen, gen.reset) == 2
+    assert cost(gen, lambda: gen.rollout("random", 8, auto_reset=True)) == 2            # general class + wide class behind it
+
+
 def test_wide_class_two_kernel_launch_for_more_workgroups_than_cus():
     """A wide-class launch of more workgroups than the device has CUs is two kernels (BbxParams::wide_tail): the first runs two
     workgroups per CU and stops — at step boundaries, BBX_ST_TIMESLICE — once the workgroups still at work would fit one per
