@@ -545,7 +545,7 @@ int finish_impl(bbx_batch* b, hipStream_t stream) {
     for (int e = 0; e < b->B; e++)
       if (b->h_lite[(size_t)e * 4] & BBX_LITE_OBS_TRUNC)
         return fail(BBX_E_CAPACITY, "environment %d: an observation had more rows than the caller's block holds (obs_rows = %d) or, in a policy "
-                                    "rollout, than the policy kernels score (1024); the extra rows were not written / scored", e, b->last.obs_rows);
+                                    "rollout, than the policy kernels score (%d); the extra rows were not written / scored", e, b->last.obs_rows, BBX_POLICY_MAX_ROWS);
   return err;
 }
 
@@ -1133,7 +1133,7 @@ int bbx_pmlp_act(const int32_t* d_obs, const int32_t* d_rows, int batch, int obs
                  const float* d_u, int32_t* d_actions, float* d_logprobs, void* stream) {
   if (!d_obs || !d_rows || !d_prepared || !d_u || !d_actions || !d_logprobs) return fail(BBX_E_ARG, "null argument");
   if (batch < 1 || obs_rows < 1) return fail(BBX_E_ARG, "bad policy shape");
-  if (obs_rows > 1024) return fail(BBX_E_UNSUPPORTED, "the policy kernels score at most 1024 rows per environment (obs_rows = %d)", obs_rows);
+  if (obs_rows > BBX_POLICY_MAX_ROWS) return fail(BBX_E_UNSUPPORTED, "the policy kernels score at most %d rows per environment (obs_rows = %d)", BBX_POLICY_MAX_ROWS, obs_rows);
   if (bbx_pmlp_prepared_floats(cols, hidden) < 0) return BBX_E_UNSUPPORTED;
   int lrc = bbx_launch_pmlp_act(d_obs, d_rows, batch, obs_rows, cols, d_prepared, hidden, d_u, d_actions, d_logprobs, (hipStream_t)stream);
   if (lrc) return fail(BBX_E_DEVICE, "policy launch failed: %s", hipGetErrorString((hipError_t)lrc));
@@ -1157,7 +1157,7 @@ static int pmlp_deep_act(const int32_t* d_obs, const int32_t* d_rows, int batch,
                          bool three, const float* d_u, int32_t* d_actions, float* d_logprobs, void* stream) {
   if (!d_obs || !d_rows || !d_prepared || !d_u || !d_actions || !d_logprobs) return fail(BBX_E_ARG, "null argument");
   if (batch < 1 || obs_rows < 1) return fail(BBX_E_ARG, "bad policy shape");
-  if (obs_rows > 1024) return fail(BBX_E_UNSUPPORTED, "the policy kernels score at most 1024 rows per environment (obs_rows = %d)", obs_rows);
+  if (obs_rows > BBX_POLICY_MAX_ROWS) return fail(BBX_E_UNSUPPORTED, "the policy kernels score at most %d rows per environment (obs_rows = %d)", BBX_POLICY_MAX_ROWS, obs_rows);
   if (pmlp_deep_floats(cols, h1, hm, h2, three) < 0) return BBX_E_UNSUPPORTED;
   int dev = 0, cus = 0, max_lds = 0;
   HIPCHK(hipGetDevice(&dev));
@@ -1222,7 +1222,7 @@ int bbx_policy_step_device(bbx_batch* b, const float* d_prepared, int hidden, co
                            double* d_rewards, uint8_t* d_dones, int32_t* d_rows, int32_t* d_obs, int obs_rows, int obs_fill, void* stream) {
   if (!b || !d_prepared || !d_u || !d_actions || !d_logprobs || !d_rows || !d_obs) return fail(BBX_E_ARG, "null argument");
   if (obs_rows < 1) return fail(BBX_E_ARG, "obs_rows must be positive");
-  if (obs_rows > 1024) return fail(BBX_E_UNSUPPORTED, "the policy kernels score at most 1024 rows per environment (obs_rows = %d)", obs_rows);
+  if (obs_rows > BBX_POLICY_MAX_ROWS) return fail(BBX_E_UNSUPPORTED, "the policy kernels score at most %d rows per environment (obs_rows = %d)", BBX_POLICY_MAX_ROWS, obs_rows);
   HIPCHK(hipSetDevice(b->device)); b->api_epoch++;
   const int cols = 2 * b->nvars * b->k;
   if (bbx_pmlp_prepared_floats(cols, hidden) < 0) return BBX_E_UNSUPPORTED;
@@ -1261,7 +1261,7 @@ int bbx_policy_rollout_device(bbx_batch* b, const float* d_prepared, int hidden,
                               long long obs_step_stride, void* stream) {
   if (!b || !d_prepared || !d_u || !d_actions || !d_logprobs) return fail(BBX_E_ARG, "null argument");
   if (nsteps < 1 || (d_obs && obs_rows < 1) || obs_step_stride < 0) return fail(BBX_E_ARG, "bad rollout arguments");
-  if (d_obs && obs_rows > 1024) return fail(BBX_E_UNSUPPORTED, "the policy kernels score at most 1024 rows per environment (obs_rows = %d)", obs_rows);
+  if (d_obs && obs_rows > BBX_POLICY_MAX_ROWS) return fail(BBX_E_UNSUPPORTED, "the policy kernels score at most %d rows per environment (obs_rows = %d)", BBX_POLICY_MAX_ROWS, obs_rows);
   const int cols = 2 * b->nvars * b->k;
   if (bbx_pmlp_prepared_floats(cols, hidden) < 0) return BBX_E_UNSUPPORTED;
   // where the policy is built into the step kernels: binomial classes with 8- or 16-byte monomials, 33..128 hidden units,
@@ -1277,7 +1277,7 @@ int bbx_policy_rollout_device(bbx_batch* b, const float* d_prepared, int hidden,
   BbxPolicy pol{d_prepared, hidden, d_u, d_actions, d_logprobs, 1, d_rewards, d_dones, d_rows, obs_step_stride, b->B, 0};
   BbxParams p; fill_params(b, &p);
   p.nsteps = nsteps; p.set_budget = 1; p.agent = BBX_AGENT_EXTERNAL; p.auto_reset = 1;
-  p.obs = d_obs; p.obs_rows = obs_rows; p.obs_fill = 0;
+  p.obs = d_obs; p.obs_rows = d_obs ? obs_rows : 0; p.obs_fill = 0;   // (no block: the kernels size their logits for every row they score)
   p.trace = nullptr;
   p.policy = &pol;
   // the register/LDS-resident kernel has the policy for 3 variables and k = 2; every other admitted shape runs in the

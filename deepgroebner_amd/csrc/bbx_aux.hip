@@ -269,7 +269,7 @@ extern "C" int bbx_launch_pmlp_prepare(const float* w1, const float* b1, const f
 extern "C" int bbx_launch_pmlp_act(const int32_t* obs, const int32_t* rows, int B, int obs_rows, int cols, const float* wp, int hidden, const float* u,
                                    int32_t* actions, float* logprobs, hipStream_t stream) {
   const int waves = 4, nb = pmlp_nb_for(hidden), ks = pmlp_ks_for(cols);
-  const size_t ml = pmlp_lds_bytes(waves);
+  const size_t ml = pmlp_lds_bytes(waves, obs_rows);
 #define BBX_PMLP_MFMA(N, K) hipLaunchKernelGGL((bbx_pmlp_act_mfma_kernel<N, K>), dim3((B + waves - 1) / waves), dim3(waves * WAVE), ml, stream, obs, rows, B, \
                                                 obs_rows, cols, wp, u, actions, logprobs)
 #define BBX_PMLP_MFMA_K(N) do { if (ks == 3) BBX_PMLP_MFMA(N, 3); else if (ks == 6) BBX_PMLP_MFMA(N, 6); else if (ks == 10) BBX_PMLP_MFMA(N, 10); \

@@ -427,6 +427,10 @@ __device__ uint64_t bin_poly_hash(const EnvB& e, int g) {
   return wave_sum64(h);
 }
 
+// per-wave LDS scratch of the policy instantiations: the update's peel scratch, or the logits where those need more
+template <int W> __host__ __device__ constexpr size_t binom_scratch_bytes(int obs_rows) {
+  return (size_t)update_lds_bytes<W>() > sizeof(float) * (size_t)pmlp_lgcap(obs_rows) ? (size_t)update_lds_bytes<W>() : sizeof(float) * (size_t)pmlp_lgcap(obs_rows);
+}
 // POL > 0 (HBM-resident instantiation only): a policy rollout (bbx_policy_rollout_device) — the per-step protocol of
 // fast_body POL (bbx_fast.h), rows gathered from the record — either as the continuation pass for environments that
 // outgrew the register/LDS-resident class or as the rollout kernel of a batch that is not in that class.  POL = unit
@@ -494,7 +498,8 @@ __device__ __forceinline__ void binom_body(const BbxParams& p_entry, char* smem,
   const bool tracing = TRACE && p.trace != nullptr;
   const int obs_term_bytes = 4 * 2 * p.nvars * p.k;
   // HBM-resident instantiation: the launcher provides one Gebauer-Moeller peel scratch per wave in LDS
-  char* const peel_lds = (!STAGED && !CACHE && smem != nullptr) ? smem + (size_t)wave_in_block * update_lds_bytes<W>() : nullptr;
+  // (policy kernels: the scratch also holds the logits of up to pmlp_lgcap(obs_rows) rows — binom_scratch_bytes)
+  char* const peel_lds = (!STAGED && !CACHE && smem != nullptr) ? smem + (size_t)wave_in_block * (POL > 0 ? binom_scratch_bytes<W>(p.obs_rows) : (size_t)update_lds_bytes<W>()) : nullptr;
 #ifdef BBX_PROF_BUILD
   unsigned long long bprof[32] = {0};
   unsigned long long blast = __builtin_amdgcn_s_memtime();

@@ -21,7 +21,8 @@ static int launch_binom_w(const BbxParams* p, int kind, int blocks, int threads,
       if (p->policy && p->policy->rollout) {               // a policy rollout: its continuation pass, or the whole of it
         BbxParams q = *p; q.policy = nullptr; q.actions = nullptr; q.rewards = nullptr; q.dones = nullptr; q.rows = nullptr; q.obs_every_step = 0;
         const int nb = pmlp_nb_for(p->policy->hidden), ks = pmlp_ks_for(2 * p->nvars * p->k);
-#define BBX_BPOL(NBV, KSV) hipLaunchKernelGGL((bbx_binom_policy_kernel<W, NBV, KSV>), dim3(blocks), dim3(threads), lds, stream, q, *p->policy)
+        const size_t lds_pol = (size_t)(threads / WAVE) * binom_scratch_bytes<W>(q.obs_rows);
+#define BBX_BPOL(NBV, KSV) hipLaunchKernelGGL((bbx_binom_policy_kernel<W, NBV, KSV>), dim3(blocks), dim3(threads), lds_pol, stream, q, *p->policy)
         if (ks == 6) { if (nb == 2) BBX_BPOL(2, 6); else BBX_BPOL(4, 6); }
         else if (W == 4 && ks == 10) { if (nb == 2) BBX_BPOL(2, 10); else BBX_BPOL(4, 10); }
         else return (int)hipErrorInvalidValue;             // (bbx_api.cpp admits only the built-in shapes)

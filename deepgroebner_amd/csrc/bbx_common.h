@@ -29,6 +29,7 @@
 #include <stdint.h>
 
 #define BBX_P 32003u
+#define BBX_POLICY_MAX_ROWS 2048    /* rows (pairs) per environment the policy kernels score: their logits live in LDS */
 #define BBX_MAXVARS 8
 
 // per-environment status (sticky except STARVED)

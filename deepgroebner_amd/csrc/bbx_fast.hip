@@ -54,7 +54,7 @@ extern "C" int bbx_launch_fast(const BbxParams* p, int blocks, int threads, int 
       return 0;
     }
     const int nb = pmlp_nb_for(q.pol.hidden), ks = pmlp_ks_for(2 * f.k * f.nvars);
-    const size_t pl = pmlp_lds_bytes(envs_per_block), ll = pl > lds_pol ? pl : lds_pol;
+    const size_t pl = pmlp_lds_bytes(envs_per_block, f.obs_rows), ll = pl > lds_pol ? pl : lds_pol;
     if (ks == 3) { if (nb == 2) hipLaunchKernelGGL((bbx_fast_policy_kernel<2, 3>), dim3(blocks), dim3(threads), ll, stream, q);
                    else hipLaunchKernelGGL((bbx_fast_policy_kernel<4, 3>), dim3(blocks), dim3(threads), ll, stream, q); }
     else { if (nb == 2) hipLaunchKernelGGL((bbx_fast_policy_kernel<2, 6>), dim3(blocks), dim3(threads), ll, stream, q);

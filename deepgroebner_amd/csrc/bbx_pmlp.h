@@ -10,7 +10,10 @@
 // torch module of deepgroebner_amd/rollout.py reproduces the draw).  fp32 throughout.  One wavefront per environment.
 // Padded rows (beyond rows[e]) never reach a logit: the -1 padding the reference masks out (networks.py:94-95, 456-457)
 // plays no part.
-constexpr int PMLP_MAXROWS = 1024;
+constexpr int PMLP_MAXROWS = BBX_POLICY_MAX_ROWS;
+// logits per wave in LDS: what the caller's block can hold, at most PMLP_MAXROWS
+// (no block, obs_rows <= 0 — a policy rollout that keeps no observations: every row the kernels score)
+__host__ __device__ constexpr int pmlp_lgcap(int obs_rows) { return obs_rows > 0 && obs_rows < PMLP_MAXROWS ? obs_rows : PMLP_MAXROWS; }
 __device__ __forceinline__ float wave_sum_f32(float x) {    // sum over the 64 lanes, valid in lane 63
 #define BBX_DPPADD(ctrl, rmask) x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), ctrl, rmask, 0xF, false));
   BBX_DPPADD(0x111, 0xF) BBX_DPPADD(0x112, 0xF) BBX_DPPADD(0x114, 0xF) BBX_DPPADD(0x118, 0xF) BBX_DPPADD(0x142, 0xA) BBX_DPPADD(0x143, 0xC)
@@ -130,7 +133,7 @@ __device__ __forceinline__ int pmlp_act_wave(char* smem, int env, bool live, con
   constexpr int HP = 32 * NB;
   constexpr int G = (KS <= 10 ? 2 : 1) < NB ? (KS <= 10 ? 2 : 1) : NB;   // unit blocks in flight together
   const int lane = lane_id(), wave = uni((int)(threadIdx.x / WAVE));
-  float* lg = (float*)smem + (size_t)wave * PMLP_MAXROWS;   // logits of this wave's environment
+  float* lg = (float*)smem + (size_t)wave * pmlp_lgcap(obs_rows);   // logits of this wave's environment
   if (!live) return 0;
   const int lr = lane & 31, lk = lane >> 5;
   const int nraw = rows[env];
@@ -166,4 +169,4 @@ __global__ __launch_bounds__(256, 4) void bbx_pmlp_act_mfma_kernel(const int32_t
   pmlp_act_wave<NB, KS>(smem, env, env < B, obs, rows, obs_rows, cols, wp, u, actions, logprobs);
 }
 // LDS bytes of pmlp_act_wave for a workgroup of `waves` waves (the logits)
-__host__ __device__ constexpr size_t pmlp_lds_bytes(int waves) { return (size_t)waves * PMLP_MAXROWS * sizeof(float); }
+__host__ __device__ constexpr size_t pmlp_lds_bytes(int waves, int obs_rows) { return (size_t)waves * pmlp_lgcap(obs_rows) * sizeof(float); }

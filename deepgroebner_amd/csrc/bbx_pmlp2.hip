@@ -167,7 +167,7 @@ __global__ __launch_bounds__(NWAVES * WAVE, 16 / NWAVES) void bbx_pmlp2_act_kern
   int* s_env = (int*)(lg_base + (size_t)nw * lgcap);                          // [nw] environment of each wave this round
   int* s_n = s_env + nw;                                                      // [nw] its row count
   int* s_q = s_n + nw;                                                        // queue length, and (s_q[1]) how much of it has been taken
-  unsigned short* queue = (unsigned short*)(s_q + 2);                         // [nw * 64] (wave << 8) | tile
+  unsigned short* queue = (unsigned short*)(s_q + 2);                         // [nw * PMLP_MAXROWS / 16] (wave << 8) | tile
   for (int base = (int)blockIdx.x * nw; base < B; base += (int)gridDim.x * nw) {
     const int env = base + wave;
     const bool valid = env < B;
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(NWAVES * WAVE, 16 / NWAVES) void bbx_pmlp2_act_kern
     if (lane == 0) { s_env[wave] = env; s_n[wave] = n; }
     if (threadIdx.x == 0) { s_q[0] = 0; s_q[1] = 0; }
     __syncthreads();
-    if (lane < T - 1) queue[atomicAdd(s_q, 1)] = (unsigned short)((wave << 8) | (1 + lane));
+    for (int tl = lane; tl < T - 1; tl += WAVE) queue[atomicAdd(s_q, 1)] = (unsigned short)((wave << 8) | (1 + tl));   // (up to PMLP_MAXROWS / 16 = 128 tiles)
     __syncthreads();
     const int nq = uni(s_q[0]);
   {
@@ -282,14 +282,14 @@ extern "C" int bbx_launch_pmlp2_act(const int32_t* obs, const int32_t* rows, int
   int hp1, hpm, hp2; pmlp2_pads(h1, hm, h2, &hp1, &hpm, &hp2);
   const int ks = pmlp2_ks_for(cols);
   // 64 KB of second-layer weights: two workgroups of 8 waves per CU; with a middle layer of that size (128 KB): one workgroup
-  // of 16 waves — or of 8 or 4 where tall observation blocks (obs_rows up to 1024: 4 KB of logits per wave) leave less room
+  // of 16 waves — or of 8 or 4 where tall observation blocks (4 bytes of logits per row and wave) leave less room
   int waves = (hpm == 128) ? 16 : PMLP2_WAVES;
   int lgcap = obs_rows < PMLP_MAXROWS ? obs_rows : PMLP_MAXROWS;              // logits per wave: what the block can hold
   lgcap = (lgcap + 63) / 64 * 64;
   size_t ml = 0;
   for (;; waves /= 2) {
     ml = ((size_t)hp1 * hpm + (size_t)(hpm ? hpm : hp1) * hp2 + hpm + 2 * hp2) * sizeof(float) + (size_t)waves * lgcap * sizeof(float) +
-         (size_t)(2 * waves + 2) * sizeof(int) + (size_t)waves * 64 * sizeof(unsigned short);
+         (size_t)(2 * waves + 2) * sizeof(int) + (size_t)waves * (PMLP_MAXROWS / 16) * sizeof(unsigned short);
     if (ml <= (size_t)max_lds || hpm != 128 || waves == 4) break;
   }
   if (ml > (size_t)max_lds) return (int)hipErrorInvalidValue;

@@ -95,13 +95,13 @@ class PMLPPolicy(torch.nn.Module):
             actions = torch.empty(B, dtype=torch.int32, device=obs.device)
         if logprobs is None:
             logprobs = torch.empty(B, dtype=torch.float32, device=obs.device)
-        if len(self.embedding) == 1 and self.fused_ok(cols, self.embedding[0].out_features) and R <= 1024:   # (the kernels score <= 1024 rows)
+        if len(self.embedding) == 1 and self.fused_ok(cols, self.embedding[0].out_features) and R <= 2048:   # (the kernels score <= 2048 rows)
             w = self._fused_weights()
             s = (stream if stream is not None else torch.cuda.current_stream()).cuda_stream
             _ffi.check(_ffi.lib().bbx_pmlp_act(C.c_void_p(obs.data_ptr()), C.c_void_p(rows.data_ptr()), B, R, cols, w["prepared"], w["hidden"],
                                                C.c_void_p(u.data_ptr()), C.c_void_p(actions.data_ptr()), C.c_void_p(logprobs.data_ptr()), C.c_void_p(s)))
             return actions, logprobs
-        if self.deep_ok(cols) and R <= 1024:
+        if self.deep_ok(cols) and R <= self.deep_max_rows():
             w = self._deep_weights()
             s = (stream if stream is not None else torch.cuda.current_stream()).cuda_stream
             fn = _ffi.lib().bbx_pmlp2_act if len(w["hidden"]) == 2 else _ffi.lib().bbx_pmlp3_act
@@ -113,6 +113,11 @@ class PMLPPolicy(torch.nn.Module):
     def deep_ok(self, cols):
         """Two or three hidden layers of at most 128 units: the shapes bbx_pmlp2_act / bbx_pmlp3_act are built for."""
         return len(self.embedding) in (2, 3) and all(1 <= l.out_features <= 128 for l in self.embedding) and 1 <= cols <= 64
+
+    def deep_max_rows(self):
+        """Rows per environment the two- / three-layer kernels score: the logits of a wave's environment live in LDS beside the
+        staged weights — 2048 rows, 1024 where three layers wider than 64 units (128 KB of weights) leave less room."""
+        return 1024 if len(self.embedding) == 3 and max(l.out_features for l in self.embedding) > 64 else 2048
 
     def _deep_weights(self):
         """The two- / three-layer kernel's view of the weights (bbx_pmlp2_prepare / bbx_pmlp3_prepare), rebuilt only when a
@@ -411,7 +416,7 @@ def _run_rollout_graph(env, policy, nsteps, obs_rows, generator, sync_every):
         c["graph"] = g
         cache[key] = c
     stream = torch.cuda.current_stream()
-    if policy.deep_ok(cols) and obs_rows <= 1024:
+    if policy.deep_ok(cols) and obs_rows <= policy.deep_max_rows():
         policy._deep_weights()                       # (weights changed since the recording: the prepared copy is refilled in place)
     st0 = env.stats()
     env.rollout_device("first", 0, False, stream.cuda_stream, c["rew"], c["done"], c["rows"], c["obs"], obs_rows, True, False)

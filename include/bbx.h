@@ -186,8 +186,8 @@ int bbx_step_device_autoreset(bbx_batch* b, const int32_t* d_actions, double* d_
  * environment (the -1 padding is masked out there, plays no part here), log-softmax over the rows and ONE action drawn
  * by inverse CDF from the uniform number d_u[e] in [0, 1) — the step of pg.py:451-503's run_episode that used to cross to
  * the host every step.  fp32, the hidden layer on the matrix cores (exact f32 MFMA); cols <= 64, hidden <= 256, at most
- * 1024 rows per environment (obs_rows > 1024: BBX_E_UNSUPPORTED; a policy rollout without an observation block whose pair
- * set outgrows 1024 rows: BBX_E_CAPACITY from bbx_sync — never a silent cut).  exp / log of the softmax are the
+ * 2048 rows per environment (obs_rows > 2048: BBX_E_UNSUPPORTED; a policy rollout without an observation block whose pair
+ * set outgrows 2048 rows: BBX_E_CAPACITY from bbx_sync — never a silent cut).  exp / log of the softmax are the
  * hardware's fast forms (__expf / __logf): log-probabilities agree with an IEEE evaluation to ~2e-4 (tests/test_rollout.py).
  * The weights are handed over PREPARED: bbx_pmlp_prepare copies d_w1 [cols][hidden] (the layout of
  * torch.nn.Linear(...).weight.t()), d_b1 [hidden], d_w2 [hidden], b2 into d_prepared (bbx_pmlp_prepared_floats(cols,
@@ -199,7 +199,7 @@ int bbx_pmlp_act(const int32_t* d_obs, const int32_t* d_rows, int batch, int obs
                  const float* d_u, int32_t* d_actions, float* d_logprobs, void* stream);
 /* The same for ParallelMultilayerPerceptron(hidden_layers=[hidden1, hidden2]) (networks.py:562-571: two dense layers in the
  * embedding): logit_r = w3 . relu(W2^T relu(W1^T x_r + b1) + b2) + b3, both layers on the matrix cores in exact f32, the
- * second layer's weights staged in LDS once per workgroup (bbx_pmlp2.hip); cols <= 64, hidden1, hidden2 <= 128, at most 1024
+ * second layer's weights staged in LDS once per workgroup (bbx_pmlp2.hip); cols <= 64, hidden1, hidden2 <= 128, at most 2048
  * rows per environment.  d_w1 [cols][hidden1], d_b1 [hidden1], d_w2 [hidden1][hidden2], d_b2 [hidden2], d_w3 [hidden2],
  * d_b3 [1] (the transposed layouts of torch.nn.Linear weights; every argument on the device: preparing never reads back).
  * Stands alone in front of bbx_step_device_autoreset (two launches per vector step, both recordable into a HIP graph);

@@ -238,6 +238,35 @@ def test_deep_policy_kernels_on_tall_observation_blocks(hidden, R):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("hidden", [(128,), (64,), (128, 128), (64, 64, 64), (128, 128, 128)])
+def test_policy_kernels_score_up_to_2048_rows(hidden):
+    """5-10-5-uniform pair sets pass a thousand rows: the policy kernels keep an environment's logits in LDS, 2048 of them
+    (1024 beside the 128 KB of weights of three wide layers: deep_max_rows, the torch path takes the rest).  Synthetic blocks
+    with 1 .. R live rows per environment: draws and log-probabilities against the torch module."""
+    import torch
+    from deepgroebner_amd.rollout import PMLPPolicy
+    torch.manual_seed(11)
+    B, cols = 40, 20
+    policy = PMLPPolicy(cols, list(hidden)).cuda()
+    with torch.no_grad():
+        for lin in list(policy.embedding) + [policy.deciding]:
+            lin.weight.mul_(0.3)
+    for R in (1500, 2048):
+        obs = torch.randint(0, 9, (B, R, cols), dtype=torch.int32, device="cuda")
+        rows = torch.randint(1, R + 1, (B,), dtype=torch.int32, device="cuda")
+        rows[0] = R; rows[1] = 1; rows[2] = 1025
+        obs[torch.arange(R, device="cuda")[None, :] >= rows[:, None]] = -1
+        u = torch.rand(B, device="cuda")
+        a_k, l_k = policy.act(obs, rows, u)
+        a_t, l_t = policy.act_torch(obs, rows, u)
+        torch.cuda.synchronize()
+        assert (a_k >= 0).all() and (a_k < rows).all()
+        lp = policy(obs)
+        assert torch.allclose(l_k, lp.gather(1, a_k.long()[:, None]).squeeze(1), atol=5e-4, rtol=1e-4)
+        assert int((a_k != a_t).sum()) <= 2                            # (equal except on round-off ties of the cumulative sum)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("hidden", [(64, 64), (32, 32, 32), (32, 32, 32, 32)])
 def test_rollout_replayed_from_a_hip_graph_equals_the_eager_rollout(hidden):
     """run_rollout(graph=True): the vector step (policy ops + bbx_step_device_autoreset) recorded once and replayed gives the
@@ -443,6 +472,62 @@ def test_policy_rollout_in_one_launch_equals_the_per_step_loop(dist, k, hidden, 
 
 
 @pytest.mark.gpu
+def test_policy_in_the_loop_on_pair_sets_of_more_than_1024_rows():
+    """Pair sets of five-variable binomial ideals pass a thousand rows (5-10-5-uniform: ~1000 at most in a batch of 4096;
+    5-15-5-uniform: 1200 within 600 steps).  The policy kernels score up to 2048 (the logits of an environment live in LDS: the
+    HBM-resident binomial class sizes its per-wave scratch for them): a batch pre-rolled until some pair set has more than
+    1100 rows, then the policy rollout kernel against one bbx_policy_step_device call per step,
+    as in test_policy_rollout_in_one_launch_equals_the_per_step_loop, and every draw against the torch module."""
+    import torch
+    from deepgroebner_amd import VecLeadMonomialsEnv
+    from deepgroebner_amd.rollout import PMLPPolicy
+    torch.manual_seed(5)
+    B, T, R, k = 256, 8, 2048, 1
+    env = VecLeadMonomialsEnv("5-15-5-uniform", batch=B, k=k)
+    env.seed(np.arange(B) + 300); env.seed_agent(np.arange(B)); env.reset(); env.accounting(False)
+    for _ in range(30):                                             # (a property of the seeds: checked, not assumed)
+        env.rollout("random", 100, auto_reset=True)
+        if int(env.rows.max()) > 1100:
+            break
+    assert 1100 < int(env.rows.max()) <= R
+    twin = env.copy(); twin.accounting(False)
+    policy = PMLPPolicy(env.cols, [64]).cuda()
+    with torch.no_grad():
+        for lin in list(policy.embedding) + [policy.deciding]:
+            lin.weight.mul_(0.3)
+    w = policy._fused_weights()
+    s = torch.cuda.current_stream().cuda_stream
+    u = torch.rand((T, B), device="cuda")
+    obs = torch.full((B, R, env.cols), -1, dtype=torch.int32, device="cuda")
+    rew = torch.zeros(B, dtype=torch.float64, device="cuda"); done = torch.zeros(B, dtype=torch.uint8, device="cuda")
+    rows = torch.zeros(B, dtype=torch.int32, device="cuda"); act = torch.zeros(B, dtype=torch.int32, device="cuda")
+    logp = torch.zeros(B, dtype=torch.float32, device="cuda")
+    env.rollout_device("first", 0, False, s, rew, done, rows, obs, R, True, False); env.sync()
+    want = {k_: [] for k_ in ("rows", "act", "logp", "rew", "done")}
+    big = 0
+    for t in range(T):
+        want["rows"].append(rows.clone())
+        big = max(big, int(rows.max()))
+        a_t, l_t = policy.act_torch(obs, rows, u[t])
+        env.policy_step_device(w["prepared"], w["hidden"], u[t], act, logp, rew, done, rows, obs, R, 1, s)
+        env.sync()
+        assert int((act != a_t).sum()) <= 1 and torch.allclose(logp[act == a_t], l_t[act == a_t], atol=5e-4, rtol=1e-4), t
+        for k_, v in (("act", act), ("logp", logp), ("rew", rew), ("done", done)):
+            want[k_].append(v.clone())
+    assert big > 1024
+    A = torch.zeros((T, B), dtype=torch.int32, device="cuda"); L = torch.zeros((T, B), dtype=torch.float32, device="cuda")
+    Rw = torch.zeros((T, B), dtype=torch.float64, device="cuda"); D = torch.zeros((T, B), dtype=torch.uint8, device="cuda")
+    N = torch.zeros((T, B), dtype=torch.int32, device="cuda")
+    twin.policy_rollout_device(w["prepared"], w["hidden"], T, u, A, L, Rw, D, N, None, R, 0, s)
+    twin.sync()
+    for t in range(T):
+        assert torch.equal(N[t], want["rows"][t]), t
+        assert torch.equal(A[t], want["act"][t]) and torch.equal(L[t], want["logp"][t]), t
+        assert torch.equal(Rw[t], want["rew"][t]) and torch.equal(D[t], want["done"][t]), t
+    assert np.array_equal(env.stats()[:, :5], twin.stats()[:, :5])
+
+
+@pytest.mark.gpu
 def test_policy_rollout_rejects_what_the_kernel_class_cannot_do():
     import torch
     from deepgroebner_amd import VecLeadMonomialsEnv, _ffi
@@ -460,7 +545,7 @@ def test_policy_rollout_rejects_what_the_kernel_class_cannot_do():
 @pytest.mark.gpu
 def test_rollout_refuses_to_overrun_the_buffer_and_policy_row_limit():
     """run_rollout_fused hands raw pointers into the trajectory buffer to the kernel: a rollout that does not fit raises
-    instead of writing past the arrays; observation blocks taller than the 1024 rows the policy kernels score are refused."""
+    instead of writing past the arrays; observation blocks taller than the 2048 rows the policy kernels score are refused."""
     import torch
     from deepgroebner_amd import VecLeadMonomialsEnv, _ffi
     from deepgroebner_amd.rollout import DeviceTrajectoryBuffer, PMLPPolicy, run_rollout_fused
@@ -475,11 +560,11 @@ def test_rollout_refuses_to_overrun_the_buffer_and_policy_row_limit():
         run_rollout_fused(env, policy, 11, buffer=buf, chunk=16)
     run_rollout_fused(env, policy, 10, buffer=buf, chunk=16)
     assert buf.t == 40
-    obs = torch.zeros((B, 1100, env.cols), dtype=torch.int32, device="cuda")
+    obs = torch.zeros((B, 2100, env.cols), dtype=torch.int32, device="cuda")
     w = policy._fused_weights()
     u = torch.rand((4, B), device="cuda"); act = torch.zeros((4, B), dtype=torch.int32, device="cuda"); lp = torch.zeros((4, B), device="cuda")
     with pytest.raises(_ffi.BbxError) as ei:
-        env.policy_rollout_device(w["prepared"], w["hidden"], 4, u, act, lp, obs=obs, obs_rows=1100)
+        env.policy_rollout_device(w["prepared"], w["hidden"], 4, u, act, lp, obs=obs, obs_rows=2100)
     assert ei.value.code == -5
     rows = torch.full((B,), 3, dtype=torch.int32, device="cuda")
     a2, l2 = policy.act(obs, rows, u[0])                            # (taller than the kernels score: the torch path serves it)
