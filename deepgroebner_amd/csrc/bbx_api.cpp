@@ -314,7 +314,9 @@ int alloc_io(bbx_batch* b, int batch) {
   memset(b->h_io, 0, b->io_bytes);
   HIPCHK(hipHostMalloc((void**)&b->h_act, (size_t)batch * sizeof(int32_t), hipHostMallocDefault));
   memset(b->h_io, 0, b->io_bytes);
-  b->zero_copy = batch <= 8 && !getenv("BBX_NO_ZERO_COPY");
+  // (host-stepped batches of up to 64 environments: B = 16 / 32 / 64 step in 24 / 28 / 32 us this way, 49 / 59 / 63 us with device
+  // buffers and copy calls — scripts/exp_small_batch.py)
+  { const char* zm = getenv("BBX_ZERO_COPY_MAX"); b->zero_copy = batch <= (zm ? atoi(zm) : 64) && !getenv("BBX_NO_ZERO_COPY"); }
   if (b->zero_copy) {
     HIPCHK(hipHostGetDevicePointer((void**)&b->zc_io_dev, b->h_io, 0));
     HIPCHK(hipHostGetDevicePointer((void**)&b->zc_act_dev, b->h_act, 0));

@@ -212,7 +212,9 @@ int launch(bbx_batch* b, BbxParams& p, hipStream_t stream, bool obs_external, bo
 // the control word, and a spin on the status words the kernel publishes with every step's outputs.  Everything else on
 // the handle closes the session through the usual path (finish): it is never observable except in time.
 bool mbox_eligible(const bbx_batch* b) {
-  return b->zero_copy && b->fast && b->staged && b->device_gen && !b->accounting && !b->timing && !(b->d_trace && b->trace_cap >= 1) &&
+  // (up to 8 environments: measured at 16 / 32 / 64 a session is no faster than — 24 / 34 / 61 against 24 / 28 / 32 us — the
+  // zero-copy launch per step, whose one kernel serves all of them at once)
+  return b->zero_copy && b->B <= 8 && b->fast && b->staged && b->device_gen && !b->accounting && !b->timing && !(b->d_trace && b->trace_cap >= 1) &&
          b->mbox_misses < 3 && !getenv("BBX_NO_MAILBOX");
 }
 // p: the step's parameters (external agent, zero-copy outputs, nsteps = 1).  Returns BBX_OK with the step taken and its outputs
