@@ -124,7 +124,8 @@ int bbx_reset(bbx_batch* b, const uint8_t* mask, int32_t* rows);
  * Small batches (<= 8 environments) on the class of the reference's C++ LeadMonomialsEnv: the step calls of a loop (from
  * the fifth call in a row on: bbx_step, bbx_step_autoreset, bbx_step_obs) feed one resident kernel through pinned host memory
  * instead of launching one each — a host mailbox session; any other call on the handle ends it first.
- * Results are those of one launch per step; the environment variable BBX_NO_MAILBOX restores that. */
+ * Results are those of one launch per step; the environment variable BBX_NO_MAILBOX restores that.  Batches of up to 64
+ * environments read the actions from and write outputs and observation rows to pinned host memory (no copy calls). */
 int bbx_step(bbx_batch* b, const int32_t* actions, double* rewards, uint8_t* dones, int32_t* rows);
 
 /* The vectorised-environment convention: an environment whose episode ends with this step is reset inside the same
