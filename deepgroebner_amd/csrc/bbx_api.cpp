@@ -239,8 +239,7 @@ int enqueue(bbx_batch* b, const BbxParams& p0, bool resume, hipStream_t stream) 
   }
   // wide class with more workgroups than CUs: a second kernel for the tail of the launch (BbxParams::wide_tail)
   int tail_at = -1;
-  if (nk > 0 && kinds[nk - 1] == 4 && nk < 3 && b->ncu > 0 && b->B > b->ncu && p.L.W <= 4 && !getenv("BBX_NO_WIDE_TAIL")) {
-    if (!b->d_wide_done) HIPCHK(hipMalloc((void**)&b->d_wide_done, 256));
+  if (nk > 0 && kinds[nk - 1] == 4 && nk < 3 && b->d_wide_done && b->B > b->ncu && p.L.W <= 4 && !getenv("BBX_NO_WIDE_TAIL")) {
     HIPCHK(hipMemsetAsync(b->d_wide_done, 0, 256, stream));
     tail_at = nk; kinds[nk++] = 4;
     p.wide_done = b->d_wide_done; p.wide_ncu = b->ncu;
@@ -645,6 +644,9 @@ int create_common(std::unique_ptr<bbx::IdealGen> proto, int nvars_obs, int elimi
   // non-binomial random ideals in <= 7 variables: wave-per-environment kernel, long-polynomial environments continue one
   // workgroup each (bbx_wide.h) behind it
   b->gen_to_wide = !b->binom && !b->wide && !b->staged && !b->fixed && !list && c.wide_waves >= 0;
+  // (the counter of a two-kernel wide launch, BbxParams::wide_tail: allocated here, never inside a launch — a launch may be
+  // recorded into a HIP graph)
+  if ((b->wide || b->gen_to_wide) && b->ncu > 0 && batch > b->ncu) HIPCHK(hipMalloc((void**)&b->d_wide_done, 256));
   if (c.max_basis > 65535 || c.max_poly_terms > (1 << 22) || c.max_basis < 2 || c.max_pairs < 2 || c.max_poly_terms < 4 || c.queue_slots < 1)
     return fail(BBX_E_ARG, "capacities out of range");
   b->L = b->binom ? make_layout_binom(b->W, c.max_basis, c.max_pairs)
@@ -791,6 +793,7 @@ int bbx_copy(const bbx_batch* s, bbx_batch** out) {
   b->fixed = s->fixed; b->listed = s->listed; b->binom = s->binom; b->L = s->L; b->LL = s->LL; b->slot_words = s->slot_words; b->nslots = s->nslots;
   b->h_q = s->h_q; b->h_tail = s->h_tail; b->h_head = s->h_head; b->q_dirty = true;
   b->no_growth = s->no_growth; b->value_rng = s->value_rng; b->gen_to_wide = s->gen_to_wide;
+  if (s->d_wide_done) HIPCHK(hipMalloc((void**)&b->d_wide_done, 256));
   b->wide = s->wide; b->wide_terms = s->wide_terms; b->accounting = s->accounting; b->staged = s->staged; b->fast = s->fast; b->envs_per_block = s->envs_per_block;
   b->fast_G = s->fast_G; b->fast_P = s->fast_P;
   if (s->device_gen) {
