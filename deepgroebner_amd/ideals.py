@@ -82,17 +82,136 @@ def _dist_name(n, d, s, dist, constants, homogeneous, pure=False, lam=None):
     return "-".join(parts)
 
 
-class RandomBinomialIdealGenerator(IdealGenerator):
-    """Reference ideals.py:192-250 / ideals.cpp:156-201."""
+P = 32003
 
-    def __init__(self, n=3, d=20, s=10, degrees="uniform", constants=False, homogeneous=False, pure=False):
+
+def _grevlex_key(e):
+    """Sort key of an exponent tuple: larger key = larger monomial in grevlex (what the reference's Python path compares,
+    ideals.py:236-238)."""
+    return (sum(e), tuple(-x for x in reversed(e)))
+
+
+class _NumpyStream:
+    """The seeded stream of the reference's PYTHON generators (ideals.py:214, 250, 302: numpy's default_rng, PCG64) instead of
+    the C++ generators' minstd_rand0: the same draws in the same order — integers(1, P) for a coefficient, choice(len, p=...)
+    for a degree, choice(len) for a monomial of that degree in the enumeration order of ideals.py:18-43, poisson(lam) for a
+    length — so that generator.seed(123) yields the ideals the reference's tests/test_ideals.py:48-69 expect.  Host-side only
+    (the batch environments draw on the device, from the C++ streams)."""
+
+    def _setup(self, n, d, degrees, constants):
+        import itertools as it
+        from math import comb
+        self.nvars = n
+        self.bases = [[tuple([0] * n)]]
+        for deg in range(1, d + 1):
+            row = []
+            for combo in it.combinations_with_replacement(range(n), deg):
+                e = [0] * n
+                for v in combo:
+                    e[v] += 1
+                row.append(tuple(e))
+            self.bases.append(row)
+        head = [1 if constants else 0]
+        if degrees == "uniform":
+            tail = [comb(n + i - 1, n - 1) for i in range(1, d + 1)]
+        elif degrees == "weighted":
+            tail = d * [1]
+        elif degrees == "maximum":
+            tail = (d - 1) * [0] + [1]
+        else:
+            raise ValueError("unrecognized dist option")
+        count = np.array(head + tail)
+        self.degree_dist = count / np.sum(count)
+        self.rng = np.random.default_rng()
+
+    def __iter__(self):
+        return self
+
+    def seed(self, seed=None):
+        self.rng = np.random.default_rng(seed)
+
+    def _monomial(self, deg):
+        row = self.bases[deg]
+        return row[self.rng.choice(len(row))]
+
+
+class _NumpyBinomials(_NumpyStream):
+    def __init__(self, n, d, s, degrees, constants, homogeneous, pure):
+        self._setup(n, d, degrees, constants)
+        self.s, self.homogeneous, self.pure = s, homogeneous, pure
+
+    def __next__(self):
+        F = []
+        for _ in range(self.s):
+            c = P - 1 if self.pure else int(self.rng.integers(1, P))
+            if self.homogeneous:
+                d1 = d2 = self.rng.choice(len(self.degree_dist), p=self.degree_dist)
+            else:
+                d1, d2 = self.rng.choice(len(self.degree_dist), size=2, p=self.degree_dist)
+            for _ in range(1000):
+                m1, m2 = self._monomial(d1), self._monomial(d2)
+                k1, k2 = _grevlex_key(m1), _grevlex_key(m2)
+                if k1 != k2:
+                    lead, tail = (m1, m2) if k1 > k2 else (m2, m1)
+                    F.append([(1, lead), (c, tail)])
+                    break
+            else:
+                raise RuntimeError("failed to generate two distinct random monomials after 1000 trials")
+        return F
+
+
+class _NumpyPolynomials(_NumpyStream):
+    def __init__(self, n, d, s, lam, degrees, constants, homogeneous):
+        self._setup(n, d, degrees, constants)
+        self.s, self.lam, self.homogeneous = s, lam, homogeneous
+
+    def __next__(self):
+        F = []
+        for _ in range(self.s):
+            f = {}
+            terms = 2 + self.rng.poisson(self.lam)
+            deg = self.rng.choice(len(self.degree_dist), p=self.degree_dist)
+            for _ in range(terms):
+                c = int(self.rng.integers(1, P))
+                m = self._monomial(deg)
+                f[m] = (f.get(m, 0) + c) % P                     # (terms are not checked to be distinct: they add up or cancel)
+                if not self.homogeneous:
+                    deg = self.rng.choice(len(self.degree_dist), p=self.degree_dist)
+            f = {m: c for m, c in f.items() if c}
+            if not f:                                            # (everything cancelled: the zero polynomial, as the reference's f.monic())
+                F.append([])
+                continue
+            inv = pow(f[max(f, key=_grevlex_key)], P - 2, P)
+            F.append(sorted(((c * inv % P, m) for m, c in f.items()), key=lambda t: _grevlex_key(t[1]), reverse=True))
+        return F
+
+
+class RandomBinomialIdealGenerator(IdealGenerator):
+    """Reference ideals.py:192-250 / ideals.cpp:156-201.  stream="cpp" (default): the C++ generator's seeded stream — what the
+    environments draw; stream="numpy": the Python generator's (see _NumpyStream), exponent tuples of n entries."""
+
+    def __new__(cls, n=3, d=20, s=10, degrees="uniform", constants=False, homogeneous=False, pure=False, stream="cpp"):
+        if stream == "numpy":
+            return _NumpyBinomials(n, d, s, degrees, constants, homogeneous, pure)
+        return super().__new__(cls)
+
+    def __init__(self, n=3, d=20, s=10, degrees="uniform", constants=False, homogeneous=False, pure=False, stream="cpp"):
+        if stream != "cpp":
+            raise ValueError("stream must be 'cpp' or 'numpy'")
         super().__init__(_dist_name(n, d, s, degrees, constants, homogeneous, pure))
 
 
 class RandomIdealGenerator(IdealGenerator):
-    """Reference ideals.py:253-323 / ideals.cpp:203-231."""
+    """Reference ideals.py:253-323 / ideals.cpp:203-231.  stream: as for RandomBinomialIdealGenerator."""
 
-    def __init__(self, n=3, d=20, s=10, lam=0.5, degrees="uniform", constants=False, homogeneous=False):
+    def __new__(cls, n=3, d=20, s=10, lam=0.5, degrees="uniform", constants=False, homogeneous=False, stream="cpp"):
+        if stream == "numpy":
+            return _NumpyPolynomials(n, d, s, lam, degrees, constants, homogeneous)
+        return super().__new__(cls)
+
+    def __init__(self, n=3, d=20, s=10, lam=0.5, degrees="uniform", constants=False, homogeneous=False, stream="cpp"):
+        if stream != "cpp":
+            raise ValueError("stream must be 'cpp' or 'numpy'")
         super().__init__(_dist_name(n, d, s, degrees, constants, homogeneous, lam=lam))
 
 

@@ -27,6 +27,38 @@ def _sel(s):
 
 
 # ---- host logic (no GPU) ------------------------------------------------------------------------------------------------
+def test_python_generators_numpy_streams_known_answers():
+    """The reference's Python generators draw from numpy's default_rng (ideals.py:214, 250, 302), not from the C++ generators'
+    engine; stream="numpy" reproduces those streams.  Expected ideals: the reference's own tests/test_ideals.py:48-69
+    (seed 123), as data — term lists (coefficient, exponents), lead term first; and its degree distributions :33-45."""
+    from deepgroebner_amd import ideals
+    g = ideals.RandomBinomialIdealGenerator(3, 5, 5, stream="numpy")
+    g.seed(123)
+    assert next(g) == [[(1, (2, 0, 1)), (495, (0, 0, 1))],
+                       [(1, (0, 1, 4)), (5901, (1, 1, 1))],
+                       [(1, (5, 0, 0)), (14384, (3, 0, 2))],
+                       [(1, (3, 1, 1)), (16417, (0, 2, 1))],
+                       [(1, (3, 1, 1)), (13109, (0, 3, 2))]]
+    g = ideals.RandomIdealGenerator(3, 5, 5, 0.5, stream="numpy")
+    g.seed(123)
+    assert next(g) == [[(1, (3, 0, 2)), (10689, (2, 1, 0)), (12547, (0, 1, 2))],
+                       [(1, (0, 1, 4)), (15388, (0, 2, 1)), (22355, (0, 1, 2))],
+                       [(1, (1, 1, 2)), (4665, (3, 0, 0)), (15800, (2, 1, 0))],
+                       [(1, (3, 0, 2)), (8782, (0, 2, 3)), (15890, (0, 1, 2))],
+                       [(1, (0, 2, 1)), (30687, (0, 2, 0))]]
+    assert np.array_equal(ideals.RandomBinomialIdealGenerator(3, 3, 1, "uniform", stream="numpy").degree_dist, np.array([0, 3, 6, 10]) / 19.0)
+    assert np.array_equal(ideals.RandomBinomialIdealGenerator(3, 3, 1, "weighted", stream="numpy").degree_dist, np.array([0, 1, 1, 1]) / 3.0)
+    # the same seed gives the same ideals again; homogeneous / pure variants keep their promises
+    a = ideals.RandomBinomialIdealGenerator(4, 6, 7, "weighted", homogeneous=True, pure=True, stream="numpy"); a.seed(5)
+    b = ideals.RandomBinomialIdealGenerator(4, 6, 7, "weighted", homogeneous=True, pure=True, stream="numpy"); b.seed(5)
+    F = next(a)
+    assert F == next(b) and len(F) == 7
+    for f in F:
+        assert f[1][0] == 32002 and sum(f[0][1]) == sum(f[1][1]) and ideals._grevlex_key(f[0][1]) > ideals._grevlex_key(f[1][1])
+    with pytest.raises(ValueError):
+        ideals.RandomIdealGenerator(3, 5, 5, 0.5, stream="pcg")
+
+
 def test_select_matches_reference_on_recorded_states(gold):
     from deepgroebner_amd.buchberger import BuchbergerAgent, select
     assert len(gold["select"]) >= 5
