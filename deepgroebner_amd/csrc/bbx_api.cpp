@@ -228,9 +228,9 @@ int enqueue(bbx_batch* b, const BbxParams& p0, bool resume, hipStream_t stream) 
     kinds[nk++] = 0; kinds[nk++] = 4;                 // workgroup-per-environment kernel for the environments whose polynomials got long
     p.spill_terms = 384;
   }
-  else {   // the hand-tuned kernel knows the external / random / degree / first agents; the others take the class kernel
+  else {   // the register/LDS-resident class (the hand-tuned kernel where the batch has it), then the HBM-resident one
     const bool pol_hbm_only = p.policy && p.policy->rollout == 2;     // a policy rollout outside the register/LDS class
-    if (b->staged && !pol_hbm_only) kinds[nk++] = (b->fast && p.agent <= BBX_AGENT_FIRST) ? 3 : 1;
+    if (b->staged && !pol_hbm_only) kinds[nk++] = b->fast ? 3 : 1;   // (the hand-tuned kernel knows every agent since round 4)
     // the HBM-resident pass behind the LDS-resident one serves environments that outgrow the LDS class inside a
     // rollout; a single host-driven step does without it: an environment that spills reports BBX_ST_SPILL and
     // finish() continues it (one launch less on the latency path)

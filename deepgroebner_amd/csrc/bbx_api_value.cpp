@@ -62,7 +62,7 @@ int value_rollouts(bbx_batch* b, const std::vector<int32_t>& src, int agent, con
     p.lite = nullptr;                                           // the clones are not the batch's environments
     if (b->wide) lrc = bbx_launch_step(&p, 4, b->wide, 0);
     else {
-      const bool vfast = b->fast && b->staged && (agent == BBX_AGENT_DEGREE || agent == BBX_AGENT_FIRST || agent == BBX_AGENT_STDRANDOM || agent == BBX_AGENT_HASH);
+      const bool vfast = b->fast && b->staged;                  // (every selection strategy: bbx_fast.h, f_select_ordered)
       lrc = 0;
       if (vfast) lrc = bbx_launch_step(&p, 3, b->envs_per_block, 0);
       if (b->gen_to_wide) p.spill_terms = 384;

@@ -128,6 +128,16 @@ struct FastState {                 // reducer-order arrays of the first 128 redu
   uint2 sin[FRB];                  // .x = tc | (-tc/lc) << 16 ; .y = sugar | basis index << 16
 };
 
+// The ordering strategies (Normal, Sugar and the reversed ones: buchberger.cpp:160-199 via select_pair, bbx_device.h) on the
+// class's LDS arrays.  Out of line: they are the agents of value() / buchberger() rollouts, not of the timed rollouts, and must
+// not weigh on the step loop's registers (until round 4 these agents ran on the LDS-staged class kernel: value('normal') 3.2 M
+// values/s against 9.1 M for 'degree').
+struct FSelView { const uint32_t* pairs; const Mono<2>* lm; };
+__device__ __attribute__((noinline)) int f_select_ordered(const uint32_t* pairs, const Mono<2>* lm, const uint2* gi, int nP, int agent) {
+  const FSelView v{pairs, lm};
+  return select_pair_inl<2>(v, nP, agent, [gi](int g) { return (int)(gi[g].y >> 16); });
+}
+
 // TRACE: per-step parity hashes (tests).  ACCT: count the algorithmic bytes of every step (roofline numerator;
 // a property of the workload, so the lean production variant leaves it out and bench.py obtains it from an
 // accounting run over a copy of the same batch).
@@ -709,6 +719,7 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem, in
       action = std_choice(x, nP);
       std_rng = x;
     }
+    else if (!HL && agent >= BBX_AGENT_NORMAL && agent <= BBX_AGENT_SPICE) action = uni(f_select_ordered(pairs, lm, gi, nP, agent));
     else {                                                 // degree: first row of minimal deg lcm (buchberger.cpp:171-176)
       uint32_t best = 0xFFFFFFFFu;
       for (int r = lane; r < nP; r += WAVE) {
