@@ -1002,22 +1002,20 @@ int bbx_step_obs(bbx_batch* b, const int32_t* actions, int auto_reset, double* r
     if (rc) return rc;
     if (!b->d_obs_off) HIPCHK(hipMalloc((void**)&b->d_obs_off, ((size_t)b->B + 1) * sizeof(int32_t)));
   }
-  BbxParams p; fill_params(b, &p);
-  p.set_budget = 1; p.agent = BBX_AGENT_EXTERNAL; p.auto_reset = auto_reset ? 1 : 0;
-  if (zc) zc_outputs(b, &p); else { p.rewards = b->d_rewards; p.dones = b->d_dones; p.rows = b->d_rows; }
   if (actions) {
     memcpy(b->h_act, actions, (size_t)b->B * sizeof(int32_t));
-    if (zc) p.actions = b->zc_act_dev;
-    else {
-      HIPCHK(hipMemcpyAsync(b->d_actions, b->h_act, (size_t)b->B * sizeof(int32_t), hipMemcpyHostToDevice, 0));
-      p.actions = b->d_actions;
-    }
-    p.nsteps = 1;
-  } else p.nsteps = 0;                                      // observation of the current state only
+    if (!zc) HIPCHK(hipMemcpyAsync(b->d_actions, b->h_act, (size_t)b->B * sizeof(int32_t), hipMemcpyHostToDevice, 0));
+  }
   for (int attempt = 0;; attempt++) {
+    // (the parameters are formed per attempt: the first one may have enlarged the records — another array, another layout —
+    // and a second attempt with the first one's parameters stepped the freed copy: found by scripts/fuzz_gym.py, round 4)
+    BbxParams p; fill_params(b, &p);
+    p.set_budget = 1; p.agent = BBX_AGENT_EXTERNAL; p.auto_reset = auto_reset ? 1 : 0;
+    if (zc) zc_outputs(b, &p); else { p.rewards = b->d_rewards; p.dones = b->d_dones; p.rows = b->d_rows; }
+    if (actions && !attempt) { p.actions = zc ? b->zc_act_dev : b->d_actions; p.nsteps = 1; }
+    else { p.nsteps = 0; p.actions = nullptr; }             // observation of the current state only / the step is done: only rewrite the observation
     const size_t cap = zc ? b->zobs_rows_cap : b->obs_rows_cap;
     p.obs = zc ? b->zc_obs_dev : b->d_obs; p.obs_rows = (int)cap; p.obs_fill = 0; p.obs_every_step = 0;
-    if (attempt) { p.nsteps = 0; p.actions = nullptr; }     // the step is done: only rewrite the observation
     bool used = false;
     if (!attempt && actions && zc && mbox_eligible(b)) {    // a step of a loop: through the resident kernel's mailbox
       BbxParams q = p;

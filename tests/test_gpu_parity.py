@@ -794,6 +794,44 @@ def test_wide_class_lockstep_stress(waves, lean):
             del env
 
 
+def test_step_with_observation_when_the_records_and_the_observation_block_grow_in_the_same_call():
+    """Found by scripts/fuzz_gym.py (seed 20261, round 1518): a host step (bbx_step_obs) whose step enlarged the records — an
+    intermediate polynomial longer than max_poly_terms — AND left a pair set taller than the observation block of the call.  The
+    second attempt (block enlarged, observation rewritten) ran with the first attempt's parameters: the freed records, whose
+    stale status then drove the growth loop to its 2^22-term limit.  The trajectory of the find, against the oracle: five
+    5-3-3-0.5-uniform environments under LCM elimination, host-supplied actions, finished environments reset now and then."""
+    from deepgroebner_amd import VecLeadMonomialsEnv
+    bo = ffi.load("bo")
+    dist, elim, rew, seed0, B, T, k = "5-3-3-0.5-uniform", "lcm", "additions", 867467, 5, 27, 2
+    arng = np.random.default_rng(seed0)
+    env = VecLeadMonomialsEnv(dist, B, elim, rew, False, True, k, 0, None, "python")
+    env.seed(np.arange(B) + seed0)
+    os_ = []
+    for e in range(B):
+        o = bo.env(dist, elimination=elim, rewards=rew); o.seed(seed0 + e); o.reset(); os_.append(o)
+    obs = env.reset()
+    grown = 0
+    for t in range(T):
+        for e in range(B):
+            assert np.array_equal(obs[e], os_[e].obs(k)), (t, e)
+        acts = np.array([arng.integers(0, max(1, os_[e].nP)) for e in range(B)], dtype=np.int32)
+        live = [os_[e].nP > 0 for e in range(B)]
+        obs, r, d, _ = env.step(acts)
+        mask = np.zeros(B, dtype=np.uint8)
+        for e in range(B):
+            if not live[e]:
+                continue
+            assert r[e] == os_[e].step(int(acts[e])) and bool(d[e]) == (os_[e].nP == 0), (t, e)
+            if os_[e].nP == 0 and arng.random() < 0.7:
+                mask[e] = 1
+        if mask.any():
+            obs = env.reset(mask)
+            for e in np.flatnonzero(mask):
+                os_[e].reset()
+        grown = env.capacities()["grown"]
+    assert grown >= 1 and max(o.nP for o in os_) > 256          # (both happened: the records grew, a pair set passed the first block)
+
+
 def test_kernels_per_call():
     """What a call costs in launches (bbx_kernels_launched): one kernel for a reset (the Python reset() is two calls: the reset
     and the observation it returns), for a host-driven step of a small batch and for a rollout of a class without a
