@@ -31,11 +31,14 @@ for it in range(rounds):
     auto = rng.random() < 0.5
     caps = rng.choice([None, None, {"lds_max_basis": 16}, {"lds_max_basis": -1}, {"general_class": 1}])
     seed0 = rng.randint(0, 10 ** 6)
+    lean = rng.random() < 0.5                            # (lean kernels; with them small batches of the register/LDS class step through host mailbox sessions)
     arng = np.random.default_rng(seed0)
-    tag = "%s k=%d B=%d T=%d elim=%s rewards=%s auto=%d caps=%s seed0=%d" % (dist, k, B, T, elim, rewards, auto, caps, seed0)
+    tag = "%s k=%d B=%d T=%d elim=%s rewards=%s auto=%d caps=%s lean=%d seed0=%d" % (dist, k, B, T, elim, rewards, auto, caps, lean, seed0)
     try:
         env = VecLeadMonomialsEnv(dist, B, elim, rewards, False, True, k, 0, caps, "python")
         env.seed(np.arange(B) + seed0)
+        if lean:
+            env.accounting(False)
         oracles = []
         for e in range(B):
             o = bo.env(dist, elimination=elim, rewards=rewards); o.seed(seed0 + e); o.reset(); oracles.append(o)
