@@ -153,6 +153,14 @@ static int launch_session_begin(bbx_batch* b, const BbxParams& p, hipStream_t st
   if (p.policy) { b->ps_pol = *p.policy; b->ps_p.policy = &b->ps_pol; }
   b->ps_target = p.nsteps; b->ps_active = true; b->ps_sessions++;
   b->ps_recent.clear(); ps_note_steps(b, p.nsteps);
+  // The control word is the handle's, not the session's: the kernels that close the PREVIOUS session (queued on the session
+  // stream, possibly not yet run) still poll it, and a new total written now would be theirs to take — steps of this session
+  // under the last one's agent and buffers (found by scripts/fuzz_sessions.py: two calls of different shapes back to back).
+  // The write therefore waits for everything queued on the session stream so far.
+  if (!b->ps_mbox) {
+    HIPCHK(hipEventRecord(b->ps_ev, b->ps_stream));
+    HIPCHK(hipStreamWaitEvent(b->ps_ctl_stream, b->ps_ev, 0));
+  }
   int rc = ps_write_ctl(b, false);
   if (rc) return rc;
   b->last = p; b->last.ctl = nullptr; b->last.policy = nullptr;

@@ -3,7 +3,7 @@ cd "$GRAFT_REPO_ROOT"
 seed=${1:-1}; secs=${2:-120}
 L=gpurun_out/fuzz_soak_$seed.log
 : > $L
-for f in parity gym policy strategies value wide generators; do
+for f in parity gym policy strategies value wide generators sessions; do
   echo "== fuzz_$f" >> $L
   timeout -k 10 $secs python scripts/fuzz_$f.py 100000 $seed > gpurun_out/fuzz_soak_$f.log 2>&1; rc=$?
   grep -c "^ok" gpurun_out/fuzz_soak_$f.log >> $L

@@ -232,3 +232,37 @@ def test_host_mailbox_session_is_invisible_except_in_time(B, auto_reset):
             if o.nP == 0 and auto_reset:
                 o.reset()
             assert np.array_equal(st[e], o.obs(k))
+
+
+def test_sessions_of_different_shapes_back_to_back():
+    """A call of another shape ends the running session and begins the next one at once.  The control word belongs to the
+    handle: the kernels that close the first session (queued, perhaps not yet run) still poll it, and the next session's step
+    total, written too early, was theirs to take — 6 of the second call's 7 steps under the FIRST call's agent (found by
+    scripts/fuzz_sessions.py).  One step under the random agent, then seven under First, on a batch most of which outgrows a
+    register/LDS class capped at 24 elements: counters and states against a twin without sessions, and against the oracle for
+    the first call alone."""
+    import torch
+    from deepgroebner_amd import VecLeadMonomialsEnv
+    B, k, R = 1000, 2, 512
+    envs = []
+    for persistent in (True, False):
+        e = VecLeadMonomialsEnv("3-10-10-uniform", batch=B, k=k, caps={"lds_max_basis": 24})
+        e.seed(np.arange(B)); e.seed_agent(np.arange(B)); e.reset(); e.accounting(False)
+        if persistent:
+            e.persistent(True)
+        envs.append(e)
+    s = torch.cuda.current_stream().cuda_stream
+    for rep in range(6):                                          # (alternating shapes: every call ends a session and begins one)
+        for e in envs:
+            rew = torch.zeros(B, dtype=torch.float64, device="cuda"); done = torch.zeros(B, dtype=torch.uint8, device="cuda")
+            rows = torch.zeros(B, dtype=torch.int32, device="cuda"); obs = torch.full((B, R, e.cols), -1, dtype=torch.int32, device="cuda")
+            e.rollout_device("random", 1, True, s, rew, done, rows, obs, R, False, False)
+            e.rollout_device("first", 7, True, s, rew, done, rows, None, 0, False, False)
+        for e in envs:
+            e.sync()
+        a, b = envs[0].stats(), envs[1].stats()
+        assert np.array_equal(a[:, 0], b[:, 0]) and (a[:, 0] == 8 * (rep + 1)).all(), (rep, a[:3], b[:3])
+        assert np.array_equal(a[:, :5], b[:, :5]) and np.array_equal(a[:, 7], b[:, 7]), rep
+    for e_ in range(0, B, 97):
+        assert fnv64(_state_words(*envs[0].state(e_))) == fnv64(_state_words(*envs[1].state(e_))), e_
+    assert envs[0].session_stats()["sessions"] >= 12
