@@ -23,11 +23,14 @@ for it in range(rounds):
     caps = rng.choice([None, None, {"lds_max_basis": 16}, {"lds_max_basis": -1}, {"general_class": 1}])
     pre = rng.randint(0, 25)
     seed0 = rng.randint(0, 10 ** 6)
+    lean = rng.random() < 0.5                            # (lean kernels: the host steps of small batches then run through mailbox sessions)
     arng = np.random.default_rng(seed0)
-    tag = "%s k=%d B=%d pre=%d caps=%s seed0=%d" % (dist, k, B, pre, caps, seed0)
+    tag = "%s k=%d B=%d pre=%d caps=%s lean=%d seed0=%d" % (dist, k, B, pre, caps, lean, seed0)
     try:
         env = VecLeadMonomialsEnv(dist, batch=B, k=k, caps=caps)
         env.seed(np.arange(B) + seed0)
+        if lean:
+            env.accounting(False)
         oracles = []
         for e in range(B):
             o = bo.env(dist); o.seed(seed0 + e); o.reset(); oracles.append(o)
