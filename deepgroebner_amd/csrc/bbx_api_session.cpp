@@ -43,12 +43,12 @@ int ps_write_ctl(bbx_batch* b, bool stop) {              // all writes to the co
 // Queue a kernel of the session on its stream: the first one (every environment starts with the steps issued so far) or a
 // later one (every environment takes what it still owes of the total), behind the last write to the control word and
 // behind what the caller queued on `after` (or null).  `sliced`: it leaves when its time slice is over.
-int session_kernel(bbx_batch* b, bool first, hipStream_t after, bool sliced) {
+int session_kernel(bbx_batch* b, bool first, hipStream_t after, bool sliced, bool behind_after) {
   if (!b->ps_mbox) {                                       // (a mailbox session's control word is written by the host, not on a stream)
     HIPCHK(hipEventRecord(b->ps_ev, b->ps_ctl_stream));
     HIPCHK(hipStreamWaitEvent(b->ps_stream, b->ps_ev, 0));
   }
-  if (after) {
+  if (behind_after) {                                      // (`after` may be the NULL stream: the session stream does not wait for it by itself)
     HIPCHK(hipEventRecord(b->ps_ev, after));
     HIPCHK(hipStreamWaitEvent(b->ps_stream, b->ps_ev, 0));
   }
@@ -143,7 +143,7 @@ static int launch_session_join(bbx_batch* b, const BbxParams& p, hipStream_t str
   int rc = ps_write_ctl(b, false);
   if (rc) return rc;
   // the session's kernel may have left meanwhile (its slice was over, or no news for 20 ms): the next one
-  if (hipStreamQuery(b->ps_stream) == hipSuccess) { rc = session_kernel(b, false, stream, true); if (rc) return rc; }
+  if (hipStreamQuery(b->ps_stream) == hipSuccess) { rc = session_kernel(b, false, stream, true, true); if (rc) return rc; }
   b->ps_joined++;
   b->in_flight = true; b->obs_external = obs_external; b->device_async = true;
   return BBX_OK;
@@ -165,7 +165,7 @@ static int launch_session_begin(bbx_batch* b, const BbxParams& p, hipStream_t st
   if (rc) return rc;
   b->last = p; b->last.ctl = nullptr; b->last.policy = nullptr;
   b->policy_rollout = false; b->last_stream = b->ps_stream; b->in_flight = true; b->obs_external = obs_external; b->device_async = true;
-  return session_kernel(b, true, stream, true);
+  return session_kernel(b, true, stream, true, true);
 }
 static int launch_plain(bbx_batch* b, const BbxParams& p, hipStream_t stream, bool obs_external, bool device_async, bool capturing) {
   if (device_async && p.agent == BBX_AGENT_EXTERNAL && p.nsteps >= 1) b->async_chain++;

@@ -147,7 +147,7 @@ int enqueue(bbx_batch* b, const BbxParams& p0, bool resume, hipStream_t stream);
 // bbx_api_session.cpp
 int launch(bbx_batch* b, BbxParams& p, hipStream_t stream, bool obs_external = false, bool device_async = false);
 int ps_write_ctl(bbx_batch* b, bool stop);
-int session_kernel(bbx_batch* b, bool first, hipStream_t after, bool sliced);
+int session_kernel(bbx_batch* b, bool first, hipStream_t after, bool sliced, bool behind_after = false);   // behind_after: ordered behind what `after` (possibly the NULL stream) holds
 int session_close(bbx_batch* b, bool wait, hipStream_t then, bool sliced);
 bool session_same_call(const BbxParams& a, const BbxParams& c);
 bool mbox_eligible(const bbx_batch* b);

@@ -520,6 +520,13 @@ __device__ __forceinline__ void binom_body(const BbxParams& p_entry, char* smem,
         break;
       }
       need_reset = 0; episode_steps = 0; obs_live = false;
+      if constexpr (POL > 0) {
+        // (per-step policy calls served by a session: the block the caller finds afterwards is the NEW episode's — bbx_fast.h)
+        if (pol->post_obs) {
+          if (p.obs) { bin_obs<W, false>(e, p, env, nP, true, false, nullptr); obs_trunc |= nP > p.obs_rows ? 1 : 0; }
+          if (lane == 0 && pol->rows_t) pol->rows_t[env] = nP;
+        }
+      }
     }
     if (budget <= 0) break;
     if (nP == 0) break;

@@ -614,6 +614,16 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem, in
       }
       if (!ok) { if (status != BBX_ST_STARVED) { nG = 0; nP = 0; } break; }
       need_reset = 0;
+      if constexpr (POL > 0 && PERSIST) {
+        // per-step policy calls served by a session (bbx_policy_step_device): the block and the row count the caller finds when
+        // the session ends are those of the NEW episode, as after a launch per step — the step that ended the episode wrote the
+        // state it left (no rows), and within the session nobody reads the block (found by scripts/fuzz_sessions.py)
+        const FColdPolicy polr = f_cold_policy();
+        if (polr->post_obs) {
+          if (p.obs) { write_obs32(); obs_trunc |= nP > p.obs_rows ? 1 : 0; }
+          if (lane == 0 && polr->rows_t) polr->rows_t[env] = nP;
+        }
+      }
     }
     FSTAMP(0);                                             // 0: loop top / reset
     if constexpr (PERSIST && POL == 0 && !HL) {

@@ -9,6 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 from deepgroebner_amd import VecLeadMonomialsEnv
+from deepgroebner_amd.rollout import PMLPPolicy
 
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -41,6 +42,16 @@ for it in range(rounds):
     for _ in envs:
         bufs.append({"rew": torch.zeros(B, dtype=torch.float64, device="cuda"), "done": torch.zeros(B, dtype=torch.uint8, device="cuda"),
                      "rows": torch.zeros(B, dtype=torch.int32, device="cuda"), "obs": torch.full((B, R, envs[0].cols), -1, dtype=torch.int32, device="cuda")})
+    torch.manual_seed(seed * 1000 + it)
+    policy = PMLPPolicy(envs[0].cols, [rng.choice([32, 64, 100, 128])]).cuda()
+    with torch.no_grad():
+        for lin in list(policy.embedding) + [policy.deciding]:
+            lin.weight.mul_(0.3)
+    pw = policy._fused_weights()
+    U = torch.rand((64, B), device="cuda")
+    for bf in bufs:
+        bf["act"] = torch.zeros(B, dtype=torch.int32, device="cuda"); bf["logp"] = torch.zeros(B, dtype=torch.float32, device="cuda")
+    u_at = 0
     side = torch.cuda.Stream()
     stream = torch.cuda.current_stream()
     shape = None                                            # (agent, K, obs mode) of the running sequence of calls
@@ -67,8 +78,8 @@ for it in range(rounds):
     nops = rng.randint(4, 14)
     del oplog[:]
     for op_i in range(nops):
-        op = rng.choice(["roll", "roll", "roll", "roll", "newshape", "hoststep", "reset", "copy", "read", "join", "sync"])
-        if op == "newshape" or shape is None:
+        op = rng.choice(["roll", "roll", "roll", "roll", "newshape", "hoststep", "reset", "copy", "read", "join", "sync", "pol", "pol"])
+        if op == "newshape" or (shape is None and op in ("roll", "sync")):
             shape = (rng.choice(["random", "degree", "first"]), rng.choice([1, 7, 64, 300]), rng.choice([0, 1, 2]))
             op = "roll"
         oplog.append(op + (" %s K=%d obs=%d" % shape if op == "roll" else ""))
@@ -76,6 +87,32 @@ for it in range(rounds):
             agent, K, om = shape
             for e, bf in zip(envs, bufs):
                 e.rollout_device(agent, K, True, stream.cuda_stream, bf["rew"], bf["done"], bf["rows"], bf["obs"] if om else None, R if om else 0, False, om == 2)
+        elif op == "pol":                                      # per-step calls of the one-layer policy: they join sessions of their own
+            n = rng.choice([1, 3, 20])
+            if u_at + n > U.shape[0]:
+                continue
+            for e, bf in zip(envs, bufs):                       # (the policy reads the block the call before it left: write it first)
+                e.rollout_device("first", 0, False, stream.cuda_stream, bf["rew"], bf["done"], bf["rows"], bf["obs"], R, True, False)
+            if os.environ.get("FUZZ_DEBUG") and it == int(os.environ["FUZZ_DEBUG"]):
+                for e in envs: e.sync()
+                print("debug op %d: after the observation call: rew[0:4] %s / %s; stats %s" % (op_i, bufs[0]["rew"][:4].tolist(), bufs[1]["rew"][:4].tolist(), envs[0].session_stats()), flush=True)
+            for t in range(n):
+                for e, bf in zip(envs, bufs):
+                    e.policy_step_device(pw["prepared"], pw["hidden"], U[u_at + t], bf["act"], bf["logp"], bf["rew"], bf["done"], bf["rows"], bf["obs"], R, 2, stream.cuda_stream)
+            u_at += n
+            ok = compare("policy steps, op %d" % op_i)
+            if ok:
+                for key in ("act", "logp", "rew", "done", "rows"):
+                    if not torch.equal(bufs[0][key], bufs[1][key]):
+                        bad = torch.nonzero(bufs[0][key] != bufs[1][key]).flatten()[:6].tolist()
+                        fail("%s: policy output %s after op %d (n=%d): envs %s session %s twin %s; host rows %s / %s; done %s / %s" % (
+                            tag, key, op_i, n, bad, bufs[0][key][bad].tolist(), bufs[1][key][bad].tolist(), envs[0].rows[bad].tolist(), envs[1].rows[bad].tolist(),
+                            bufs[0]["done"][bad].tolist(), bufs[1]["done"][bad].tolist()) + " | session stats %s | steps taken %s / %s" % (
+                            envs[0].session_stats(), envs[0].stats()[bad, 0].tolist(), envs[1].stats()[bad, 0].tolist()))
+                live = torch.arange(R, device="cuda")[None, :] < bufs[0]["rows"][:, None]
+                if not torch.equal(bufs[0]["obs"][live], bufs[1]["obs"][live]):
+                    fail("%s: observation rows after policy steps, op %d" % (tag, op_i))
+            shape = None
         elif op == "join":
             envs[0].join(side.cuda_stream)
             side.synchronize()

@@ -266,3 +266,40 @@ def test_sessions_of_different_shapes_back_to_back():
     for e_ in range(0, B, 97):
         assert fnv64(_state_words(*envs[0].state(e_))) == fnv64(_state_words(*envs[1].state(e_))), e_
     assert envs[0].session_stats()["sessions"] >= 12
+
+
+def test_policy_step_session_leaves_the_new_episodes_block():
+    """bbx_policy_step_device with auto-reset: the observation block and row counts the call leaves describe the NEW episode of an
+    environment whose episode the step ended.  Served by a session, the step wrote the block of the state it left (no rows) and
+    the reset at the top of the next loop iteration wrote nothing — within the session nobody reads the block, but the caller
+    does when the session ends (found by scripts/fuzz_sessions.py; both the register/LDS class and the HBM-resident continuation
+    of a class capped at 16 basis elements).  After every call: the block against a fresh observation of the state."""
+    import torch
+    from deepgroebner_amd import VecLeadMonomialsEnv
+    from deepgroebner_amd.rollout import PMLPPolicy
+    B, R, k = 64, 512, 2
+    env = VecLeadMonomialsEnv("3-3-7-uniform", batch=B, k=k, caps={"lds_max_basis": 16})
+    env.seed(np.arange(B) + 51); env.seed_agent(np.arange(B) + 3); env.reset(); env.accounting(False)
+    env.persistent(True)
+    torch.manual_seed(5003)
+    policy = PMLPPolicy(env.cols, [64]).cuda()
+    pw = policy._fused_weights()
+    s = torch.cuda.current_stream().cuda_stream
+    def bufs():
+        return (torch.zeros(B, dtype=torch.float64, device="cuda"), torch.zeros(B, dtype=torch.uint8, device="cuda"),
+                torch.zeros(B, dtype=torch.int32, device="cuda"), torch.full((B, R, env.cols), -1, dtype=torch.int32, device="cuda"))
+    rew, done, rows, obs = bufs()
+    rew2, done2, rows2, obs2 = bufs()
+    act = torch.zeros(B, dtype=torch.int32, device="cuda"); logp = torch.zeros(B, dtype=torch.float32, device="cuda")
+    U = torch.rand((120, B), device="cuda")
+    env.rollout_device("first", 0, False, s, rew, done, rows, obs, R, True, False); env.sync()
+    ended = 0
+    for t in range(120):
+        env.policy_step_device(pw["prepared"], pw["hidden"], U[t], act, logp, rew, done, rows, obs, R, 2, s)
+        env.sync()
+        ended += int(done.sum())
+        env.rollout_device("first", 0, False, s, rew2, done2, rows2, obs2, R, True, False); env.sync()
+        assert torch.equal(rows, rows2), t
+        live = torch.arange(R, device="cuda")[None, :] < rows2[:, None]
+        assert torch.equal(obs[live], obs2[live]), t
+    assert ended > 50                                           # (episodes did end inside the calls)
