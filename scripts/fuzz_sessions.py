@@ -78,7 +78,7 @@ for it in range(rounds):
     nops = rng.randint(4, 14)
     del oplog[:]
     for op_i in range(nops):
-        op = rng.choice(["roll", "roll", "roll", "roll", "newshape", "hoststep", "reset", "copy", "read", "join", "sync", "pol", "pol"])
+        op = rng.choice(["roll", "roll", "roll", "roll", "newshape", "hoststep", "reset", "copy", "read", "join", "sync", "pol", "pol", "stepdev", "value"])
         if op == "newshape" or (shape is None and op in ("roll", "sync")):
             shape = (rng.choice(["random", "degree", "first"]), rng.choice([1, 7, 64, 300]), rng.choice([0, 1, 2]))
             op = "roll"
@@ -113,6 +113,29 @@ for it in range(rounds):
                 if not torch.equal(bufs[0]["obs"][live], bufs[1]["obs"][live]):
                     fail("%s: observation rows after policy steps, op %d" % (tag, op_i))
             shape = None
+        elif op == "stepdev":                                  # caller-supplied actions from a device buffer: launches of their own, behind the session
+            n = rng.choice([1, 4])
+            zero = torch.zeros(B, dtype=torch.int32, device="cuda")
+            for t in range(n):
+                for e, bf in zip(envs, bufs):
+                    e.step_device(zero, bf["rew"], bf["done"], bf["rows"], bf["obs"], R, 1, stream.cuda_stream, auto_reset=True)
+            ok = compare("device steps, op %d" % op_i)
+            if ok:
+                for key in ("rew", "done", "rows"):
+                    if not torch.equal(bufs[0][key], bufs[1][key]):
+                        fail("%s: output %s after device steps, op %d" % (tag, key, op_i))
+                live = torch.arange(R, device="cuda")[None, :] < bufs[0]["rows"][:, None]
+                if not torch.equal(bufs[0]["obs"][live], bufs[1]["obs"][live]):
+                    fail("%s: observation rows after device steps, op %d" % (tag, op_i))
+            shape = None
+        elif op == "value":
+            try:
+                v0, v1 = envs[0].values("degree", 0.99), envs[1].values("degree", 0.99)
+            except Exception:
+                compare("after a value() that raised, op %d" % op_i)
+                continue
+            if not np.array_equal(np.asarray(v0), np.asarray(v1)):
+                fail("%s: value() at op %d" % (tag, op_i))
         elif op == "join":
             envs[0].join(side.cuda_stream)
             side.synchronize()
