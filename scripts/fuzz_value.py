@@ -50,6 +50,14 @@ for it in range(rounds):
                 want = oracles[e].value(strategy, gamma)
                 if got[e] != want:
                     print("MISMATCH %s: value(%s, %s) of env %d: device %r oracle %r" % (tag, strategy, gamma, e, got[e], want)); sys.exit(1)
+        # in-batch clones (a tree search's node pool): environment src[i] over dst[i]; both continue alike afterwards
+        if B >= 4 and rng.random() < 0.6:
+            nc = rng.randint(1, B // 2)
+            perm = list(range(B)); rng.shuffle(perm)
+            src, dst = perm[:nc], perm[nc:2 * nc]
+            env.clone_envs(src, dst)
+            for a, b2 in zip(src, dst):
+                oracles[b2] = oracles[a].copy()
         # value() must not disturb the environments; a copy continues like the original
         twin = env.copy()
         for t in range(8):
