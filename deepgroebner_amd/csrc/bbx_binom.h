@@ -488,7 +488,7 @@ __device__ __forceinline__ void binom_body(const BbxParams& p_entry, char* smem,
   else e = STAGED ? benv_view<W>(smem + (size_t)wave_in_block * L.rec_bytes, L) : ge;
   if (CACHE && status == BBX_ST_OK) benv_load_cache(e, nG, nP);
   bool staged_in = false;
-  if (STAGED && status == BBX_ST_OK) {
+  if (STAGED && status == BBX_ST_OK && !(!need_reset && nP == 0)) {   // (an idle environment is not staged: bbx_fast.h, idle0)
     if (nG > (int)L.maxG || nP > (int)L.maxP) status = BBX_ST_SPILL;
     else { if constexpr (STAGED) bstage_copy<W>(e, ge, nG, nP); staged_in = true; wave_sync(); }
   }

@@ -230,7 +230,11 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem, in
   clear_reducers();
   f_banks<FRB>([&](auto b_) { constexpr int b = decltype(b_)::value; S.stm[b] = m_zero<2>(); S.sin[b] = make_uint2(0, 0); });
   bool staged_in = false;
-  if (status == BBX_ST_OK) {
+  // (an environment with nothing to do in this launch — its episode is over and no reset is due — is not staged, whatever its
+  // size: handing it to the HBM-resident pass, which has nothing to do for it either, left its outputs unwritten and a host
+  // step returned the previous call's row count / reward / done flag for it: found by scripts/fuzz_gym.py)
+  const bool idle0 = !PERSIST && !need_reset && nP == 0;
+  if (status == BBX_ST_OK && !idle0) {
     if (nG > limG || nP > limP) status = BBX_ST_SPILL;
     else {
       F_HBM_PTRS(&p)
@@ -1170,9 +1174,14 @@ __device__ __forceinline__ void fast_body(const BbxFastParams& p, char* smem, in
       if (seq) {                                       // the word the host watches goes last and alone, behind a system-scope fence
         // (a mailbox session: bit 30 of the budget word says "this wave has left and stored its environment" — what the host
         // waits for when it closes the session, instead of the runtime's completion signal)
-        lw[1] = q_head; lw[2] = (PERSIST && cz->mbox) ? (budget | 0x40000000) : budget; lw[3] = nP;
+        lw[1] = q_head; lw[2] = budget; lw[3] = nP;
         __threadfence_system();
         __hip_atomic_store(lw, word0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        // (the mark is this wave's LAST store: the host, seeing it, clears the status words and may begin the next session at once —
+        // a status word arriving behind the mark carried this session's last sequence number into the next one, where a session of
+        // one step has the number the next session's first step waits for: the host then returned the OLD step's outputs.  Found
+        // by scripts/fuzz_gym.py mixing bbx_step_obs and bbx_step calls.)
+        if (PERSIST && cz->mbox) __hip_atomic_store(lw + 2, budget | 0x40000000, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
       } else *(int4*)lw = make_int4(word0, q_head, budget, nP);
     }
   }

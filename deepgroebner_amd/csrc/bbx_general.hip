@@ -40,7 +40,7 @@ __device__ __forceinline__ void step_body(const BbxParams& p, char* smem, unsign
   Env<W> e = STAGED ? env_view<W>(smem + (size_t)wave_in_block * L.rec_bytes, L) : ge;
   bool staged_in = false;
   if (STAGED) {
-    if (status == BBX_ST_OK) {
+    if (status == BBX_ST_OK && !(!need_reset && nP == 0)) {   // (an idle environment is not staged: bbx_fast.h, idle0)
       if (nG > (int)L.maxG || nP > (int)L.maxP || arena_used > (int)L.arena) status = BBX_ST_SPILL;
       else {
         stage_copy<W>(e, ge, nG, nP, arena_used);

@@ -4,7 +4,7 @@ reward and done flag against the CPU restatement's environment objects.   python
 import os, sys, random, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-from deepgroebner_amd import CLeadMonomialsEnv, LeadMonomialsEnv, VecLeadMonomialsEnv
+from deepgroebner_amd import CLeadMonomialsEnv, LeadMonomialsEnv, VecLeadMonomialsEnv, _ffi
 from oracle import ffi
 
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 30
@@ -43,15 +43,29 @@ for it in range(rounds):
         for e in range(B):
             o = bo.env(dist, elimination=elim, rewards=rewards); o.seed(seed0 + e); o.reset(); oracles.append(o)
         obs = env.reset()
+        how = "reset"
+        hist = []
         for t in range(T):
             for e in range(B):
                 if not np.array_equal(obs[e], oracles[e].obs(k)):
-                    fail(tag + ": observation of env %d at step %d" % (e, t))
+                    w = oracles[e].obs(k)
+                    fail(tag + ": observation of env %d at step %d (last step through %s): device %s %s oracle %s %s rows %s" % (
+                        e, t, how, np.asarray(obs[e]).shape, np.asarray(obs[e])[:2].tolist(), w.shape, w[:2].tolist(), env.rows.tolist()))
             acts = np.array([arng.integers(0, max(1, oracles[e].nP)) for e in range(B)], dtype=np.int32)
             live = [oracles[e].nP > 0 for e in range(B)]
             if not any(live):
                 break
-            if auto:
+            how = "env.step"
+            hist.append(0)
+            if rng.random() < 0.3:                             # the C ABI's two-call form: bbx_step(_autoreset), then bbx_obs (padded block)
+                r = np.zeros(B); dn = np.zeros(B, dtype=np.uint8)
+                fn = _ffi.lib().bbx_step_autoreset if auto else _ffi.lib().bbx_step
+                _ffi.check(fn(env._h, _ffi.ptr(acts), _ffi.ptr(r), _ffi.ptr(dn), _ffi.ptr(env.rows)))
+                d = dn.astype(bool)
+                obs = env.observations()
+                how = "bbx_step + bbx_obs"
+                hist[-1] = 1
+            elif auto:
                 obs, r, d, _ = env.step(acts, auto_reset=True)
             else:
                 obs, r, d, _ = env.step(acts)
@@ -62,7 +76,7 @@ for it in range(rounds):
                 want_r = oracles[e].step(int(acts[e]))
                 done = oracles[e].nP == 0
                 if r[e] != want_r or bool(d[e]) != done:
-                    fail(tag + ": reward/done of env %d at step %d: device (%s, %s) oracle (%s, %s)" % (e, t, r[e], d[e], want_r, done))
+                    fail(tag + ": reward/done of env %d at step %d (through %s; the steps before: %s): device (%s, %s) oracle (%s, %s); session stats %s" % (e, t, how, hist[-8:], r[e], d[e], want_r, done, env.session_stats()))
                 if done:
                     if auto:
                         oracles[e].reset()

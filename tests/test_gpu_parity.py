@@ -1271,3 +1271,29 @@ def test_full_size_cyclic7_vs_oracle(lean):
     scripts/bench_configs.py times; accounting: the eagerly merged one whose byte counter feeds the roofline): counters of
     all environments, the complete final state of every 64th."""
     _full_size("cyclic-7", 512, 128, 2, 6, bool(lean), 1024, 64)
+
+
+def test_host_step_outputs_of_a_finished_environment_too_large_for_the_register_class():
+    """Found by scripts/fuzz_gym.py: bbx_step on a batch in which one environment has finished its episode (no auto-reset) with
+    a basis beyond the register/LDS class's capacity.  The class's kernel handed it to the HBM-resident pass, which had nothing
+    to do for it either — nobody wrote its outputs, and the call returned the PREVIOUS call's row count, reward and done flag for
+    it.  An environment with nothing to do is no longer handed over."""
+    from deepgroebner_amd import VecLeadMonomialsEnv, _ffi
+    B, k = 16, 2
+    env = VecLeadMonomialsEnv("3-8-6-uniform", batch=B, k=k, caps={"lds_max_basis": 16})
+    env.seed(np.arange(B) + 50965); env.reset()
+    L = _ffi.lib()
+    acts = np.zeros(B, dtype=np.int32)
+    seen = 0
+    for t in range(400):
+        rew = np.full(B, 7.0); done = np.full(B, 9, dtype=np.uint8); rows = np.full(B, -5, dtype=np.int32)
+        finished_before = env.rows == 0
+        _ffi.check(L.bbx_step(env._h, _ffi.ptr(acts), _ffi.ptr(rew), _ffi.ptr(done), _ffi.ptr(rows)))
+        st = env.stats()
+        big = finished_before & (st[:, 7] > 16)
+        assert (rows[finished_before] == 0).all() and (done[finished_before] == 1).all() and (rew[finished_before] == 0.0).all(), (t, rows, done, rew)
+        seen += int(big.sum())
+        env.rows[:] = rows
+        if finished_before.all():
+            break
+    assert seen > 0                                            # (the case occurred: a finished environment with more than 16 basis elements)
