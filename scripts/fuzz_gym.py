@@ -51,6 +51,12 @@ for it in range(rounds):
                     w = oracles[e].obs(k)
                     fail(tag + ": observation of env %d at step %d (last step through %s): device %s %s oracle %s %s rows %s" % (
                         e, t, how, np.asarray(obs[e]).shape, np.asarray(obs[e])[:2].tolist(), w.shape, w[:2].tolist(), env.rows.tolist()))
+            if n <= 3 and B <= 5 and elim == "gebauermoeller" and dist.count("-") == 3 and rng.random() < 0.08:
+                # value() between the steps of a loop (pg.py:461-465 with --value_model degree): ends a mailbox session, runs clones
+                got = env.values("degree", 0.99)
+                for e in range(B):
+                    if oracles[e].nP > 0 and got[e] != oracles[e].value("degree", 0.99):
+                        fail(tag + ": value() of env %d at step %d: device %r oracle %r" % (e, t, got[e], oracles[e].value("degree", 0.99)))
             acts = np.array([arng.integers(0, max(1, oracles[e].nP)) for e in range(B)], dtype=np.int32)
             live = [oracles[e].nP > 0 for e in range(B)]
             if not any(live):
