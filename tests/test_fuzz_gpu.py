@@ -21,6 +21,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     ("fuzz_value.py", 150, 306, {}),
     ("fuzz_policy.py", 60, 307, {}),
     ("fuzz_strategies.py", 150, 308, {}),
+    ("fuzz_sessions.py", 300, 309, {}),                        # persistent sessions against a twin without them
 ])
 def test_fuzz_slice(script, rounds, seed, env):
     p = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", script), str(rounds), str(seed)], cwd=ROOT,
